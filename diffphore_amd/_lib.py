@@ -1,0 +1,89 @@
+"""ctypes binding of libdiffphore_hip.so (C ABI: include/diffphore_amd.h).  No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdiffphore_hip.so")
+
+c_i32 = C.c_int32
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+VOIDP = C.c_void_p
+
+DP_ABI_VERSION = 1
+
+CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
+EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER = range(4)
+
+
+class DpConvArgs(C.Structure):
+    _fields_ = [
+        ("kind", c_i32), ("mode", c_i32), ("B", c_i32), ("slices", c_i32),
+        ("scat_ptr", VOIDP), ("lig_ptr", VOIDP), ("ph_ptr", VOIDP), ("x_ptr", VOIDP),
+        ("rowptr", VOIDP), ("rowend", VOIDP), ("nbr", VOIDP),
+        ("gather_tab", VOIDP), ("gather_stride", c_i32),
+        ("attr1_tab", VOIDP), ("attr1_stride", c_i32),
+        ("attr2_tab", VOIDP), ("attr2_stride", c_i32), ("attr_swap", c_i32),
+        ("edge_emb", VOIDP), ("edge_sh", VOIDP), ("sh_stride", c_i32),
+        ("w1p", VOIDP), ("w2p", VOIDP), ("bn_scale", VOIDP), ("bn_shift", VOIDP),
+        ("out", VOIDP), ("out_stride", c_i32), ("accumulate", c_i32),
+        ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32),
+    ]
+
+
+class DiffPhoreLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the HIP library; raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DiffPhoreLibraryError(
+                f"{LIB_PATH} not found: build it with `python diffphore_amd/csrc/build.py` "
+                "(there is no CPU / PyTorch fallback for the DiffPhore hot path)")
+        L = C.CDLL(LIB_PATH)
+        L.dp_abi_version.restype = C.c_int
+        if L.dp_abi_version() != DP_ABI_VERSION:
+            raise DiffPhoreLibraryError(f"ABI mismatch: library {L.dp_abi_version()} != binding {DP_ABI_VERSION}")
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def _declare(L):
+    L.dp_tp_conv.argtypes = [C.POINTER(DpConvArgs), VOIDP]
+    L.dp_tp_conv.restype = C.c_int
+    L.dp_conv_w1p_floats.argtypes = [c_i32]
+    L.dp_conv_w1p_floats.restype = C.c_int
+    L.dp_conv_w2p_floats.argtypes = [c_i32]
+    L.dp_conv_w2p_floats.restype = C.c_int
+    L.dp_conv_dims.argtypes = [c_i32] + [c_i32p] * 5
+    L.dp_conv_dims.restype = C.c_int
+    L.dp_pack_conv_weights.argtypes = [c_i32, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP]
+    L.dp_pack_conv_weights.restype = C.c_int
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise DiffPhoreLibraryError(f"{what} failed with code {rc}" + (" (bad argument)" if rc == -1 else ""))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor passed to the C ABI must be contiguous"
+    return t.data_ptr()
+
+
+def conv_dims(kind: int):
+    v = [c_i32() for _ in range(5)]
+    check(lib().dp_conv_dims(kind, *[C.byref(x) for x in v]), "dp_conv_dims")
+    return dict(zip(("d_in", "d_out", "numel", "n_attr", "hidden"), (x.value for x in v)))

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Build libdiffphore_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  In-tree output so it ships with gpurun."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "libdiffphore_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
+
+
+def _stale(objs_src):
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = objs_src + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = sorted(glob.glob(os.path.join(HERE, "*.hip")))
+    if not srcs:
+        raise RuntimeError("no .hip sources found")
+    if not force and not _stale(srcs):
+        return OUT
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(
+                [os.path.getmtime(s)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(HERE, "*.h"))]
+                + [os.path.getmtime(h) for h in glob.glob(os.path.join(HERE, "..", "..", "include", "*.h"))]):
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

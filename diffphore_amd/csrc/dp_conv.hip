@@ -1,0 +1,536 @@
+// dp_conv.hip - fused tensor-product convolution for gfx950 (MI355X).
+//
+// One launch = one TensorProductConvLayer.forward of the reference (score_model_phore.py:134-149):
+//     w   = fc(edge_attr_)                      Linear(N_ATTR->HID), ReLU, Linear(HID->numel)      [never materialised]
+//     msg = tp(node_attr[edge_dst], edge_sh, w) e3nn FullyConnectedTensorProduct, per-edge weights
+//     out = scatter_mean(msg, edge_src) ; out = BatchNorm_eval(out) ; (+ residual stream)
+//
+// Mapping to CDNA4
+//   * a wave owns 32 edges (the N dimension of v_mfma_f32_32x32x2_f32); lanes l and l+32 share edge l&31.
+//   * GEMM1  hidden[64 x 32 edges] = W1p[64 x K1] * attr[K1 x 32]          (2 x k1 MFMAs)
+//     its D registers ARE the B operand of GEMM2 (K index permuted at pack time so no lane movement is needed).
+//   * GEMM2  per 32-row weight tile: Wt[32 x 32 edges] = W2p[32 x K2] * hidden[K2 x 32]   (K2 MFMAs of 64 cycles)
+//     rows of a tile are 16 "triples" (path, in-channel pair q, out channel w) x 2 lane halves; half h holds
+//     in-channel u = h*mul_in/2 + q.  The per-edge weight therefore lives in a register for exactly one use.
+//   * contraction on the VALU: acc[out_off + w*d + k] += Wt * z(path, u, k), z = CG-contracted gathered input x sh
+//     (path coefficient and CG norm folded into W2p).  Fully unrolled: every register index is static.
+//   * halves are summed with one ds_swizzle/shfl, messages staged in LDS, a per-workgroup ordered segmented sum
+//     reduces edges (sorted by scatter node) into LDS node accumulators -> mean -> BN affine -> global.
+//   The [E, numel] weight tensor of the reference (2.4-8.8 KB per edge) never exists in memory.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+
+#include "../../include/diffphore_amd.h"
+#include "dp_spec.h"
+
+namespace dp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVES = 4;            // waves per workgroup
+constexpr int CHUNK = WAVES * 32;   // edges per workgroup iteration
+constexpr int MAX_NODES = 64;       // scatter nodes per workgroup (host picks `slices` accordingly)
+
+template <int KIND> struct Geo {
+  using S = Spec<KIND>;
+  static constexpr int K1 = k1_steps<KIND>();
+  static constexpr int K1P = k1_steps_pad<KIND>();
+  static constexpr int K2 = k2_steps<KIND>();
+  static constexpr int NT = n_tiles<KIND>();
+  static constexpr int NTRI = n_triples<KIND>();
+  static constexpr int ABLK = S::N_ATTR / 20;        // attr blocks of 20 (edge emb, attr1, attr2)
+  static constexpr int W1P_FLOATS = 2 * K1P * 64;
+  static constexpr int W2P_FLOATS = NT * K2 * 64;
+  static constexpr int MSG_LD = S::D_OUT + 1;        // +1: conflict-free column reads in the segmented sum
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side packing (single source of truth for the operand layouts the kernel assumes)
+// ---------------------------------------------------------------------------------------------------------------
+// attr index k consumed by lane half `half` at GEMM1 K-step s:   block = s/10 ; k = block*20 + half*10 + s%10
+// (each lane reads 10 contiguous floats per 20-float attr block).  Last real step: bias (half 0) / zero (half 1).
+template <int KIND> void pack_w1(const float* fc0_w, const float* fc0_b, float* w1p) {
+  using G = Geo<KIND>;
+  using S = Spec<KIND>;
+  for (int i = 0; i < G::W1P_FLOATS; ++i) w1p[i] = 0.f;
+  for (int t = 0; t < 2; ++t)
+    for (int s = 0; s < G::K1; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        int row = t * 32 + (lane & 31), half = lane >> 5;
+        float v = 0.f;
+        if (s < S::N_ATTR / 2) {
+          int k = (s / 10) * 20 + half * 10 + (s % 10);
+          if (row < S::HID) v = fc0_w[row * S::N_ATTR + k];
+        } else if (half == 0) {                       // bias step: attr value 1.0
+          if (row < S::HID) v = fc0_b[row];
+          else if (row == S::HID) v = 1.f;            // constant-one hidden unit that carries fc.3's bias through GEMM2
+        }
+        // layout [t][s/4][lane][s%4]  -> one dwordx4 per lane per 4 MFMAs
+        w1p[((t * (G::K1P / 4) + s / 4) * 64 + lane) * 4 + (s & 3)] = v;
+      }
+}
+
+template <int KIND> void pack_w2(const float* fc3_w, const float* fc3_b, float* w2p) {
+  using G = Geo<KIND>;
+  using S = Spec<KIND>;
+  for (int i = 0; i < G::W2P_FLOATS; ++i) w2p[i] = 0.f;
+  for (int tile = 0; tile < G::NT; ++tile)
+    for (int sg = 0; sg < G::K2; ++sg)
+      for (int lane = 0; lane < 64; ++lane) {
+        int c = lane & 31, half = lane >> 5;           // c = D row of the tile this lane's A operand feeds
+        int r = (c & 3) + 4 * (c >> 3), chalf = (c >> 2) & 1;
+        int n = tile * 16 + r;
+        Triple tr = triple_at<KIND>(n);
+        float v = 0.f;
+        if (tr.valid) {
+          const PathC& p = S::P[tr.p];
+          int u = chalf * (p.mul_in / 2) + tr.q;
+          int widx = p.w_off + u * p.mul_out + tr.w;
+          double scale = __builtin_sqrt((double)(2 * (d_out_of(p.ztype) == 3 ? 1 : 0) + 1) / (double)p.fan_in) * cg_const(p.ztype);
+          int hrow = hid_row(sg, half);
+          if (hrow < S::HID) v = (float)(scale * (double)fc3_w[widx * S::HID + hrow]);
+          else if (hrow == S::HID) v = (float)(scale * (double)fc3_b[widx]);
+        }
+        w2p[((tile * (G::K2 / 4) + sg / 4) * 64 + lane) * 4 + (sg & 3)] = v;
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+struct EdgeRef {
+  int scat_local;   // scatter node index within the workgroup's node range, -1 = padding slot
+  int gather;       // row in gather_tab
+  int a1, a2;       // rows in attr1_tab / attr2_tab
+  int feat;         // row in edge_emb / edge_sh
+};
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) vf4* gptr4;   // global (not flat) pointer to packed weights
+
+template <int KIND> constexpr int NACC = n_acc<KIND>() > 0 ? n_acc<KIND>() : 1;
+
+template <int KIND, int N>
+__device__ __forceinline__ void contract_one(float wv, const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
+                                             const float (&M)[9], float (&acc)[NACC<KIND>]) {
+  constexpr Triple T = triple_at<KIND>(N);
+  if constexpr (T.valid) {
+    constexpr PathC p = Spec<KIND>::P[T.p];
+    constexpr int din = d_in_of(p.ztype);
+    constexpr int xo = p.in_off / 2 + T.q * din;      // this half's slice of the in-slot starts at in_off/2
+    constexpr int co = compact_off<KIND>(T.p);        // accumulator base of the out slot within its phase
+    if constexpr (p.ztype == Z000) {
+      acc[co + T.w] += wv * (xr[xo] * sh[p.sh_off]);
+    } else if constexpr (p.ztype == Z011) {
+      const float t = wv * xr[xo];
+      acc[co + 3 * T.w + 0] += t * sh[p.sh_off + 0];
+      acc[co + 3 * T.w + 1] += t * sh[p.sh_off + 1];
+      acc[co + 3 * T.w + 2] += t * sh[p.sh_off + 2];
+    } else if constexpr (p.ztype == Z101) {
+      const float t = wv * sh[p.sh_off];
+      acc[co + 3 * T.w + 0] += t * xr[xo + 0];
+      acc[co + 3 * T.w + 1] += t * xr[xo + 1];
+      acc[co + 3 * T.w + 2] += t * xr[xo + 2];
+    } else if constexpr (p.ztype == Z110) {
+      const float d = xr[xo] * sh[p.sh_off] + xr[xo + 1] * sh[p.sh_off + 1] + xr[xo + 2] * sh[p.sh_off + 2];
+      acc[co + T.w] += wv * d;
+    } else if constexpr (p.ztype == Z111) {
+      const float a0 = xr[xo], a1 = xr[xo + 1], a2 = xr[xo + 2];
+      const float b0 = sh[p.sh_off], b1 = sh[p.sh_off + 1], b2 = sh[p.sh_off + 2];
+      acc[co + 3 * T.w + 0] += wv * (a1 * b2 - a2 * b1);
+      acc[co + 3 * T.w + 1] += wv * (a2 * b0 - a0 * b2);
+      acc[co + 3 * T.w + 2] += wv * (a0 * b1 - a1 * b0);
+    } else {  // Z121: z[k] = sum_i x[i] M[i][k], M symmetric
+      const float a0 = xr[xo], a1 = xr[xo + 1], a2 = xr[xo + 2];
+      acc[co + 3 * T.w + 0] += wv * (a0 * M[0] + a1 * M[3] + a2 * M[6]);
+      acc[co + 3 * T.w + 1] += wv * (a0 * M[1] + a1 * M[4] + a2 * M[7]);
+      acc[co + 3 * T.w + 2] += wv * (a0 * M[2] + a1 * M[5] + a2 * M[8]);
+    }
+    // Pin the update in program order.  Without this the DAG scheduler sinks every tile's contraction below all the
+    // MFMA chains of the phase (the accumulators are only read at the end) and spills each 16-register D tile.
+    if constexpr (d_out_of(p.ztype) == 1) {
+      asm volatile("" : "+v"(acc[co + T.w]));
+    } else {
+      asm volatile("" : "+v"(acc[co + 3 * T.w + 0]), "+v"(acc[co + 3 * T.w + 1]), "+v"(acc[co + 3 * T.w + 2]));
+    }
+  }
+}
+
+template <int KIND, int TILE, int... R>
+__device__ __forceinline__ void contract_tile(const f32x16& D, const float (&xr)[Spec<KIND>::D_IN / 2],
+                                              const float (&sh)[Spec<KIND>::SH_DIM], const float (&M)[9],
+                                              float (&acc)[NACC<KIND>], std::integer_sequence<int, R...>) {
+  (contract_one<KIND, TILE * 16 + R>(D[R], xr, sh, M, acc), ...);
+}
+
+// One pipeline stage: prefetch W2p of tile T+1, run the MFMA chain of tile T, contract tile T-1 on the VALU.
+// The MFMA chain and the contraction are independent, so the VALU work can sit in the 64-cycle MFMA issue shadows;
+// the sched_barrier keeps stages from smearing into each other (register pressure).
+template <int KIND> struct WTile { vf4 v[Geo<KIND>::K2 / 4]; };
+
+// `wp` is a wave-uniform pointer advanced tile by tile and laundered through an empty asm, so no per-tile address is
+// hoisted out of the chunk loop (hipcc otherwise materialises NT*K2/4 64-bit addresses and spills them).
+template <int KIND>
+__device__ __forceinline__ void load_wtile(gptr4 wp, int lane, WTile<KIND>& w) {
+  using G = Geo<KIND>;
+#pragma unroll
+  for (int g = 0; g < G::K2 / 4; ++g) w.v[g] = wp[g * 64 + lane];
+}
+
+// MFMA chain of one tile; as each dwordx4 of W operands is consumed, the same registers are refilled with the next
+// tile's operands (single W buffer: the refill has a whole tile, ~2k cycles, to land).
+template <int KIND, bool PREFETCH>
+__device__ __forceinline__ f32x16 mfma_tile(WTile<KIND>& w, gptr4 wp_next, int lane, const float (&hid)[32]) {
+  using G = Geo<KIND>;
+  f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < G::K2 / 4; ++g) {
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].x, hid[4 * g + 0], D, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].y, hid[4 * g + 1], D, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].z, hid[4 * g + 2], D, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].w, hid[4 * g + 3], D, 0, 0, 0);
+    if constexpr (PREFETCH) w.v[g] = wp_next[g * 64 + lane];
+  }
+  return D;
+}
+
+// tiles [TILE, TEND) of one phase.  No intra-wave software pipelining: the kernel runs two waves per SIMD, so one
+// wave's VALU contraction overlaps the other wave's 64-cycle MFMAs, and each D tile is consumed as soon as it lands.
+template <int KIND, int TILE, int TEND>
+struct Stage {
+  static __device__ __forceinline__ void run(gptr4 wp, int lane, WTile<KIND>& w, const float (&hid)[32],
+                                             const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
+                                             const float (&M)[9], float (&acc)[NACC<KIND>]) {
+    using G = Geo<KIND>;
+    if constexpr (TILE < TEND) {
+      wp += (G::K2 / 4) * 64;
+      asm volatile("" : "+s"(wp));
+      const f32x16 D = mfma_tile<KIND, (TILE + 1 < TEND)>(w, wp, lane, hid);
+      contract_tile<KIND, TILE>(D, xr, sh, M, acc, std::make_integer_sequence<int, 16>{});
+      __builtin_amdgcn_sched_barrier(0);
+      Stage<KIND, TILE + 1, TEND>::run(wp, lane, w, hid, xr, sh, M, acc);
+    }
+  }
+};
+
+// cross-half sum of one phase's accumulators + staging into the LDS message row at the real channel positions
+template <int KIND, int PH, int... CI>
+__device__ __forceinline__ void stage_phase(float (&acc)[NACC<KIND>], float* row, int half, std::integer_sequence<int, CI...>) {
+  (
+      [&] {
+        constexpr int ch = channel_of<KIND>(PH, CI);
+        const float other = __shfl_xor(acc[CI], 32, 64);
+        if ((CI & 1) == half) row[ch] = acc[CI] + other;   // halves split the stores
+      }(),
+      ...);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
+  using S = Spec<KIND>;
+  using G = Geo<KIND>;
+  __shared__ float s_msg[CHUNK * G::MSG_LD];
+  __shared__ float s_acc[MAX_NODES * S::D_OUT];
+  __shared__ int s_node[CHUNK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
+  const int pose = blockIdx.x / a.slices, slice = blockIdx.x % a.slices;
+
+  // ---- this workgroup's scatter-node range and sorted edge-slot range ----------------------------------------------
+  const int sc0 = a.scat_ptr[pose], sc1 = a.scat_ptr[pose + 1];
+  const int nsc = sc1 - sc0;
+  const int n_lo = sc0 + (int)(((long long)nsc * slice) / a.slices);
+  const int n_hi = sc0 + (int)(((long long)nsc * (slice + 1)) / a.slices);
+  const int n_loc = n_hi - n_lo;
+  if (n_loc <= 0) return;
+  int l0 = 0, p0 = 0, NL = 0, NP = 0, x0 = 0;
+  if (a.mode != DP_EDGES_CSR) {
+    l0 = a.lig_ptr[pose];
+    NL = a.lig_ptr[pose + 1] - l0;
+    if (a.mode != DP_EDGES_CENTER) {
+      p0 = a.ph_ptr[pose];
+      NP = a.ph_ptr[pose + 1] - p0;
+      x0 = a.x_ptr[pose];
+    }
+  }
+  int k_begin, k_end;   // sorted edge slots, local numbering depends on the mode
+  if (a.mode == DP_EDGES_CSR) {
+    k_begin = a.rowptr[n_lo];
+    k_end = a.rowend[n_hi - 1];
+  } else if (a.mode == DP_EDGES_P2L) {
+    k_begin = (n_lo - sc0) * NP;
+    k_end = (n_hi - sc0) * NP;
+  } else if (a.mode == DP_EDGES_L2P) {
+    k_begin = (n_lo - sc0) * NL;
+    k_end = (n_hi - sc0) * NL;
+  } else {
+    k_begin = 0;
+    k_end = NL;
+  }
+
+  for (int i = tid; i < n_loc * S::D_OUT; i += WAVES * 64) s_acc[i] = 0.f;
+
+  gptr4 w1p_lane = (gptr4)a.w1p + lane;
+
+  for (int kc = k_begin; kc < k_end; kc += CHUNK) {
+    const int k = kc + wave * 32 + ecol;
+    const bool valid = k < k_end;
+    EdgeRef e;
+    // ---- edge slot -> (scatter, gather, attr rows, feature row) -----------------------------------------------------
+    if (a.mode == DP_EDGES_CSR) {
+      const int kk = valid ? k : k_begin;
+      e.feat = kk;
+      e.gather = a.nbr[kk];
+      // scatter node: edges are sorted by scatter node; find it by scanning the (short) local row table
+      int sn = 0;
+      for (int n = 0; n < n_loc; ++n) sn += (kk >= a.rowend[n_lo + n]) ? 1 : 0;
+      // rows may have gaps between rowend[n] and rowptr[n+1]; slots inside a gap are padding
+      const bool in_row = sn < n_loc && kk >= a.rowptr[n_lo + sn];
+      e.scat_local = (valid && in_row) ? sn : -1;
+      const int sg = n_lo + (sn < n_loc ? sn : n_loc - 1);
+      e.a1 = a.attr_swap ? e.gather : sg;
+      e.a2 = a.attr_swap ? sg : e.gather;
+    } else if (a.mode == DP_EDGES_P2L) {
+      const int kk = valid ? k : k_begin;
+      const int i = kk / NP, j = kk - i * NP;
+      e.feat = x0 + kk;
+      e.gather = p0 + j;
+      e.a1 = l0 + i;
+      e.a2 = p0 + j;
+      e.scat_local = valid ? (i - (n_lo - sc0)) : -1;
+    } else if (a.mode == DP_EDGES_L2P) {
+      const int kk = valid ? k : k_begin;
+      const int j = kk / NL, i = kk - j * NL;
+      e.feat = x0 + i * NP + j;
+      e.gather = l0 + i;
+      e.a1 = l0 + i;
+      e.a2 = p0 + j;
+      e.scat_local = valid ? (j - (n_lo - sc0)) : -1;
+    } else {
+      const int kk = valid ? k : 0;
+      e.feat = l0 + kk;
+      e.gather = l0 + kk;
+      e.a1 = l0 + kk;
+      e.a2 = 0;
+      e.scat_local = valid ? 0 : -1;
+    }
+
+    // ---- per-edge operands -------------------------------------------------------------------------------------------
+    float av[G::ABLK * 10];                      // this half's 10 floats of every 20-float attr block
+    {
+      const float* pe = a.edge_emb + (size_t)e.feat * 20 + half * 10;
+#pragma unroll
+      for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(pe + i); av[i] = v.x; av[i + 1] = v.y; }
+      const float* p1 = a.attr1_tab + (size_t)e.a1 * a.attr1_stride + half * 10;
+#pragma unroll
+      for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(p1 + i); av[10 + i] = v.x; av[11 + i] = v.y; }
+      if constexpr (G::ABLK == 3) {
+        const float* p2 = a.attr2_tab + (size_t)e.a2 * a.attr2_stride + half * 10;
+#pragma unroll
+        for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(p2 + i); av[20 + i] = v.x; av[21 + i] = v.y; }
+      }
+    }
+    float xr[S::D_IN / 2];                       // this half's in-channels: u = half*mul/2 + q for every in-slot
+    {
+      const float* px = a.gather_tab + (size_t)e.gather * a.gather_stride;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) xr[i] = px[half * 10 + i];                                   // 20x0e
+      if constexpr (S::D_IN >= 50) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) xr[10 + i] = px[20 + half * 15 + i];                       // 10x1o
+      }
+      if constexpr (S::D_IN >= 80) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) xr[25 + i] = px[50 + half * 15 + i];                       // 10x1e
+      }
+      if constexpr (S::D_IN >= 100) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) xr[40 + i] = px[80 + half * 10 + i];                       // 20x0o
+      }
+    }
+    float sh[S::SH_DIM];
+    {
+      const float* ps = a.edge_sh + (size_t)e.feat * a.sh_stride;
+#pragma unroll
+      for (int i = 0; i < S::SH_DIM; ++i) sh[i] = ps[i];
+    }
+    float M[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (S::SH_DIM == 9) {              // sqrt(10) * sum_j sh2[j] C(1,2,1)[i,j,k]  (1/sqrt10 folded into W2p)
+      const float c = 0.57735026918962576451f * sh[6];
+      M[0] = -c - sh[8]; M[4] = 2.f * c; M[8] = -c + sh[8];
+      M[1] = M[3] = sh[5]; M[2] = M[6] = sh[4]; M[5] = M[7] = sh[7];
+    }
+
+    // ---- GEMM1: hidden = relu(W1 attr + b1) --------------------------------------------------------------------------
+    float hid[32];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 H = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G::K1P / 4; ++g) {
+        const vf4 w = w1p_lane[(t * (G::K1P / 4) + g) * 64];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int s = 4 * g + c;
+          float b;
+          if (s < S::N_ATTR / 2) b = av[s];
+          else if (s == S::N_ATTR / 2) b = half ? 0.f : 1.f;
+          else b = 0.f;
+          const float wa = c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w;
+          if (s < G::K1) H = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, b, H, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[t * 16 + r] = fmaxf(H[r], 0.f);
+    }
+
+    // ---- GEMM2 tiles + CG contraction, phase 0 (scalar outputs) then phase 1 (vector outputs) ----------------------
+    __syncthreads();                              // previous chunk's segmented sum has finished reading s_msg
+    float* row = s_msg + (size_t)(wave * 32 + ecol) * G::MSG_LD;
+    {
+      constexpr int NT0 = n_tiles_phase<KIND>(0), NT1 = n_tiles_phase<KIND>(1);
+      constexpr int NA0 = n_acc_phase<KIND>(0), NA1 = n_acc_phase<KIND>(1);
+      float acc[NACC<KIND>];
+      if constexpr (NT0 > 0) {
+#pragma unroll
+        for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
+        gptr4 wp = (gptr4)a.w2p;
+        WTile<KIND> w0;
+        load_wtile<KIND>(wp, lane, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        Stage<KIND, 0, NT0>::run(wp, lane, w0, hid, xr, sh, M, acc);
+        stage_phase<KIND, 0>(acc, row, half, std::make_integer_sequence<int, NA0>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (NT1 > 0) {
+#pragma unroll
+        for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
+        gptr4 wp = (gptr4)a.w2p + (size_t)NT0 * (G::K2 / 4) * 64;
+        asm volatile("" : "+s"(wp));
+        WTile<KIND> w0;
+        load_wtile<KIND>(wp, lane, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        Stage<KIND, NT0, NT0 + NT1>::run(wp, lane, w0, hid, xr, sh, M, acc);
+        stage_phase<KIND, 1>(acc, row, half, std::make_integer_sequence<int, NA1>{});
+      }
+      if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
+    }
+    __syncthreads();
+    // ---- ordered segmented sum over the chunk (deterministic: edge order) ------------------------------------------
+    if (tid < S::D_OUT) {
+      float run = 0.f;
+      int cur = -1;
+      const int nedge = min(CHUNK, k_end - kc);
+      for (int ei = 0; ei < nedge; ++ei) {
+        const int n = s_node[ei];
+        if (n != cur) {
+          if (cur >= 0) s_acc[cur * S::D_OUT + tid] += run;
+          run = 0.f;
+          cur = n;
+        }
+        if (n >= 0) run += s_msg[ei * G::MSG_LD + tid];
+      }
+      if (cur >= 0) s_acc[cur * S::D_OUT + tid] += run;
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: mean, BatchNorm affine, residual stream --------------------------------------------------------------
+  for (int i = tid; i < n_loc * S::D_OUT; i += WAVES * 64) {
+    const int n = i / S::D_OUT, c = i - n * S::D_OUT;
+    const int node = n_lo + n;
+    int deg;
+    if (a.mode == DP_EDGES_CSR) deg = a.rowend[node] - a.rowptr[node];
+    else if (a.mode == DP_EDGES_P2L) deg = NP;
+    else deg = NL;
+    float v = s_acc[i] / (float)max(deg, 1);
+    v = v * a.bn_scale[c] + a.bn_shift[c];
+    float* o = a.out + (size_t)node * a.out_stride + c;
+    if (a.accumulate) {
+      *o += v;
+    } else {
+      if (a.resid != nullptr && c < a.resid_width) v += a.resid[(size_t)node * a.resid_stride + c];
+      *o = v;
+    }
+  }
+}
+
+template <int KIND> int launch(const DpConvArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)(a.B * a.slices)), block(WAVES * 64);
+  hipLaunchKernelGGL(tp_conv_kernel<KIND>, grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace dp
+
+extern "C" {
+
+int dp_abi_version(void) { return DP_ABI_VERSION; }
+
+int dp_conv_dims(int32_t kind, int32_t* d_in, int32_t* d_out, int32_t* numel, int32_t* n_attr, int32_t* hidden) {
+#define DP_CASE(K)                                                                        \
+  case K:                                                                                 \
+    if (d_in) *d_in = dp::Spec<K>::D_IN;                                                  \
+    if (d_out) *d_out = dp::Spec<K>::D_OUT;                                               \
+    if (numel) *numel = dp::Spec<K>::NUMEL;                                               \
+    if (n_attr) *n_attr = dp::Spec<K>::N_ATTR;                                            \
+    if (hidden) *hidden = dp::Spec<K>::HID;                                               \
+    return DP_OK;
+  switch (kind) {
+    DP_CASE(0) DP_CASE(1) DP_CASE(2) DP_CASE(3) DP_CASE(4) DP_CASE(5)
+    default: return DP_E_BADARG;
+  }
+#undef DP_CASE
+}
+
+int dp_conv_w1p_floats(int32_t kind) {
+  switch (kind) {
+    case 0: return dp::Geo<0>::W1P_FLOATS; case 1: return dp::Geo<1>::W1P_FLOATS; case 2: return dp::Geo<2>::W1P_FLOATS;
+    case 3: return dp::Geo<3>::W1P_FLOATS; case 4: return dp::Geo<4>::W1P_FLOATS; case 5: return dp::Geo<5>::W1P_FLOATS;
+    default: return DP_E_BADARG;
+  }
+}
+int dp_conv_w2p_floats(int32_t kind) {
+  switch (kind) {
+    case 0: return dp::Geo<0>::W2P_FLOATS; case 1: return dp::Geo<1>::W2P_FLOATS; case 2: return dp::Geo<2>::W2P_FLOATS;
+    case 3: return dp::Geo<3>::W2P_FLOATS; case 4: return dp::Geo<4>::W2P_FLOATS; case 5: return dp::Geo<5>::W2P_FLOATS;
+    default: return DP_E_BADARG;
+  }
+}
+
+// HOST pointers in, HOST pointers out: re-orders one TensorProductConvLayer's `fc` parameters (reference layout:
+// fc.0.weight [HID, N_ATTR], fc.0.bias [HID], fc.3.weight [numel, HID], fc.3.bias [numel]) into MFMA operand order.
+int dp_pack_conv_weights(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
+                         float* w1p, float* w2p) {
+  if (!fc0_w || !fc0_b || !fc3_w || !fc3_b || !w1p || !w2p) return DP_E_BADARG;
+  switch (kind) {
+#define DP_CASE(K) case K: dp::pack_w1<K>(fc0_w, fc0_b, w1p); dp::pack_w2<K>(fc3_w, fc3_b, w2p); return DP_OK;
+    DP_CASE(0) DP_CASE(1) DP_CASE(2) DP_CASE(3) DP_CASE(4) DP_CASE(5)
+#undef DP_CASE
+    default: return DP_E_BADARG;
+  }
+}
+
+int dp_tp_conv(const DpConvArgs* a, void* stream) {
+  if (!a || a->B <= 0 || a->slices <= 0 || !a->scat_ptr || !a->gather_tab || !a->attr1_tab || !a->edge_emb || !a->edge_sh ||
+      !a->w1p || !a->w2p || !a->bn_scale || !a->bn_shift || !a->out)
+    return DP_E_BADARG;
+  if (a->mode == DP_EDGES_CSR && (!a->rowptr || !a->rowend || !a->nbr)) return DP_E_BADARG;
+  if (a->mode != DP_EDGES_CSR && !a->lig_ptr) return DP_E_BADARG;
+  if ((a->mode == DP_EDGES_P2L || a->mode == DP_EDGES_L2P) && (!a->ph_ptr || !a->x_ptr)) return DP_E_BADARG;
+  if (a->kind != DP_CONV_FINAL && !a->attr2_tab) return DP_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (a->kind) {
+    case 0: return dp::launch<0>(*a, st);
+    case 1: return dp::launch<1>(*a, st);
+    case 2: return dp::launch<2>(*a, st);
+    case 3: return dp::launch<3>(*a, st);
+    case 4: return dp::launch<4>(*a, st);
+    case 5: return dp::launch<5>(*a, st);
+    default: return DP_E_BADARG;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+"""Host-side weight re-ordering for the HIP kernels (runs once at model load; not on the hot path)."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import _lib
+from . import config as C
+
+_OUT_IRREPS = {0: C.SEQ[1], 1: C.SEQ[2], 2: C.SEQ[3], 3: C.SEQ[3], 4: C.FINAL_OUT, 5: C.TOR_OUT}
+
+
+def bn_affine(sd: Dict[str, torch.Tensor], prefix: str, irreps, eps: float = 1e-5):
+    """e3nn BatchNorm(eval) as a per-channel affine map: out = x*scale + shift."""
+    rm, rv = sd[prefix + ".running_mean"].double(), sd[prefix + ".running_var"].double()
+    w, b = sd[prefix + ".weight"].double(), sd[prefix + ".bias"].double()
+    scale, shift = [], []
+    im = iv = 0
+    for mul, l, p in irreps:
+        d = 2 * l + 1
+        s = (rv[iv:iv + mul] + eps).pow(-0.5) * w[iv:iv + mul]
+        iv += mul
+        if l == 0 and p == 1:
+            sh = b[im:im + mul] - rm[im:im + mul] * s
+            im += mul
+        else:
+            sh = torch.zeros(mul, dtype=torch.float64)
+        scale.append(s.repeat_interleave(d))
+        shift.append(sh.repeat_interleave(d))
+    return torch.cat(scale).float().contiguous(), torch.cat(shift).float().contiguous()
+
+
+def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int) -> Dict[str, torch.Tensor]:
+    """fc.0 / fc.3 / batch_norm of one TensorProductConvLayer -> MFMA operand order (host tensors)."""
+    L = _lib.lib()
+    dims = _lib.conv_dims(kind)
+    fc0_w = sd[prefix + ".fc.0.weight"].float().contiguous()
+    fc0_b = sd[prefix + ".fc.0.bias"].float().contiguous()
+    fc3_w = sd[prefix + ".fc.3.weight"].float().contiguous()
+    fc3_b = sd[prefix + ".fc.3.bias"].float().contiguous()
+    assert tuple(fc0_w.shape) == (dims["hidden"], dims["n_attr"]), (prefix, fc0_w.shape, dims)
+    assert tuple(fc3_w.shape) == (dims["numel"], dims["hidden"]), (prefix, fc3_w.shape, dims)
+    w1p = torch.empty(L.dp_conv_w1p_floats(kind), dtype=torch.float32)
+    w2p = torch.empty(L.dp_conv_w2p_floats(kind), dtype=torch.float32)
+    _lib.check(L.dp_pack_conv_weights(kind, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
+                                      w1p.data_ptr(), w2p.data_ptr()), "dp_pack_conv_weights")
+    scale, shift = bn_affine(sd, prefix + ".batch_norm", _OUT_IRREPS[kind])
+    return dict(w1p=w1p, w2p=w2p, bn_scale=scale, bn_shift=shift)

@@ -1,0 +1,230 @@
+"""Parity of the fused HIP tensor-product conv (dp_tp_conv, through the C ABI) against the oracle's
+TensorProductConvLayer restatement on the same seeded inputs.  fp32 kernel vs fp64 oracle; tolerance 2e-5 of the
+per-tensor max magnitude (fp32 accumulation over <=2200 weights x <=80 edges)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffphore_amd import _lib, config, packing, weights  # noqa: E402
+
+TOL = 2e-5
+
+
+def _oracle_conv(sd, prefix, kind, x_gather, attr, sh, scatter, n_out):
+    from oracle import e3
+    from oracle.model import OracleScoreModel
+    m = OracleScoreModel(sd, config.ModelConfig(), dtype=torch.float64, tables=(np.ones(1000), np.ones(5001)))
+    ir_in = m.seq[min(kind, 3)] if kind < 4 else m.seq[3]
+    if kind < 4:
+        ir_out, ir_sh = m.seq[min(kind + 1, 3)], m.sh_irreps
+    elif kind == 4:
+        ir_out, ir_sh = m.final_out, m.sh_irreps
+    else:
+        ir_out, ir_sh = m.tor_out, m.tor_sh_irreps
+    w = m.mlp(prefix + ".fc", attr.double())
+    tp = e3.fctp_apply(x_gather.double(), sh.double(), w, ir_in, ir_sh, ir_out)
+    from oracle.model import scatter_mean
+    out = scatter_mean(tp, scatter, n_out)
+    bn = prefix + ".batch_norm"
+    return e3.batchnorm_eval(out, ir_out, m.sd[bn + ".running_mean"], m.sd[bn + ".running_var"], m.sd[bn + ".weight"],
+                             m.sd[bn + ".bias"])
+
+
+def _dev(t):
+    return t.contiguous().cuda()
+
+
+def _run(args_dict, keep):
+    a = _lib.DpConvArgs()
+    for k, v in args_dict.items():
+        if torch.is_tensor(v):
+            keep.append(v)
+            v = v.data_ptr()
+        setattr(a, k, v)
+    _lib.check(_lib.lib().dp_tp_conv(C.byref(a), torch.cuda.current_stream().cuda_stream), "dp_tp_conv")
+    torch.cuda.synchronize()
+
+
+def _i32(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.int32)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("slices", [1, 3])
+def test_conv_csr_ragged(kind, slices):
+    """lig-lig / phore-phore style: explicit CSR with ragged degrees incl. empty rows, several poses, residual + accumulate."""
+    g = torch.Generator().manual_seed(100 + kind)
+    sd = weights.init_state_dict(7)
+    prefix = f"encoder.lig_conv_layers.{kind}"
+    dims = _lib.conv_dims(kind)
+    B = 5
+    n_nodes = [9, 1, 17, 30, 12]
+    scat_ptr = np.concatenate([[0], np.cumsum(n_nodes)])
+    N = int(scat_ptr[-1])
+    h = torch.randn(N, dims["d_in"], generator=g)
+    rowptr, rowend, nbr, scatter = [], [], [], []
+    e0 = 0
+    for b in range(B):
+        e0 += int(torch.randint(0, 5, (1,), generator=g))          # gap between poses (capacity padding)
+        for n in range(scat_ptr[b], scat_ptr[b + 1]):
+            deg = int(torch.randint(0, 40, (1,), generator=g)) if n_nodes[b] > 1 else 3
+            if n % 7 == 3:
+                deg = 0
+            rowptr.append(e0)
+            rowend.append(e0 + deg)
+            for _ in range(deg):
+                nbr.append(int(torch.randint(int(scat_ptr[b]), int(scat_ptr[b + 1]), (1,), generator=g)))
+                scatter.append(n)
+            e0 += deg
+    E_slots = e0 + 3
+    slot_of = []
+    for n in range(N):
+        slot_of += list(range(rowptr[n], rowend[n]))
+    slot_of = torch.tensor(slot_of)
+    nbr_slots = torch.zeros(E_slots, dtype=torch.int32)
+    nbr_slots[slot_of] = torch.tensor(nbr, dtype=torch.int32)
+    emb = torch.randn(E_slots, 20, generator=g)
+    sh = torch.randn(E_slots, 9, generator=g)
+    sh[:, 0] = 1.0
+    scatter_t = torch.tensor(scatter)
+    nbr_t = torch.tensor(nbr)
+    attr = torch.cat([emb[slot_of], h[scatter_t, :20], h[nbr_t, :20]], 1)
+    ref = _oracle_conv(sd, prefix, kind, h[nbr_t], attr, sh[slot_of], scatter_t, N)
+    pk = packing.pack_conv(sd, prefix, kind)
+    resid = torch.randn(N, dims["d_in"], generator=g)
+    out = torch.full((N, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    base = dict(kind=kind, mode=_lib.EDGES_CSR, B=B, slices=slices, scat_ptr=_dev(_i32(scat_ptr)),
+                rowptr=_dev(_i32(rowptr)), rowend=_dev(_i32(rowend)), nbr=_dev(nbr_slots),
+                gather_tab=_dev(h), gather_stride=dims["d_in"], attr1_tab=_dev(h), attr1_stride=dims["d_in"],
+                attr2_tab=_dev(h), attr2_stride=dims["d_in"], attr_swap=0, edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9,
+                w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]), bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]),
+                out=out, out_stride=dims["d_out"], accumulate=0, resid=_dev(resid), resid_stride=dims["d_in"],
+                resid_width=dims["d_in"])
+    _run(base, keep)
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err < TOL, err
+    # accumulate mode: out += conv
+    base["accumulate"] = 1
+    _run(base, keep)
+    got2 = out.cpu().double()
+    err = (got2 - (want + ref)).abs().max().item() / want.abs().max().item()
+    assert err < 2 * TOL, err
+
+
+@pytest.mark.parametrize("kind", [0, 3])
+@pytest.mark.parametrize("mode", ["p2l", "l2p"])
+def test_conv_dense_cross(kind, mode):
+    g = torch.Generator().manual_seed(300 + kind)
+    sd = weights.init_state_dict(11)
+    fam = "phore_to_lig_conv_layers" if mode == "p2l" else "lig_to_phore_norm_conv_layers"
+    if kind == 3 and mode == "l2p":
+        fam = "lig_to_phore_conv_layers"
+    prefix = f"encoder.{fam}.{kind}"
+    dims = _lib.conv_dims(kind)
+    NL, NP = [7, 30, 13], [32, 5, 79]
+    B = len(NL)
+    lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+    ph_ptr = np.concatenate([[0], np.cumsum(NP)])
+    x_ptr = np.concatenate([[0], np.cumsum(np.asarray(NL) * np.asarray(NP))])
+    hl = torch.randn(int(lig_ptr[-1]), dims["d_in"], generator=g)
+    hp = torch.randn(int(ph_ptr[-1]), dims["d_in"], generator=g)
+    E = int(x_ptr[-1])
+    emb = torch.randn(E, 20, generator=g)
+    sh = torch.randn(E, 9, generator=g)
+    src = torch.cat([torch.arange(lig_ptr[b], lig_ptr[b + 1]).repeat_interleave(NP[b]) for b in range(B)])
+    dst = torch.cat([torch.arange(ph_ptr[b], ph_ptr[b + 1]).repeat(NL[b]) for b in range(B)])
+    attr = torch.cat([emb, hl[src, :20], hp[dst, :20]], 1)
+    if mode == "p2l":
+        ref = _oracle_conv(sd, prefix, kind, hp[dst], attr, sh, src, hl.shape[0])
+        n_out, gt, scat_ptr, m = hl.shape[0], hp, lig_ptr, _lib.EDGES_P2L
+    else:
+        ref = _oracle_conv(sd, prefix, kind, hl[src], attr, sh, dst, hp.shape[0])
+        n_out, gt, scat_ptr, m = hp.shape[0], hl, ph_ptr, _lib.EDGES_L2P
+    pk = packing.pack_conv(sd, prefix, kind)
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    _run(dict(kind=kind, mode=m, B=B, slices=2, scat_ptr=_dev(_i32(scat_ptr)), lig_ptr=_dev(_i32(lig_ptr)),
+              ph_ptr=_dev(_i32(ph_ptr)), x_ptr=_dev(_i32(x_ptr)), gather_tab=_dev(gt), gather_stride=dims["d_in"],
+              attr1_tab=_dev(hl), attr1_stride=dims["d_in"], attr2_tab=_dev(hp), attr2_stride=dims["d_in"], attr_swap=0,
+              edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]),
+              bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]), out=out, out_stride=dims["d_out"],
+              accumulate=0, resid=None, resid_stride=0, resid_width=0), keep)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < TOL, err
+
+
+def test_conv_center_and_torsion_kinds():
+    g = torch.Generator().manual_seed(500)
+    sd = weights.init_state_dict(13)
+    # final_conv: one scatter node per pose, one edge per atom, attr = [emb | h_l[atom,:20]]
+    dims = _lib.conv_dims(4)
+    NL = [20, 3, 44]
+    B = len(NL)
+    lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+    n = int(lig_ptr[-1])
+    hl = torch.randn(n, 100, generator=g)
+    emb = torch.randn(n, 20, generator=g)
+    sh = torch.randn(n, 9, generator=g)
+    batch = torch.repeat_interleave(torch.arange(B), torch.tensor(NL))
+    attr = torch.cat([emb, hl[:, :20]], 1)
+    ref = _oracle_conv(sd, "final_conv", 4, hl, attr, sh, batch, B)
+    pk = packing.pack_conv(sd, "final_conv", 4)
+    out = torch.full((B, 12), float("nan")).cuda()
+    keep = []
+    _run(dict(kind=4, mode=_lib.EDGES_CENTER, B=B, slices=1, scat_ptr=_dev(_i32(np.arange(B + 1))), lig_ptr=_dev(_i32(lig_ptr)),
+              gather_tab=_dev(hl), gather_stride=100, attr1_tab=_dev(hl), attr1_stride=100, attr2_tab=None, attr2_stride=0,
+              attr_swap=0, edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]),
+              bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]), out=out, out_stride=12, accumulate=0,
+              resid=None, resid_stride=0, resid_width=0), keep)
+    got = out.cpu().double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < TOL, err
+
+    # tor_bond_conv: scatter = bonds (CSR), gather = atoms, attr = [emb | h_l[atom,:20] | hb[bond,:20]], sh = 45-dim FullTP
+    from oracle import e3
+    T = [4, 0, 9]
+    tor_ptr = np.concatenate([[0], np.cumsum(T)])
+    nb = int(tor_ptr[-1])
+    hb = torch.randn(nb, 20, generator=g)
+    rowptr, rowend, nbr, scat = [], [], [], []
+    e0 = 0
+    for b in range(B):
+        for k in range(tor_ptr[b], tor_ptr[b + 1]):
+            deg = int(torch.randint(1, 33, (1,), generator=g))
+            rowptr.append(e0)
+            rowend.append(e0 + deg)
+            nbr += [int(torch.randint(int(lig_ptr[b]), int(lig_ptr[b + 1]), (1,), generator=g)) for _ in range(deg)]
+            scat += [k] * deg
+            e0 += deg
+    E = e0
+    nbr_t, scat_t = torch.tensor(nbr), torch.tensor(scat)
+    temb = torch.randn(E, 20, generator=g)
+    sh9 = e3.spherical_harmonics_lmax2(torch.randn(E, 3, generator=g).double())
+    b5 = e3.spherical_harmonics_2e(torch.randn(nb, 3, generator=g).double())[scat_t]
+    sh45 = e3.full_tp_apply(sh9, b5, e3.SH_IRREPS, e3.parse_irreps("1x2e"))
+    sh7 = sh45[:, :7].float()                      # [0e | 1o | 1e] is all tor_bond_conv can consume
+    attr = torch.cat([temb, hl[nbr_t, :20], hb[scat_t]], 1)
+    ref = _oracle_conv(sd, "tor_bond_conv", 5, hl[nbr_t], attr, sh45, scat_t, nb)
+    pk = packing.pack_conv(sd, "tor_bond_conv", 5)
+    out = torch.full((nb, 40), float("nan")).cuda()
+    _run(dict(kind=5, mode=_lib.EDGES_CSR, B=B, slices=1, scat_ptr=_dev(_i32(tor_ptr)), rowptr=_dev(_i32(rowptr)),
+              rowend=_dev(_i32(rowend)), nbr=_dev(_i32(nbr)), gather_tab=_dev(hl), gather_stride=100,
+              attr1_tab=_dev(hl), attr1_stride=100, attr2_tab=_dev(hb), attr2_stride=20, attr_swap=1,
+              edge_emb=_dev(temb), edge_sh=_dev(sh7), sh_stride=7, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]),
+              bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]), out=out, out_stride=40, accumulate=0,
+              resid=None, resid_stride=0, resid_width=0), keep)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < TOL, err

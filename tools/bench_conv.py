@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused TP conv kernel alone (dense cross edge set, cfg2 shape by default)."""
+import argparse
+import ctypes as C
+import json
+
+import numpy as np
+import torch
+
+from diffphore_amd import _lib, packing, weights
+
+ALG_BYTES = {0: 2516, 1: 4636, 2: 6756, 3: 9236}   # 4*(numel + D_in + 9) per edge-conv
+FLOPS = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=512)
+    ap.add_argument("--nl", type=int, default=30)
+    ap.add_argument("--np", type=int, default=32)
+    ap.add_argument("--kind", type=int, default=3)
+    ap.add_argument("--slices", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--mode", default="p2l")
+    a = ap.parse_args()
+    dims = _lib.conv_dims(a.kind)
+    sd = weights.init_state_dict(1)
+    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind)
+    B, NL, NP = a.B, a.nl, a.np
+    dev = "cuda"
+    lig_ptr = torch.arange(B + 1, dtype=torch.int32) * NL
+    ph_ptr = torch.arange(B + 1, dtype=torch.int32) * NP
+    x_ptr = torch.arange(B + 1, dtype=torch.int32) * (NL * NP)
+    E = B * NL * NP
+    hl = torch.randn(B * NL, dims["d_in"], device=dev)
+    hp = torch.randn(B * NP, dims["d_in"], device=dev)
+    emb = torch.randn(E, 20, device=dev)
+    sh = torch.randn(E, 9, device=dev)
+    n_out = B * NL if a.mode == "p2l" else B * NP
+    out = torch.zeros(n_out, dims["d_out"], device=dev)
+    keep = {k: v.to(dev) for k, v in pk.items()}
+    keep.update(lig_ptr=lig_ptr.to(dev), ph_ptr=ph_ptr.to(dev), x_ptr=x_ptr.to(dev))
+    args = _lib.DpConvArgs()
+    args.kind, args.B, args.slices = a.kind, B, a.slices
+    args.mode = _lib.EDGES_P2L if a.mode == "p2l" else _lib.EDGES_L2P
+    args.scat_ptr = keep["lig_ptr"].data_ptr() if a.mode == "p2l" else keep["ph_ptr"].data_ptr()
+    args.lig_ptr, args.ph_ptr, args.x_ptr = keep["lig_ptr"].data_ptr(), keep["ph_ptr"].data_ptr(), keep["x_ptr"].data_ptr()
+    args.gather_tab = (hp if a.mode == "p2l" else hl).data_ptr()
+    args.gather_stride = dims["d_in"]
+    args.attr1_tab, args.attr1_stride = hl.data_ptr(), dims["d_in"]
+    args.attr2_tab, args.attr2_stride = hp.data_ptr(), dims["d_in"]
+    args.edge_emb, args.edge_sh, args.sh_stride = emb.data_ptr(), sh.data_ptr(), 9
+    args.w1p, args.w2p = keep["w1p"].data_ptr(), keep["w2p"].data_ptr()
+    args.bn_scale, args.bn_shift = keep["bn_scale"].data_ptr(), keep["bn_shift"].data_ptr()
+    args.out, args.out_stride, args.accumulate = out.data_ptr(), dims["d_out"], 0
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        _lib.check(L.dp_tp_conv(C.byref(args), st), "conv")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        L.dp_tp_conv(C.byref(args), st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    print(json.dumps(dict(kind=a.kind, mode=a.mode, B=B, edges=E, ms=ms, ns_per_edge=ms * 1e6 / E,
+                          alg_GBps=E * ALG_BYTES[a.kind] / ms / 1e6, TFLOPs=E * FLOPS[a.kind] / ms / 1e9)))
+
+
+if __name__ == "__main__":
+    main()
