@@ -22,7 +22,7 @@ class DpConvArgs(C.Structure):
     _fields_ = [
         ("kind", c_i32), ("mode", c_i32), ("B", c_i32), ("slices", c_i32),
         ("scat_ptr", VOIDP), ("lig_ptr", VOIDP), ("ph_ptr", VOIDP), ("x_ptr", VOIDP),
-        ("rowptr", VOIDP), ("rowend", VOIDP), ("nbr", VOIDP),
+        ("rowptr", VOIDP), ("rowend", VOIDP), ("nbr", VOIDP), ("edge_scat", VOIDP),
         ("gather_tab", VOIDP), ("gather_stride", c_i32),
         ("attr1_tab", VOIDP), ("attr1_stride", c_i32),
         ("attr2_tab", VOIDP), ("attr2_stride", c_i32), ("attr_swap", c_i32),

@@ -283,13 +283,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
       const int kk = valid ? k : k_begin;
       e.feat = kk;
       e.gather = a.nbr[kk];
-      // scatter node: edges are sorted by scatter node; find it by scanning the (short) local row table
-      int sn = 0;
-      for (int n = 0; n < n_loc; ++n) sn += (kk >= a.rowend[n_lo + n]) ? 1 : 0;
-      // rows may have gaps between rowend[n] and rowptr[n+1]; slots inside a gap are padding
-      const bool in_row = sn < n_loc && kk >= a.rowptr[n_lo + sn];
-      e.scat_local = (valid && in_row) ? sn : -1;
-      const int sg = n_lo + (sn < n_loc ? sn : n_loc - 1);
+      const int sabs = a.edge_scat[kk];
+      const bool in_rng = sabs >= n_lo && sabs < n_hi;
+      e.scat_local = (valid && in_rng) ? sabs - n_lo : -1;
+      const int sg = in_rng ? sabs : n_lo;
       e.a1 = a.attr_swap ? e.gather : sg;
       e.a2 = a.attr_swap ? sg : e.gather;
     } else if (a.mode == DP_EDGES_P2L) {
@@ -517,7 +514,7 @@ int dp_tp_conv(const DpConvArgs* a, void* stream) {
   if (!a || a->B <= 0 || a->slices <= 0 || !a->scat_ptr || !a->gather_tab || !a->attr1_tab || !a->edge_emb || !a->edge_sh ||
       !a->w1p || !a->w2p || !a->bn_scale || !a->bn_shift || !a->out)
     return DP_E_BADARG;
-  if (a->mode == DP_EDGES_CSR && (!a->rowptr || !a->rowend || !a->nbr)) return DP_E_BADARG;
+  if (a->mode == DP_EDGES_CSR && (!a->rowptr || !a->rowend || !a->nbr || !a->edge_scat)) return DP_E_BADARG;
   if (a->mode != DP_EDGES_CSR && !a->lig_ptr) return DP_E_BADARG;
   if ((a->mode == DP_EDGES_P2L || a->mode == DP_EDGES_L2P) && (!a->ph_ptr || !a->x_ptr)) return DP_E_BADARG;
   if (a->kind != DP_CONV_FINAL && !a->attr2_tab) return DP_E_BADARG;

@@ -1,0 +1,72 @@
+// dp_dev.h - small device helpers shared by the graph / head / update kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/diffphore_amd.h"
+
+namespace dp {
+
+constexpr int NS = 20;           // scalar channels / sigma-embedding width / distance-embedding width
+constexpr int NPT = 11;          // pharmacophore types, 10 = exclusion sphere
+constexpr int EX = 10;
+constexpr int TP_STRIDE = 32;    // floats per pose in DpWork::tparams
+constexpr int MAXN_L = 256, MAXN_P = 256, MAXT = 128, TOR_SLOTS = 32;
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }     // F.softplus, beta=1, threshold=20
+__device__ __forceinline__ float leaky_f(float x) { return x >= 0.f ? x : 0.01f * x; }
+
+// e3nn spherical harmonics l<=2, normalize=True (v / max(|v|,1e-12)), 'component' normalisation.
+__device__ __forceinline__ void sh9(float x, float y, float z, float* o) {
+  const float n = sqrtf(x * x + y * y + z * z);
+  const float inv = 1.f / fmaxf(n, 1e-12f);
+  x *= inv; y *= inv; z *= inv;
+  const float s3 = 1.7320508075688772f, s5 = 2.23606797749979f, s15 = 3.872983346207417f;
+  o[0] = 1.f;
+  o[1] = s3 * x; o[2] = s3 * y; o[3] = s3 * z;
+  o[4] = s15 * x * z;
+  o[5] = s15 * x * y;
+  o[6] = s5 * (y * y - 0.5f * (x * x + z * z));
+  o[7] = s15 * y * z;
+  o[8] = 0.5f * s15 * (z * z - x * x);
+}
+
+// GaussianSmearing.forward: exp(coeff * (d - offset[k])^2), offset = the module's registered buffer (linspace(0, stop, 20))
+__device__ __forceinline__ void gauss20(float d, const float* __restrict__ mu, float coeff, float* g) {
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const float t = d - mu[k];
+    g[k] = expf(coeff * (t * t));
+  }
+}
+
+// out[o] = b[o] + sum_i W[o*ld + off + i] * x[i]   (uniform weight addresses -> scalar loads)
+template <int NOUT, int NIN>
+__device__ __forceinline__ void matvec_acc(const float* __restrict__ W, int ld, int off, const float* x, float* out) {
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    float a = out[o];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) a = fmaf(W[o * ld + off + i], x[i], a);
+    out[o] = a;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void store_row(float* __restrict__ dst, const float* v) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) dst[i] = v[i];
+}
+
+// second Linear of a 20->20 MLP with ReLU in between:  out = b3 + W3 relu(h)
+__device__ __forceinline__ void mlp_tail20(const DpMlp& m, const float* h, float* out) {
+#pragma unroll
+  for (int o = 0; o < NS; ++o) {
+    float a = m.b3[o];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) a = fmaf(m.w3[o * NS + i], fmaxf(h[i], 0.f), a);
+    out[o] = a;
+  }
+}
+
+}  // namespace dp

@@ -1,0 +1,673 @@
+// dp_graph.hip - per-step graph construction, embeddings and score heads of the DiffPhore score model for gfx950.
+//
+// Everything here is small, latency/launch-bound work around the fused TP convs (dp_conv.hip): one workgroup per
+// pose, atoms / edges of the pose spread over the threads, per-pose constants staged in LDS, MLP weights read through
+// wave-uniform (scalar) loads.  No host synchronisation anywhere.  Reference line numbers: score_model_phore.py.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "dp_dev.h"
+
+namespace dp {
+
+constexpr int LIG_DIMS[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};   // process_mols.py:162-179
+
+// ---------------------------------------------------------------------------------------------------------------------
+// time parameters per pose: sinusoidal sigma embedding, sigmas, SO(3)/torus score norms
+//   diffusion_utils.py:16-20,82-93 ; so3.py:92-96 ; torus.py:82-86 ; score_model_phore.py:333,352,376
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void time_params_kernel(int B, const float* __restrict__ t, DpWeights w, float* __restrict__ tp) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const float t_tr = t[p * 3 + 0], t_rot = t[p * 3 + 1], t_tor = t[p * 3 + 2];
+  float* o = tp + (size_t)p * TP_STRIDE;
+  const float st = __fmul_rn(w.emb_scale, t_tr);                 // embedding_scale * x      (float32)
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const float arg = __fmul_rn(st, w.emb_freq[k]);              // timesteps[:,None] * emb[None,:]
+    o[k] = (float)sin((double)arg);
+    o[10 + k] = (float)cos((double)arg);
+  }
+  const float s_tr = powf(w.tr_smin, 1.f - t_tr) * powf(w.tr_smax, t_tr);
+  const float s_rot = powf(w.rot_smin, 1.f - t_rot) * powf(w.rot_smax, t_rot);
+  const float s_tor = powf(w.tor_smin, 1.f - t_tor) * powf(w.tor_smax, t_tor);
+  o[20] = s_tr; o[21] = s_rot; o[22] = s_tor;
+  {  // so3.score_norm: nearest index on a log10 grid of 1000 eps in [0.01, 2]
+    const double x = (log10((double)s_rot) - log10(0.01)) / (log10(2.0) - log10(0.01)) * 1000.0;
+    int idx = (int)rint(x);
+    idx = idx < 0 ? 0 : (idx > 999 ? 999 : idx);
+    o[23] = w.so3_table[idx];
+  }
+  {  // torus.score_norm: index on a log grid of 5001 sigma/pi in [3e-3, 2]; clip BEFORE round (torus.py:85)
+    double x = (log((double)s_tor / M_PI) - log(3e-3)) / (log(2.0) - log(3e-3)) * 5000.0;
+    x = x < 0.0 ? 0.0 : (x > 5000.0 ? 5000.0 : x);
+    const int idx = (int)rint(x);
+    o[24] = sqrtf(w.torus_table[idx]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// one-time static tables
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void static_nodes_kernel(DpBatch b, DpWeights w, DpWork k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b.n_lig) {
+    // AtomEncoder categorical part (:64-69): sum of 16 embedding rows
+    float acc[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) acc[c] = 0.f;
+    int off = 0;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      const float* row = w.lig_emb + (size_t)(off + b.lig_x[i * 16 + f]) * NS;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) acc[c] += row[c];
+      off += LIG_DIMS[f];
+    }
+    store_row<NS>(k.lig_x_emb + (size_t)i * NS, acc);
+    // static parts of the cross edge MLPs per (atom, phore type):  P = [A | onehot(type) | phorefp[atom]]  (:790-796)
+    float fp[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) fp[t] = b.phorefp[i * NPT + t];
+    for (int ty = 0; ty < NPT; ++ty) {
+      const float a = ty == EX ? 0.f : fp[ty];
+      float pre[NS];
+#pragma unroll
+      for (int o = 0; o < NS; ++o) {
+        const float* W = w.x_edge.w0 + o * 73 + 40;
+        float s = w.x_edge.b0[o] + a * W[ty] + W[11 + ty];
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) s = fmaf(W[22 + t], fp[t], s);
+        pre[o] = s;
+      }
+      store_row<NS>(k.pair_pre + ((size_t)i * NPT + ty) * NS, pre);
+      // phoretype_match_transition: Linear(33,11), ReLU, Linear(11,1), Softplus  (:571-573, :807)
+      float z = w.pmt.b3[0];
+#pragma unroll
+      for (int o = 0; o < NPT; ++o) {
+        const float* W = w.pmt.w0 + o * 33;
+        float s = w.pmt.b0[o] + a * W[ty] + W[11 + ty];
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) s = fmaf(W[22 + t], fp[t], s);
+        z = fmaf(w.pmt.w3[o], fmaxf(s, 0.f), z);
+      }
+      k.pair_fm[(size_t)i * NPT + ty] = softplus_f(z);
+    }
+  }
+  if (i < b.n_ph) {
+    // phore AtomEncoder: 3 embeddings + Linear on [alpha, weight | sigma emb]; the sigma part is added per step (:64-73, :662)
+    float acc[NS];
+    const float al = b.ph_scalar[i * 2 + 0], wt = b.ph_scalar[i * 2 + 1];
+    const float* r0 = w.ph_emb + (size_t)b.ph_x[i * 3 + 0] * NS;
+    const float* r1 = w.ph_emb + (size_t)(11 + b.ph_x[i * 3 + 1]) * NS;
+    const float* r2 = w.ph_emb + (size_t)(13 + b.ph_x[i * 3 + 2]) * NS;
+#pragma unroll
+    for (int c = 0; c < NS; ++c)
+      acc[c] = r0[c] + r1[c] + r2[c] + (w.ph_lin_b[c] + w.ph_lin_w[c * 22 + 0] * al + w.ph_lin_w[c * 22 + 1] * wt);
+    store_row<NS>(k.ph_x_emb + (size_t)i * NS, acc);
+  }
+}
+
+__global__ void static_pp_kernel(DpBatch b, DpWeights w, DpWork k) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= b.n_pp) return;
+  const int s = b.pp_src[e], d = b.pp_dst[e];
+  const float vx = b.ph_pos[d * 3 + 0] - b.ph_pos[s * 3 + 0];
+  const float vy = b.ph_pos[d * 3 + 1] - b.ph_pos[s * 3 + 1];
+  const float vz = b.ph_pos[d * 3 + 2] - b.ph_pos[s * 3 + 2];
+  float sh[9];
+  sh9(vx, vy, vz, sh);
+  store_row<9>(k.pp_sh + (size_t)e * 9, sh);
+  float g[NS], pre[NS];
+  gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.ph_gauss_mu, w.ph_gauss_coeff, g);
+#pragma unroll
+  for (int o = 0; o < NS; ++o) pre[o] = w.ph_edge.b0[o];
+  matvec_acc<NS, NS>(w.ph_edge.w0, 40, 20, g, pre);
+  store_row<NS>(k.pp_pre + (size_t)e * NS, pre);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ligand graph per pose: radius graph (torch_cluster CUDA semantics) + bond edges, CSR by scatter node, edge embedding, SH
+//   build_lig_conv_graph :715-739 ; lig_edge_embedding :657
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, DpWork k) {
+  __shared__ float s_pos[MAXN_L * 3];
+  __shared__ uint32_t s_adj[MAXN_L * (MAXN_L / 32)];     // s_adj[centre][nbr/32]: bit set <=> edge (nbr -> centre) exists
+  __shared__ int s_deg[MAXN_L], s_row[MAXN_L + 1];
+  __shared__ float s_c0[NS];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
+  const int bo0 = b.bond_ptr[p], nbond = b.bond_ptr[p + 1] - bo0;
+  const int base = b.ll_ptr[p];
+  const int words = (N + 31) / 32;
+  for (int i = tid; i < N * 3; i += 256) s_pos[i] = b.pos[(size_t)l0 * 3 + i];
+  for (int i = tid; i < N * words; i += 256) s_adj[i] = 0u;
+  if (tid < NS) {   // layer-0 bias + sigma-embedding part of the edge MLP (same for every edge of the pose)
+    const float* se = k.tparams + (size_t)p * TP_STRIDE;
+    float a = w.lig_edge.b0[tid];
+    for (int i = 0; i < NS; ++i) a = fmaf(w.lig_edge.w0[tid * 44 + 4 + i], se[i], a);
+    s_c0[tid] = a;
+  }
+  __syncthreads();
+  // radius search: for centre y scan x ascending, keep d^2 < 25, stop after 33 hits (incl. self), drop self.
+  for (int y = tid; y < N; y += 256) {
+    const float yx = s_pos[y * 3], yy = s_pos[y * 3 + 1], yz = s_pos[y * 3 + 2];
+    int cnt = 0;
+    for (int x = 0; x < N && cnt < 33; ++x) {
+      const float dx = s_pos[x * 3] - yx, dy = s_pos[x * 3 + 1] - yy, dz = s_pos[x * 3 + 2] - yz;
+      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      if (d2 < 25.0f) {
+        ++cnt;
+        if (x != y) s_adj[y * words + (x >> 5)] |= 1u << (x & 31);     // own row only: no race
+      }
+    }
+  }
+  __syncthreads();
+  // degree of scatter node a = #bond edges with src a + #centres y whose list contains a
+  for (int a = tid; a < N; a += 256) {
+    int deg = 0;
+    for (int e = 0; e < nbond; ++e) deg += (b.bond_src[bo0 + e] - l0 == a) ? 1 : 0;
+    for (int y = 0; y < N; ++y) deg += (s_adj[y * words + (a >> 5)] >> (a & 31)) & 1u;
+    s_deg[a] = deg;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int a = 0; a < N; ++a) { s_row[a] = run; run += s_deg[a]; }
+    s_row[N] = run;
+  }
+  __syncthreads();
+  for (int a = tid; a < N; a += 256) {
+    k.ll_rowptr[l0 + a] = base + s_row[a];
+    k.ll_rowend[l0 + a] = base + s_row[a + 1];
+    int o = base + s_row[a];
+    for (int e = 0; e < nbond; ++e)
+      if (b.bond_src[bo0 + e] - l0 == a) {
+        k.ll_nbr[o] = b.bond_dst[bo0 + e];
+        k.ll_src[o] = (l0 + a) | (b.bond_type[bo0 + e] << 28);      // stash the bond type in the top bits until the feature pass
+        ++o;
+      }
+    for (int y = 0; y < N; ++y)
+      if ((s_adj[y * words + (a >> 5)] >> (a & 31)) & 1u) {
+        k.ll_nbr[o] = l0 + y;
+        k.ll_src[o] = (l0 + a) | (7 << 28);
+        ++o;
+      }
+  }
+  __syncthreads();
+  const int E = s_row[N];
+  for (int e = tid; e < E; e += 256) {
+    const int o = base + e;
+    const int packed = k.ll_src[o];
+    const int bt = (packed >> 28) & 7, src = packed & 0x0fffffff, dst = k.ll_nbr[o];
+    k.ll_src[o] = src;
+    const float vx = s_pos[(dst - l0) * 3] - s_pos[(src - l0) * 3];
+    const float vy = s_pos[(dst - l0) * 3 + 1] - s_pos[(src - l0) * 3 + 1];
+    const float vz = s_pos[(dst - l0) * 3 + 2] - s_pos[(src - l0) * 3 + 2];
+    float sh[9];
+    sh9(vx, vy, vz, sh);
+    store_row<9>(k.ll_sh + (size_t)o * 9, sh);
+    float g[NS], h[NS], out[NS];
+    gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.lig_gauss_mu, w.lig_gauss_coeff, g);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) h[c] = s_c0[c] + (bt < 4 ? w.lig_edge.w0[c * 44 + bt] : 0.f);
+    matvec_acc<NS, NS>(w.lig_edge.w0, 44, 24, g, h);
+    mlp_tail20(w.lig_edge, h, out);
+    store_row<NS>(k.ll_emb + (size_t)o * NS, out);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// node embeddings per pose (:649-655, :662, boarder_analyze :898-935) and per-step phore edge embedding (:663)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void node_embed_kernel(DpBatch b, DpWeights w, DpWork k) {
+  __shared__ float s_ls[NS], s_ps[NS], s_pc[NS];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int l0 = b.lig_ptr[p], NL = b.lig_ptr[p + 1] - l0, p0 = b.ph_ptr[p], NP = b.ph_ptr[p + 1] - p0;
+  const float* se = k.tparams + (size_t)p * TP_STRIDE;
+  if (tid < NS) {
+    float a = w.lig_lin_b[tid], c = 0.f, d = 0.f;
+    for (int i = 0; i < NS; ++i) {
+      a = fmaf(w.lig_lin_w[tid * NS + i], se[i], a);
+      c = fmaf(w.ph_lin_w[tid * 22 + 2 + i], se[i], c);
+      d = fmaf(w.ph_edge.w0[tid * 40 + i], se[i], d);
+    }
+    s_ls[tid] = a; s_ps[tid] = c; s_pc[tid] = d;
+  }
+  __syncthreads();
+  for (int i = tid; i < NL; i += 256) {
+    const float x = b.pos[(l0 + i) * 3], y = b.pos[(l0 + i) * 3 + 1], z = b.pos[(l0 + i) * 3 + 2];
+    float dmin2 = -1.f;
+    for (int j = 0; j < NP; ++j)
+      if (b.ph_type[p0 + j] == EX) {
+        const float dx = x - b.ph_pos[(p0 + j) * 3], dy = y - b.ph_pos[(p0 + j) * 3 + 1], dz = z - b.ph_pos[(p0 + j) * 3 + 2];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        dmin2 = (dmin2 < 0.f || d2 < dmin2) ? d2 : dmin2;
+      }
+    const float dmin = dmin2 < 0.f ? 1e9f : sqrtf(dmin2);
+    float* o = k.h_l[0] + (size_t)(l0 + i) * 100;
+    const float* xe = k.lig_x_emb + (size_t)(l0 + i) * NS;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+      float v = xe[c] + s_ls[c];
+      float bd = w.boarder_lin_b[c] + w.boarder_lin_w[c] * dmin;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) bd += w.boarder_emb[(q * 2 + (dmin <= (float)(q + 1) ? 1 : 0)) * NS + c];
+      o[c] = v + bd;
+    }
+  }
+  for (int j = tid; j < NP; j += 256) {
+    float* o = k.h_p[0] + (size_t)(p0 + j) * 100;
+    const float* xe = k.ph_x_emb + (size_t)(p0 + j) * NS;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) o[c] = xe[c] + s_ps[c];
+  }
+  const int e0 = b.pp_ptr[p], e1 = b.pp_ptr[p + 1];
+  for (int e = e0 + tid; e < e1; e += 256) {
+    float h[NS], out[NS];
+    const float* pre = k.pp_pre + (size_t)e * NS;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) h[c] = pre[c] + s_pc[c];
+    mlp_tail20(w.ph_edge, h, out);
+    store_row<NS>(k.pp_emb + (size_t)e * NS, out);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dense ligand x pharmacophore cross edges per pose (_build_phoretype_cross_conv_graph :759-895, cross_edge_embedding :673)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w, DpWork k) {
+  __shared__ float s_cs[NS];
+  __shared__ float s_den[MAXN_L];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int l0 = b.lig_ptr[p], NL = b.lig_ptr[p + 1] - l0, p0 = b.ph_ptr[p], NP = b.ph_ptr[p + 1] - p0;
+  const int x0 = b.x_ptr[p], E = NL * NP;
+  if (tid < NS) {
+    const float* se = k.tparams + (size_t)p * TP_STRIDE;
+    float a = 0.f;
+    for (int i = 0; i < NS; ++i) a = fmaf(w.x_edge.w0[tid * 73 + i], se[i], a);
+    s_cs[tid] = a;
+  }
+  __syncthreads();
+  // pass 1: total_weight and its exponential (:801-811, :839)
+  for (int e = tid; e < E; e += 256) {
+    const int i = e / NP, j = e - i * NP;
+    const float vx = b.ph_pos[(p0 + j) * 3] - b.pos[(l0 + i) * 3];
+    const float vy = b.ph_pos[(p0 + j) * 3 + 1] - b.pos[(l0 + i) * 3 + 1];
+    const float vz = b.ph_pos[(p0 + j) * 3 + 2] - b.pos[(l0 + i) * 3 + 2];
+    float g[NS];
+    gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.x_gauss_mu, w.x_gauss_coeff, g);
+    float z = w.cdt.b3[0];
+#pragma unroll
+    for (int o = 0; o < 10; ++o) {
+      float s = w.cdt.b0[o];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) s = fmaf(w.cdt.w0[o * NS + q], g[q], s);
+      z = fmaf(w.cdt.w3[o], fmaxf(s, 0.f), z);
+    }
+    const float dist = softplus_f(z);
+    const float fm = k.pair_fm[(size_t)(l0 + i) * NPT + b.ph_type[p0 + j]];
+    const float tw = fm * (dist * 1.0f) * w.scaler;
+    k.x_ew[x0 + e] = expf(tw);
+  }
+  __syncthreads();
+  for (int i = tid; i < NL; i += 256) {     // scatter(..., reduce='sum') over the atom's edges, in edge order
+    float s = 0.f;
+    for (int j = 0; j < NP; ++j) s += k.x_ew[x0 + i * NP + j];
+    s_den[i] = s;
+  }
+  __syncthreads();
+  // pass 2: everything else
+  for (int e = tid; e < E; e += 256) {
+    const int i = e / NP, j = e - i * NP;
+    const int li = l0 + i, pj = p0 + j, ty = b.ph_type[pj];
+    float vx = b.ph_pos[pj * 3] - b.pos[li * 3];
+    float vy = b.ph_pos[pj * 3 + 1] - b.pos[li * 3 + 1];
+    float vz = b.ph_pos[pj * 3 + 2] - b.pos[li * 3 + 2];
+    float g[NS];
+    gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.x_gauss_mu, w.x_gauss_coeff, g);
+    // edge embedding: Linear(73,20) on [sigma emb | gauss | P], ReLU, Linear(20,20)
+    {
+      float h[NS], out[NS];
+      const float* pre = k.pair_pre + ((size_t)li * NPT + ty) * NS;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) h[c] = pre[c] + s_cs[c];
+      matvec_acc<NS, NS>(w.x_edge.w0, 73, 20, g, h);
+      mlp_tail20(w.x_edge, h, out);
+      store_row<NS>(k.x_emb + (size_t)(x0 + e) * NS, out);
+    }
+    // sign rule (:813-816) and softmax weight (:839,:845-848)
+    {
+      float z = w.cdt.b3[0];
+#pragma unroll
+      for (int o = 0; o < 10; ++o) {
+        float s = w.cdt.b0[o];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) s = fmaf(w.cdt.w0[o * NS + q], g[q], s);
+        z = fmaf(w.cdt.w3[o], fmaxf(s, 0.f), z);
+      }
+      const float tw = k.pair_fm[(size_t)li * NPT + ty] * (softplus_f(z) * 1.0f) * w.scaler;
+      float dz = w.pdt.b3[0];
+#pragma unroll
+      for (int o = 0; o < NPT; ++o) dz = fmaf(w.pdt.w3[o], leaky_f(fmaf(w.pdt.w0[o], tw, w.pdt.b0[o])), dz);
+      const float dir = leaky_f(dz) < 0.f ? -1.f : 1.f;
+      const float aw = k.x_ew[x0 + e] / s_den[i];
+      vx = vx * dir * aw; vy = vy * dir * aw; vz = vz * dir * aw;
+      float sh[9];
+      sh9(vx, vy, vz, sh);
+      store_row<9>(k.x_sh + (size_t)(x0 + e) * 9, sh);
+    }
+    // normal-vector rule (:874-889); only the phore's own type can agree (phoretype is one-hot)
+    {
+      const float a = ty == EX ? 0.f : b.phorefp[li * NPT + ty];
+      const float* ln = b.norm + (size_t)li * 33 + ty * 3;
+      const float lx = a * ln[0], ly = a * ln[1], lz = a * ln[2];
+      const float px = b.ph_norm[pj * 3], py = b.ph_norm[pj * 3 + 1], pz = b.ph_norm[pj * 3 + 2];
+      float rx = fmaxf(ly * pz - lz * py, 1e-12f) * a;       // torch.clip(cross, 1e-12) * sum(agreement)  (quirk N4)
+      float ry = fmaxf(lz * px - lx * pz, 1e-12f) * a;
+      float rz = fmaxf(lx * py - ly * px, 1e-12f) * a;
+      const float rn = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+      rx /= rn; ry /= rn; rz /= rn;
+      const float lnm = sqrtf(lx * lx + ly * ly + lz * lz), pnm = sqrtf(px * px + py * py + pz * pz);
+      const float mx = lx * pnm - lnm * px, my = ly * pnm - lnm * py, mz = lz * pnm - lnm * pz;
+      const float qx = lx * pnm + lnm * px, qy = ly * pnm + lnm * py, qz = lz * pnm + lnm * pz;
+      const float ang = 2.f * atan2f(sqrtf(mx * mx + my * my + mz * mz), sqrtf(qx * qx + qy * qy + qz * qz));
+      const float d1 = ang - a * b.norm_angle1[li * NPT + ty], d2 = ang - a * b.norm_angle2[li * NPT + ty];
+      const float dl = fabsf(d2) < fabsf(d1) ? d2 : d1;
+      float sh[9];
+      sh9(rx * dl, ry * dl, rz * dl, sh);
+      store_row<9>(k.x_nsh + (size_t)(x0 + e) * 9, sh);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// centre edges (build_center_conv_graph :381-406, center_edge_embedding :249-254,336)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void center_edges_kernel(DpBatch b, DpWeights w, DpWork k) {
+  __shared__ float s_c[3];
+  __shared__ float s_cs[NS];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
+  if (tid == 0) {     // index_add_ over the atoms in order, then / count
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int i = 0; i < N; ++i) { sx += b.pos[(l0 + i) * 3]; sy += b.pos[(l0 + i) * 3 + 1]; sz += b.pos[(l0 + i) * 3 + 2]; }
+    s_c[0] = sx / (float)N; s_c[1] = sy / (float)N; s_c[2] = sz / (float)N;
+  }
+  if (tid >= 64 && tid < 64 + NS) {
+    const int c = tid - 64;
+    const float* se = k.tparams + (size_t)p * TP_STRIDE;
+    float a = w.center_edge.b0[c];
+    for (int i = 0; i < NS; ++i) a = fmaf(w.center_edge.w0[c * 40 + 20 + i], se[i], a);
+    s_cs[c] = a;
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    const float vx = b.pos[(l0 + i) * 3] - s_c[0], vy = b.pos[(l0 + i) * 3 + 1] - s_c[1], vz = b.pos[(l0 + i) * 3 + 2] - s_c[2];
+    float sh[9], g[NS], h[NS], out[NS];
+    sh9(vx, vy, vz, sh);
+    store_row<9>(k.c_sh + (size_t)(l0 + i) * 9, sh);
+    gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.center_gauss_mu, w.center_gauss_coeff, g);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) h[c] = s_cs[c];
+    matvec_acc<NS, NS>(w.center_edge.w0, 40, 0, g, h);
+    mlp_tail20(w.center_edge, h, out);
+    store_row<NS>(k.c_emb + (size_t)(l0 + i) * NS, out);
+  }
+}
+
+// tr / rot heads (get_trtheta_score :340-352)
+__global__ void trrot_head_kernel(int B, DpWeights w, DpWork k, float* __restrict__ tr, float* __restrict__ rot) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B) return;
+  const float* g = k.gpred + (size_t)p * 12;
+  const float* tp = k.tparams + (size_t)p * TP_STRIDE;
+  float v[2][3];
+  for (int c = 0; c < 3; ++c) { v[0][c] = g[c] + g[6 + c]; v[1][c] = g[3 + c] + g[9 + c]; }
+  for (int hsel = 0; hsel < 2; ++hsel) {
+    const DpMlp& m = hsel == 0 ? w.tr_final : w.rot_final;
+    const float nrm = sqrtf(v[hsel][0] * v[hsel][0] + v[hsel][1] * v[hsel][1] + v[hsel][2] * v[hsel][2]);
+    float out = m.b3[0];
+    for (int o = 0; o < NS; ++o) {
+      float s = fmaf(m.w0[o * 21], nrm, m.b0[o]);
+      for (int i = 0; i < NS; ++i) s = fmaf(m.w0[o * 21 + 1 + i], tp[i], s);
+      out = fmaf(m.w3[o], fmaxf(s, 0.f), out);
+    }
+    const float scale = hsel == 0 ? 1.f / tp[20] : tp[23];
+    float* dst = (hsel == 0 ? tr : rot) + (size_t)p * 3;
+    for (int c = 0; c < 3; ++c) {
+      float x = v[hsel][c] / nrm * out;
+      x = hsel == 0 ? x / tp[20] : x * tp[23];
+      dst[c] = x;
+    }
+    (void)scale;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// torsion graph (build_bond_conv_graph :409-437, FullTensorProduct(sh, 2e) :276,365-366, edge attrs :368-369)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tor_graph_kernel(DpBatch b, DpWeights w, DpWork k, const float* __restrict__ h_l) {
+  __shared__ float s_pos[MAXN_L * 3];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
+  const int t0 = b.tor_ptr[p], T = b.tor_ptr[p + 1] - t0;
+  if (T == 0) return;
+  for (int i = tid; i < N * 3; i += 256) s_pos[i] = b.pos[(size_t)l0 * 3 + i];
+  __syncthreads();
+  // one thread per bond builds the capped neighbour list (torch_cluster.radius, max 32, index order)
+  for (int q = tid; q < T; q += 256) {
+    const int u = b.tor_u[t0 + q] - l0, v = b.tor_v[t0 + q] - l0;
+    const float cx = (s_pos[u * 3] + s_pos[v * 3]) / 2.f, cy = (s_pos[u * 3 + 1] + s_pos[v * 3 + 1]) / 2.f,
+                cz = (s_pos[u * 3 + 2] + s_pos[v * 3 + 2]) / 2.f;
+    const int slot0 = (t0 + q) * TOR_SLOTS;
+    int cnt = 0;
+    for (int x = 0; x < N && cnt < TOR_SLOTS; ++x) {
+      const float dx = s_pos[x * 3] - cx, dy = s_pos[x * 3 + 1] - cy, dz = s_pos[x * 3 + 2] - cz;
+      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      if (d2 < 25.0f) {
+        k.t_nbr[slot0 + cnt] = l0 + x;
+        k.t_src[slot0 + cnt] = t0 + q;
+        ++cnt;
+      }
+    }
+    k.t_rowptr[t0 + q] = slot0;
+    k.t_rowend[t0 + q] = slot0 + cnt;
+    for (int c = cnt; c < TOR_SLOTS; ++c) { k.t_nbr[slot0 + c] = l0; k.t_src[slot0 + c] = -1; }
+    // (h_l[u] + h_l[v])[:20]
+    const float* hu = h_l + (size_t)(l0 + u) * 100;
+    const float* hv = h_l + (size_t)(l0 + v) * 100;
+    for (int c = 0; c < NS; ++c) k.t_hb[(size_t)(t0 + q) * NS + c] = hu[c] + hv[c];
+  }
+  __syncthreads();
+  for (int e = tid; e < T * TOR_SLOTS; e += 256) {
+    const int q = e / TOR_SLOTS, slot = (t0 + q) * TOR_SLOTS + (e - q * TOR_SLOTS);
+    if (k.t_src[slot] < 0) continue;
+    const int u = b.tor_u[t0 + q] - l0, v = b.tor_v[t0 + q] - l0, x = k.t_nbr[slot] - l0;
+    const float cx = (s_pos[u * 3] + s_pos[v * 3]) / 2.f, cy = (s_pos[u * 3 + 1] + s_pos[v * 3 + 1]) / 2.f,
+                cz = (s_pos[u * 3 + 2] + s_pos[v * 3 + 2]) / 2.f;
+    const float vx = s_pos[x * 3] - cx, vy = s_pos[x * 3 + 1] - cy, vz = s_pos[x * 3 + 2] - cz;
+    float sh[9], bsh[9];
+    sh9(vx, vy, vz, sh);
+    sh9(s_pos[v * 3] - s_pos[u * 3], s_pos[v * 3 + 1] - s_pos[u * 3 + 1], s_pos[v * 3 + 2] - s_pos[u * 3 + 2], bsh);
+    const float* Y1 = sh + 1;
+    const float* Y2 = sh + 4;
+    const float* bb = bsh + 4;                 // Y_2e(bond vector)
+    float o7[7];
+    // FullTensorProduct 'uvuv', coefficient sqrt(2 l_out + 1):
+    //   0e <- 2e x 2e : sqrt(1) * (Y2 . b) / sqrt(5)
+    o7[0] = (Y2[0] * bb[0] + Y2[1] * bb[1] + Y2[2] * bb[2] + Y2[3] * bb[3] + Y2[4] * bb[4]) * 0.4472135954999579f;
+    //   1o <- 1o x 2e : sqrt(3) * sum_ij C(1,2,1)[i,j,k] Y1_i b_j = sqrt(3/10) * (M(b) Y1)_k
+    {
+      const float c = 0.57735026918962576451f * bb[2];
+      const float m00 = -c - bb[4], m11 = 2.f * c, m22 = -c + bb[4], m01 = bb[1], m02 = bb[0], m12 = bb[3];
+      const float f = 0.5477225575051661f;
+      o7[1] = f * (m00 * Y1[0] + m01 * Y1[1] + m02 * Y1[2]);
+      o7[2] = f * (m01 * Y1[0] + m11 * Y1[1] + m12 * Y1[2]);
+      o7[3] = f * (m02 * Y1[0] + m12 * Y1[1] + m22 * Y1[2]);
+    }
+    //   1e <- 2e x 2e : sqrt(3) * sum_ij C(2,2,1)[i,j,k] Y2_i b_j   (C(2,2,1) * sqrt(10): 1/sqrt3, 1, 2/sqrt3 entries)
+    {
+      const float a = 0.57735026918962576451f, c2 = 1.1547005383792517f, f = 0.5477225575051661f;
+      const float k0 = -a * Y2[0] * bb[1] + a * Y2[1] * bb[0] + Y2[2] * bb[3] - Y2[3] * bb[2] + a * Y2[3] * bb[4] - a * Y2[4] * bb[3];
+      const float k1 = -c2 * Y2[0] * bb[4] - a * Y2[1] * bb[3] + a * Y2[3] * bb[1] + c2 * Y2[4] * bb[0];
+      const float k2 = a * Y2[0] * bb[3] + Y2[1] * bb[2] + a * Y2[1] * bb[4] - Y2[2] * bb[1] - a * Y2[3] * bb[0] - a * Y2[4] * bb[1];
+      o7[4] = f * k0; o7[5] = f * k1; o7[6] = f * k2;
+    }
+    store_row<7>(k.t_sh + (size_t)slot * 7, o7);
+    float g[NS], h[NS], out[NS];
+    gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.lig_gauss_mu, w.lig_gauss_coeff, g);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) h[c] = w.final_edge.b0[c];
+    matvec_acc<NS, NS>(w.final_edge.w0, 20, 0, g, h);
+    mlp_tail20(w.final_edge, h, out);
+    store_row<NS>(k.t_emb + (size_t)slot * NS, out);
+  }
+}
+
+// tor_final_layer: Linear(40,20,no bias), Tanh, Linear(20,1,no bias); * sqrt(torus.score_norm(sigma))  (:286-291,372-377)
+__global__ void tor_head_kernel(DpBatch b, DpWeights w, DpWork k, float* __restrict__ tor) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b.n_tor) return;
+  // pose of this bond: binary search in tor_ptr
+  int lo = 0, hi = b.B;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.tor_ptr[mid] <= q) lo = mid; else hi = mid; }
+  const float* x = k.t_q + (size_t)q * 40;
+  float out = 0.f;
+  for (int o = 0; o < NS; ++o) {
+    float s = 0.f;
+    for (int i = 0; i < 40; ++i) s = fmaf(w.tor_w0[o * 40 + i], x[i], s);
+    out = fmaf(w.tor_w3[o], tanhf(s), out);
+  }
+  tor[q] = out * k.tparams[(size_t)lo * TP_STRIDE + 24];
+}
+
+}  // namespace dp
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI: orchestration
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+static int dp_check_batch(const DpBatch* b) {
+  if (!b || b->B <= 0) return DP_E_BADARG;
+  if (b->max_nl > dp::MAXN_L || b->max_np > dp::MAXN_P || b->max_t > dp::MAXT) return DP_E_TOOLARGE;
+  return DP_OK;
+}
+
+int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream) {
+  int rc = dp_check_batch(b);
+  if (rc) return rc;
+  if (!w || !k) return DP_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = b->n_lig > b->n_ph ? b->n_lig : b->n_ph;
+  hipLaunchKernelGGL(dp::static_nodes_kernel, dim3((n + 127) / 128), dim3(128), 0, st, *b, *w, *k);
+  if (b->n_pp > 0) hipLaunchKernelGGL(dp::static_pp_kernel, dim3((b->n_pp + 127) / 128), dim3(128), 0, st, *b, *w, *k);
+  return (int)hipGetLastError();
+}
+
+int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float* rot, float* tor, void* stream) {
+  int rc = dp_check_batch(b);
+  if (rc) return rc;
+  if (!w || !k || !tr || !rot || (b->n_tor > 0 && !tor)) return DP_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = b->B;
+  hipLaunchKernelGGL(dp::time_params_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, b->t, *w, k->tparams);
+  hipLaunchKernelGGL(dp::lig_graph_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  hipLaunchKernelGGL(dp::node_embed_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  hipLaunchKernelGGL(dp::cross_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  // workgroups per pose: keep <= 64 scatter nodes per workgroup and >= ~2 workgroups per CU in flight
+  int slices = 1;
+  {
+    const int mx = b->max_nl > b->max_np ? b->max_nl : b->max_np;
+    while ((mx + slices - 1) / slices > 64) ++slices;
+    while (B * slices < 512 && slices < 8) ++slices;
+  }
+  int cur = 0;
+  static const int D[5] = {20, 50, 80, 100, 100};
+  for (int l = 0; l < 4; ++l) {
+    const float* hl = k->h_l[cur];
+    const float* hp = k->h_p[cur];
+    float* hl2 = k->h_l[cur ^ 1];
+    float* hp2 = k->h_p[cur ^ 1];
+    const int din = D[l];
+    DpConvArgs a;
+    // ligand side: lig_conv (+ residual stream), phore_to_lig, phore_to_lig_norm      (:678-689, :703-706)
+    memset(&a, 0, sizeof(a));
+    a.kind = l; a.B = B; a.slices = slices; a.lig_ptr = b->lig_ptr; a.ph_ptr = b->ph_ptr; a.x_ptr = b->x_ptr;
+    a.sh_stride = 9; a.out_stride = 100; a.resid_stride = 100;
+    a.gather_stride = a.attr1_stride = a.attr2_stride = 100;
+    {
+      DpConvArgs c = a;
+      c.mode = DP_EDGES_CSR; c.scat_ptr = b->lig_ptr; c.rowptr = k->ll_rowptr; c.rowend = k->ll_rowend; c.nbr = k->ll_nbr;
+      c.edge_scat = k->ll_src; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hl; c.edge_emb = k->ll_emb; c.edge_sh = k->ll_sh;
+      c.w1p = w->lig_conv[l].w1p; c.w2p = w->lig_conv[l].w2p; c.bn_scale = w->lig_conv[l].bn_scale; c.bn_shift = w->lig_conv[l].bn_shift;
+      c.out = hl2; c.accumulate = 0; c.resid = hl; c.resid_width = din;
+      if ((rc = dp_tp_conv(&c, st))) return rc;
+    }
+    for (int nv = 0; nv < 2; ++nv) {
+      DpConvArgs c = a;
+      const DpConvW& cw = nv ? w->p2l_norm_conv[l] : w->p2l_conv[l];
+      c.mode = DP_EDGES_P2L; c.scat_ptr = b->lig_ptr; c.gather_tab = hp; c.attr1_tab = hl; c.attr2_tab = hp;
+      c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
+      c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
+      c.out = hl2; c.accumulate = 1;
+      if ((rc = dp_tp_conv(&c, st))) return rc;
+    }
+    if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
+      {
+        DpConvArgs c = a;
+        c.mode = DP_EDGES_CSR; c.scat_ptr = b->ph_ptr; c.rowptr = b->pp_rowptr; c.rowend = b->pp_rowend; c.nbr = b->pp_dst;
+        c.edge_scat = b->pp_src; c.gather_tab = hp; c.attr1_tab = hp; c.attr2_tab = hp; c.edge_emb = k->pp_emb; c.edge_sh = k->pp_sh;
+        c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
+        c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
+        if ((rc = dp_tp_conv(&c, st))) return rc;
+      }
+      for (int nv = 0; nv < 2; ++nv) {
+        DpConvArgs c = a;
+        const DpConvW& cw = nv ? w->l2p_norm_conv[l] : w->l2p_conv[l];
+        c.mode = DP_EDGES_L2P; c.scat_ptr = b->ph_ptr; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hp;
+        c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
+        c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
+        c.out = hp2; c.accumulate = 1;
+        if ((rc = dp_tp_conv(&c, st))) return rc;
+      }
+    }
+    cur ^= 1;
+  }
+  const float* hl = k->h_l[cur];
+  // translation / rotation head
+  hipLaunchKernelGGL(dp::center_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  {
+    DpConvArgs c;
+    memset(&c, 0, sizeof(c));
+    c.kind = DP_CONV_FINAL; c.mode = DP_EDGES_CENTER; c.B = B; c.slices = 1; c.scat_ptr = b->pose_ptr; c.lig_ptr = b->lig_ptr;
+    c.gather_tab = hl; c.gather_stride = 100; c.attr1_tab = hl; c.attr1_stride = 100;
+    c.edge_emb = k->c_emb; c.edge_sh = k->c_sh; c.sh_stride = 9;
+    c.w1p = w->final_conv.w1p; c.w2p = w->final_conv.w2p; c.bn_scale = w->final_conv.bn_scale; c.bn_shift = w->final_conv.bn_shift;
+    c.out = k->gpred; c.out_stride = 12;
+    if ((rc = dp_tp_conv(&c, st))) return rc;
+  }
+  hipLaunchKernelGGL(dp::trrot_head_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, *w, *k, tr, rot);
+  // torsion head
+  if (b->n_tor > 0) {
+    hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k, hl);
+    DpConvArgs c;
+    memset(&c, 0, sizeof(c));
+    c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr;
+    c.slices = 1;
+    while ((b->max_t + c.slices - 1) / c.slices > 64) ++c.slices;
+    c.rowptr = k->t_rowptr; c.rowend = k->t_rowend; c.nbr = k->t_nbr; c.edge_scat = k->t_src;
+    c.gather_tab = hl; c.gather_stride = 100; c.attr1_tab = hl; c.attr1_stride = 100; c.attr2_tab = k->t_hb; c.attr2_stride = 20;
+    c.attr_swap = 1; c.edge_emb = k->t_emb; c.edge_sh = k->t_sh; c.sh_stride = 7;
+    c.w1p = w->tor_conv.w1p; c.w2p = w->tor_conv.w2p; c.bn_scale = w->tor_conv.bn_scale; c.bn_shift = w->tor_conv.bn_shift;
+    c.out = k->t_q; c.out_stride = 40;
+    if ((rc = dp_tp_conv(&c, st))) return rc;
+    hipLaunchKernelGGL(dp::tor_head_kernel, dim3((b->n_tor + 63) / 64), dim3(64), 0, st, *b, *w, *k, tor);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""Drop-in for the reference sampler entry points (src/utils/sampling.py:16-63, 174-280) on the HIP path.
+
+`sampling_phore` keeps the reference signature.  All N poses are packed ONCE into a device-resident batch; the whole
+reverse-diffusion loop then runs on the GPU (score model + conformer update per step, no host synchronisation and no
+per-step collate / H2D / D2H as in sampling.py:210-254); results are written back into `data_list` at the end.
+
+Extra, optional keywords:
+    noise      pre-drawn normals {'tr': [S,N,3], 'rot': [S,N,3], 'tor': [S,sum T]} (pose-major) so that a CPU oracle and
+               this path consume identical noise.  With noise=None the numbers are drawn from the global torch CPU
+               generator in exactly the reference's order (per `batch_size` chunk: z_tr, z_rot, z_tor; sampling.py:230-243).
+    engine     a prepared `diffphore_amd.engine.Engine` to reuse a packed batch across calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as R
+
+from . import _lib
+from .engine import DpStepParams, Engine, PackedBatch, _declare, _stream
+
+
+def _step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero_noise) -> DpStepParams:
+    """Scalars of one reverse step (sampling.py:205-244), evaluated in float64 like the reference, stored as float32."""
+    last = t_idx == inference_steps - 1
+    t_tr, t_rot, t_tor = tr_schedule[t_idx], rot_schedule[t_idx], tor_schedule[t_idx]
+    dt_tr = tr_schedule[t_idx] - tr_schedule[t_idx + 1] if not last else tr_schedule[t_idx]
+    dt_rot = rot_schedule[t_idx] - rot_schedule[t_idx + 1] if not last else rot_schedule[t_idx]
+    dt_tor = tor_schedule[t_idx] - tor_schedule[t_idx + 1] if not last else tor_schedule[t_idx]
+    tr_sigma, rot_sigma, tor_sigma = t_to_sigma(t_tr, t_rot, t_tor)
+    tr_g = float(tr_sigma) * np.sqrt(2 * np.log(model_args.tr_sigma_max / model_args.tr_sigma_min))
+    rot_g = 2 * float(rot_sigma) * np.sqrt(np.log(model_args.rot_sigma_max / model_args.rot_sigma_min))
+    tor_g = float(tor_sigma) * np.sqrt(2 * np.log(model_args.tor_sigma_max / model_args.tor_sigma_min))
+    sp = DpStepParams()
+    half = 0.5 if ode else 1.0
+    sp.tr_c1, sp.rot_c1, sp.tor_c1 = half * tr_g ** 2 * dt_tr, half * rot_g ** 2 * dt_rot, half * tor_g ** 2 * dt_tor
+    nz = 0.0 if (ode or zero_noise) else 1.0
+    sp.tr_c2, sp.rot_c2, sp.tor_c2 = nz * tr_g * np.sqrt(dt_tr), nz * rot_g * np.sqrt(dt_rot), nz * tor_g * np.sqrt(dt_tor)
+    sp.no_torsion = 1 if getattr(model_args, "no_torsion", False) else 0
+    return sp
+
+
+def _draw_reference_order(N, T_per_pose: np.ndarray, batch_size: int):
+    """One step's normals from the global CPU generator in the reference's order (per chunk: tr, rot, tor)."""
+    ztr, zrot, ztor = [], [], []
+    for lo in range(0, N, batch_size):
+        b = min(batch_size, N - lo)
+        ztr.append(torch.normal(mean=0, std=1, size=(b, 3)))
+        zrot.append(torch.normal(mean=0, std=1, size=(b, 3)))
+        ztor.append(torch.normal(mean=0, std=1, size=(int(T_per_pose[lo:lo + b].sum()),)))
+    return torch.cat(ztr), torch.cat(zrot), torch.cat(ztor)
+
+
+def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
+                   no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
+                   confidence_model_args=None, batch_size=20, no_final_step_noise=False, noise=None, engine: Optional[Engine] = None,
+                   write_back=True):
+    if confidence_model is not None:
+        raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
+    N = len(data_list)
+    eng = engine if engine is not None else Engine(model.device_model, PackedBatch(data_list, device))
+    pb = eng.pb
+    dev = pb.device
+    if engine is not None:   # caller-managed engine: refresh the diffusion state from data_list
+        pb.set_state(torch.cat([g["ligand"].pos for g in data_list]), torch.cat([g["ligand"].norm.reshape(-1, 33) for g in data_list]))
+    no_torsion = bool(getattr(model_args, "no_torsion", False))
+    for t_idx in range(inference_steps):
+        last = t_idx == inference_steps - 1
+        zero = no_random or (no_final_step_noise and last)
+        sp = _step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero)
+        pb.set_time(float(tr_schedule[t_idx]), float(rot_schedule[t_idx]), float(tor_schedule[t_idx]))
+        z_tr = z_rot = z_tor = None
+        if not (ode or zero):
+            if noise is not None:
+                z_tr, z_rot, z_tor = noise["tr"][t_idx], noise["rot"][t_idx], noise["tor"][t_idx]
+            else:
+                z_tr, z_rot, z_tor = _draw_reference_order(N, pb.nt, batch_size)
+            z_tr = z_tr.to(dev, torch.float32).contiguous()
+            z_rot = z_rot.to(dev, torch.float32).contiguous()
+            z_tor = z_tor.to(dev, torch.float32).contiguous() if (not no_torsion and z_tor.numel()) else None
+        eng.sample_step(sp, z_tr, z_rot, z_tor)
+        if visualization_list is not None:
+            pos = pb.pos.cpu()
+            for idx, vis in enumerate(visualization_list):
+                lo, hi = int(pb.lig_ptr[idx]), int(pb.lig_ptr[idx + 1])
+                vis.add((pos[lo:hi] + data_list[idx].original_center).detach().cpu(), part=1, order=t_idx + 2)
+    if write_back:
+        status = eng.ws.t["status"].cpu()
+        if bool((status != 0).any()):
+            # the reference raises from torch.linalg.svd and the caller string-matches this text (inference.py:211)
+            raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status).flatten().tolist()}")
+        pos, norm = pb.pos.cpu(), pb.norm.cpu()
+        for i, g in enumerate(data_list):
+            lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
+            g["ligand"].pos = pos[lo:hi].clone()
+            g["ligand"].norm = norm[lo:hi].clone()
+    return data_list, None
+
+
+def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, keep_update=False, device="cuda", draws=None):
+    """sampling.py:16-63.  Random numbers come from the same global generators, in the same order, as the reference
+    (np.random.uniform per graph, then per graph scipy `R.random()` and `torch.normal`); the geometry runs in
+    `dp_randomize_position`.  `draws` (list of dicts 'tor','rot','tr') overrides the RNG for reproducible tests."""
+    L = _declare()
+    L.dp_randomize_position.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]
+    L.dp_randomize_position.restype = C.c_int
+    pb = PackedBatch(data_list, device)
+    thetas, rots, trs = [], [], []
+    if not no_torsion:
+        for i, g in enumerate(data_list):
+            T = int(pb.nt[i])
+            th = draws[i]["tor"] if draws is not None else np.random.uniform(low=-np.pi, high=np.pi, size=T)
+            thetas.append(torch.as_tensor(np.asarray(th), dtype=torch.float64))
+            if keep_update:
+                g.fw_tor_update = np.asarray(th)
+    for i, g in enumerate(data_list):
+        rot = draws[i]["rot"] if draws is not None else R.random().as_matrix()
+        rots.append(torch.from_numpy(np.asarray(rot)).float())
+        if not no_random:
+            tr = draws[i]["tr"] if draws is not None else torch.normal(mean=0, std=tr_sigma_max, size=(1, 3))
+            trs.append(torch.as_tensor(tr).float().reshape(1, 3))
+            if keep_update:
+                g.fw_tr_update = trs[-1].numpy()
+        if keep_update:
+            g.fw_rot_update = rots[-1].numpy()
+    dev = pb.device
+    theta = torch.cat(thetas).float().to(dev) if thetas and sum(t.numel() for t in thetas) else None
+    rm = torch.stack(rots).contiguous().to(dev)
+    tr = torch.cat(trs).contiguous().to(dev) if trs else None
+    _lib.check(L.dp_randomize_position(C.byref(pb.struct), _lib.ptr(theta), rm.data_ptr(), _lib.ptr(tr), 1 if no_torsion else 0,
+                                       _stream()), "dp_randomize_position")
+    pos, norm = pb.pos.cpu(), pb.norm.cpu()
+    for i, g in enumerate(data_list):
+        lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
+        g["ligand"].pos = pos[lo:hi].clone()
+        g["ligand"].norm = norm[lo:hi].clone()

@@ -1,0 +1,127 @@
+"""Drop-in for `TensorProductScoreModel` (src/models/score_model_phore.py:152-310) backed by the HIP library.
+
+Same constructor keywords (the released configuration only - anything else raises), same `forward(data)` contract:
+reads the hetero-graph batch fields listed in SURVEY.md 8a, returns `(tr_pred [B,3], rot_pred [B,3], tor_pred [sum T])`
+on the model device, and leaves `node_sigma_emb` / `graph_sigma_emb` on `data` like the reference does (:342,717,744).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import config as cfgmod
+from .engine import DeviceModel, Engine, PackedBatch
+from .weights import init_state_dict
+
+_KW = {"lig_max_radius": "lig_max_radius", "num_conv_layers": "num_conv_layers", "sigma_embed_dim": "sigma_embed_dim",
+       "distance_embed_dim": "distance_embed_dim", "cross_distance_embed_dim": "cross_distance_embed_dim", "ns": "ns", "nv": "nv",
+       "scale_by_sigma": "scale_by_sigma", "batch_norm": "batch_norm", "dropout": "dropout",
+       "use_second_order_repr": "use_second_order_repr", "cross_max_distance": "cross_max_distance",
+       "consider_norm": "consider_norm", "auto_phorefp": "auto_phorefp", "angle_match": "angle_match",
+       "cross_distance_transition": "cross_distance_transition", "phore_direction_transition": "phore_direction_transition",
+       "phoretype_match_transition": "phoretype_match_transition", "new": "new", "boarder": "boarder", "by_radius": "by_radius",
+       "use_att": "use_att", "use_phore_match_feat": "use_phore_match_feat", "atom_weight": "atom_weight", "scaler": "scaler",
+       "multiple": "multiple", "no_torsion": "no_torsion", "sh_lmax": "sh_lmax", "phoretype_match": "phoretype_match",
+       "phore_max_radius": "phore_max_radius", "center_max_distance": "center_max_distance",
+       "in_lig_edge_features": "in_lig_edge_features"}
+
+
+class TensorProductScoreModel:
+    def __init__(self, t_to_sigma=None, device="cuda", timestep_emb_func=None, sigma_args=None, **kwargs):
+        cfg = cfgmod.ModelConfig()
+        if "clash_cutoff" in kwargs:
+            cfg.clash_cutoff = tuple(float(x) for x in kwargs.pop("clash_cutoff"))
+        for k, v in kwargs.items():
+            if k in _KW:
+                setattr(cfg, _KW[k], v)
+        if sigma_args is not None:
+            for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max", "tor_sigma_min", "tor_sigma_max"):
+                setattr(cfg, k, float(getattr(sigma_args, k)))
+        elif t_to_sigma is not None and hasattr(t_to_sigma, "keywords") and "args" in t_to_sigma.keywords:
+            a = t_to_sigma.keywords["args"]                 # partial(t_to_sigma_compl, args=args)  (inference.py:408)
+            for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max", "tor_sigma_min", "tor_sigma_max"):
+                setattr(cfg, k, float(getattr(a, k)))
+        cfg.check_supported()
+        self.cfg = cfg
+        self.t_to_sigma = t_to_sigma
+        self.device = torch.device(device)
+        self.no_torsion = cfg.no_torsion
+        self.training = False
+        self._sd = None
+        self._dev: Optional[DeviceModel] = None
+        self._cache_key = None
+        self._engine: Optional[Engine] = None
+
+    # ---- nn.Module-like surface used by the reference callers (inference.py:437-443) --------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        self._sd = state_dict
+        self._dev = DeviceModel(state_dict, self.cfg, self.device)
+        self._engine = None
+        return self
+
+    def init_random(self, seed: int = 20250321):
+        return self.load_state_dict(init_state_dict(seed, self.cfg))
+
+    def state_dict(self):
+        return self._sd
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            self.device = torch.device(device)
+            if self._sd is not None:
+                self.load_state_dict(self._sd)
+        return self
+
+    @property
+    def device_model(self) -> DeviceModel:
+        if self._dev is None:
+            raise RuntimeError("load_state_dict(...) or init_random() must be called before forward()")
+        return self._dev
+
+    # ---- forward ------------------------------------------------------------------------------------------------------
+    def engine_for(self, data) -> Engine:
+        """Pack `data` (a collated batch) - reusing the packed topology when the same batch object comes back."""
+        key = (id(data), int(data["ligand"].pos.shape[0]), int(data["phore"].pos.shape[0]))
+        if self._engine is None or self._cache_key != key:
+            graphs = data.to_data_list() if hasattr(data, "to_data_list") else [data]
+            self._engine = Engine(self.device_model, PackedBatch(graphs, self.device))
+            self._cache_key = key
+        return self._engine
+
+    def forward(self, data):
+        eng = self.engine_for(data)
+        pb = eng.pb
+        pb.set_state(torch.as_tensor(data["ligand"].pos), torch.as_tensor(data["ligand"].norm))
+        ct = data.complex_t
+        pb.set_time(ct["tr"], ct["rot"], ct["tor"])
+        tr, rot, tor = eng.forward()
+        tp = eng.ws.t["tparams"]
+        data["ligand"].node_sigma_emb = tp[:, :20].repeat_interleave(torch.as_tensor(pb.nl, device=tp.device), dim=0)
+        data["phore"].node_sigma_emb = tp[:, :20].repeat_interleave(torch.as_tensor(pb.np_, device=tp.device), dim=0)
+        data.graph_sigma_emb = tp[:, :20].clone()
+        if self.no_torsion or tor.numel() == 0:
+            return tr.clone(), rot.clone(), torch.empty(0, device=tr.device)
+        return tr.clone(), rot.clone(), tor.clone()
+
+    __call__ = forward
+
+
+def get_model(args, device, t_to_sigma, no_parallel=True, confidence_mode=False, contrastive_model=None):
+    """Mirror of src/utils/utils.py:113-176 for model_type == 'diff' (always `no_parallel`: one process per GPU)."""
+    g = lambda k, d=None: getattr(args, k, d)        # noqa: E731
+    return TensorProductScoreModel(
+        t_to_sigma=t_to_sigma, device=device, sigma_args=args if hasattr(args, "tr_sigma_min") else None,
+        no_torsion=g("no_torsion", False), num_conv_layers=g("num_conv_layers", 4), lig_max_radius=g("max_radius", 5.0),
+        scale_by_sigma=g("scale_by_sigma", True), sigma_embed_dim=g("sigma_embed_dim", 20), ns=g("ns", 20), nv=g("nv", 10),
+        distance_embed_dim=g("distance_embed_dim", 20), cross_distance_embed_dim=g("cross_distance_embed_dim", 20),
+        batch_norm=not g("no_batch_norm", False), dropout=g("dropout", 0.0), use_second_order_repr=g("use_second_order_repr", False),
+        cross_max_distance=g("cross_max_distance", 25.0), consider_norm=g("consider_norm", True), auto_phorefp=g("auto_phorefp", False),
+        angle_match=g("angle_match", True), cross_distance_transition=g("cross_distance_transition", True),
+        phore_direction_transition=g("phore_direction_transition", True), phoretype_match_transition=g("phoretype_match_transition", True),
+        new=g("new", True), boarder=g("boarder", False), by_radius=g("by_radius", False),
+        clash_cutoff=g("clash_cutoff", [1.0, 2.0, 3.0, 4.0, 5.0]), use_att=g("use_att", False),
+        use_phore_match_feat=g("use_phore_match_feat", False), atom_weight=g("atom_weight", "softmax"), scaler=g("scaler", 1.0))

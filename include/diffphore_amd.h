@@ -64,6 +64,7 @@ typedef struct DpConvArgs {
   const int32_t* rowptr;     /* [n_scatter] first edge slot of each scatter node */
   const int32_t* rowend;     /* [n_scatter] one-past-last edge slot */
   const int32_t* nbr;        /* [n_edge_slots] gather node of each edge */
+  const int32_t* edge_scat;  /* [n_edge_slots] scatter node of each edge (edges sorted by it) */
   /* node tables */
   const float* gather_tab;   /* features gathered through the TP: [n, D_in] */
   int32_t gather_stride;
@@ -102,6 +103,116 @@ int dp_conv_dims(int32_t kind, int32_t* d_in, int32_t* d_out, int32_t* numel, in
 /* HOST pointers: reorder one TensorProductConvLayer's fc parameters (reference state_dict layout) into MFMA operand order */
 int dp_pack_conv_weights(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
                          float* w1p, float* w2p);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Packed batch of B poses (struct of arrays, CSR offsets per pose).  One "pose" = one (ligand conformer, pharmacophore)
+ * sample of the reference's data_list (sampling.py:184,210).  Static fields come from the reference's graph builder
+ * (pdbbind_phore.py:1143-1188); `pos` / `norm` are the diffusion state.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct DpBatch {
+  int32_t B;
+  int32_t n_lig, n_ph, n_bond, n_tor, n_pp, n_x, ll_cap;  /* totals over the batch */
+  int32_t max_nl, max_np, max_t;                           /* per-pose maxima (kernel limits: 256 / 256 / 128) */
+  /* pose CSRs, B+1 entries */
+  const int32_t *lig_ptr, *ph_ptr, *bond_ptr, *tor_ptr, *pp_ptr, *x_ptr, *ll_ptr, *mask_ptr;
+  const int32_t* pose_ptr;    /* [B+1] = 0..B (scatter CSR of the centre conv) */
+  /* ligand, static */
+  const int32_t* lig_x;       /* [n_lig,16] categorical atom features                     process_mols.py:162-179 */
+  const int32_t *bond_src, *bond_dst, *bond_type; /* [n_bond] directed bonds, global atom ids, type 0..3 (one-hot index) */
+  const int32_t *tor_u, *tor_v;                   /* [n_tor] rotatable bonds (edge_index[:, edge_mask])  torsion.py:13-61 */
+  const uint8_t* mask_rotate; /* per pose T x N_l bytes at mask_ptr[p]                    torsion.py:54-61 */
+  const float* phorefp;       /* [n_lig,11] */
+  const float *norm_angle1, *norm_angle2;         /* [n_lig,11] */
+  /* pharmacophore, static */
+  const float* ph_pos;        /* [n_ph,3] */
+  const float* ph_norm;       /* [n_ph,3] unit normal or 0 */
+  const int32_t* ph_x;        /* [n_ph,3] categorical: type, is-EX idx, has-norm idx      process_pharmacophore.py:717-748 */
+  const float* ph_scalar;     /* [n_ph,2] alpha, weight */
+  const int32_t* ph_type;     /* [n_ph] argmax of the one-hot `phoretype`; 10 = exclusion sphere */
+  const int32_t *pp_src, *pp_dst;                 /* [n_pp] phore-phore edges sorted by src, global node ids */
+  const int32_t *pp_rowptr, *pp_rowend;           /* [n_ph] */
+  /* diffusion state */
+  float* pos;                 /* [n_lig,3] */
+  float* norm;                /* [n_lig,33] ligand normal buffer (atom-major [N,11,3]) */
+  const float* t;             /* [B,3] diffusion times (tr, rot, tor) per pose            diffusion_utils.py:181-207 */
+} DpBatch;
+
+typedef struct DpMlp { const float *w0, *b0, *w3, *b3; } DpMlp;   /* nn.Sequential(Linear, act, Dropout, Linear) */
+typedef struct DpConvW { const float *w1p, *w2p, *bn_scale, *bn_shift; } DpConvW;
+
+/* Device pointers into the uploaded parameter blob.  Reference names: score_model_phore.py:248-291, 524-641. */
+typedef struct DpWeights {
+  const float* lig_emb;        /* 16 embedding tables concatenated, [sum dims, 20] */
+  const float *lig_lin_w, *lig_lin_b;            /* encoder.lig_node_embedding.linear   [20,20] */
+  const float* boarder_emb;    /* [5,2,20] */
+  const float *boarder_lin_w, *boarder_lin_b;    /* [20,1], [20] */
+  const float* ph_emb;         /* 3 tables concatenated [15,20] */
+  const float *ph_lin_w, *ph_lin_b;              /* [20,22] (alpha, weight, sigma emb) */
+  DpMlp lig_edge, ph_edge, x_edge;               /* 44->20->20, 40->20->20, 73->20->20 */
+  DpMlp cdt, pdt, pmt;                           /* cross_distance / phore_direction / phoretype_match transitions */
+  DpMlp center_edge, final_edge, tr_final, rot_final;
+  const float *tor_w0, *tor_w3;                  /* tor_final_layer: [20,40], [1,20], no bias */
+  DpConvW lig_conv[4], ph_conv[4], l2p_conv[4], p2l_conv[4], l2p_norm_conv[4], p2l_norm_conv[4];
+  DpConvW final_conv, tor_conv;
+  const float* so3_table;      /* [1000] so3._exp_score_norms as float                 utils/so3.py:92-96 */
+  const float* torus_table;    /* [5001] torus.score_norm_ as float                    utils/torus.py:82-86 */
+  const float *lig_gauss_mu, *ph_gauss_mu, *x_gauss_mu, *center_gauss_mu;     /* GaussianSmearing.offset buffers [20] */
+  const float* emb_freq;       /* [10] exp(-k ln(10000)/9) as the reference computes it (float32, torch CPU) */
+  float lig_gauss_coeff, ph_gauss_coeff, x_gauss_coeff, center_gauss_coeff;  /* GaussianSmearing.coeff (python floats) */
+  float scaler;                /* 100.0 */
+  float tr_smin, tr_smax, rot_smin, rot_smax, tor_smin, tor_smax;
+  float emb_scale;             /* 10000 */
+} DpWeights;
+
+/* Caller-owned scratch; sizes in floats/ints are given by dp_work_sizes(). */
+typedef struct DpWork {
+  /* one-time static tables (dp_prepare) */
+  float* lig_x_emb;    /* [n_lig,20] */
+  float* ph_x_emb;     /* [n_ph,20]  */
+  float* pair_pre;     /* [n_lig,11,20] static part of cross_edge_embedding layer 0 per (atom, phore type) */
+  float* pair_fm;      /* [n_lig,11] softplus(phoretype_match_transition) per (atom, phore type) */
+  float* pp_pre;       /* [n_pp,20] static part of phore_edge_embedding layer 0 */
+  float* pp_sh;        /* [n_pp,9] */
+  /* per-forward */
+  float* tparams;      /* [B,32]: sigma emb (20) | tr_sigma, rot_sigma, tor_sigma, so3 norm, sqrt(torus norm) | pad */
+  int32_t *ll_rowptr, *ll_rowend;   /* [n_lig] */
+  int32_t *ll_nbr, *ll_src;         /* [ll_cap] */
+  float *ll_emb, *ll_sh;            /* [ll_cap,20], [ll_cap,9] */
+  float* pp_emb;                    /* [n_pp,20] */
+  float *x_emb, *x_sh, *x_nsh;      /* [n_x,20], [n_x,9], [n_x,9] */
+  float* x_ew;                      /* [n_x] exp(total_weight) */
+  float *h_l[2], *h_p[2];           /* [n_lig,100], [n_ph,100] ping-pong */
+  float *c_emb, *c_sh;              /* [n_lig,20], [n_lig,9] centre edges */
+  float* gpred;                     /* [B,12] */
+  int32_t *t_rowptr, *t_rowend, *t_nbr, *t_src;   /* [n_tor], [n_tor], [n_tor*32], [n_tor*32] */
+  float *t_emb, *t_sh, *t_hb, *t_q;               /* [n_tor*32,20], [n_tor*32,7], [n_tor,20], [n_tor,40] */
+  int32_t* status;                  /* [B] 0 ok, bit0 Kabsch degenerate / non-finite */
+} DpWork;
+
+typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */
+  float tr_c1, tr_c2;               /* tr_perturb  = tr_c1 * tr_score  + tr_c2 * z_tr   (c1 = g^2 dt or g^2 dt / 2 for ODE) */
+  float rot_c1, rot_c2;
+  float tor_c1, tor_c2;
+  int32_t no_torsion;
+} DpStepParams;
+
+/* one-time per batch: embedding sums and other step-invariant tables */
+int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream);
+/* score model forward: writes tr [B,3], rot [B,3], tor [n_tor].   score_model_phore.py:294-310 */
+int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float* rot, float* tor, void* stream);
+/* SDE/ODE perturbation + modify_conformer for every pose (updates b->pos / b->norm in place).
+ * sampling.py:223-254, diffusion_utils.py:23-79.  z_* may be NULL (treated as zeros). */
+int dp_conformer_update(const DpBatch* b, const DpStepParams* sp, const float* tr, const float* rot, const float* tor,
+                        const float* z_tr, const float* z_rot, const float* z_tor, int32_t* status, void* stream);
+/* randomize_position (sampling.py:16-63): theta [n_tor] random torsion angles, rot_mats [B,3,3] random rotations, tr [B,3]
+ * translation (NULL = no_random).  The random numbers are drawn by the caller, exactly as the reference draws them. */
+int dp_randomize_position(const DpBatch* b, const float* theta, const float* rot_mats, const float* tr, int32_t no_torsion, void* stream);
+/* dp_forward + dp_conformer_update */
+int dp_sample_step(const DpBatch* b, const DpWeights* w, DpWork* k, const DpStepParams* sp, float* tr, float* rot, float* tor,
+                   const float* z_tr, const float* z_rot, const float* z_tor, void* stream);
+
+/* sizeof() of DpConvArgs, DpBatch, DpWeights, DpWork, DpStepParams, DpMlp (binding self-check) */
+int dp_struct_sizes(int32_t* out, int32_t n);
 
 int dp_abi_version(void);
 

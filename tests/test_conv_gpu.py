@@ -87,6 +87,8 @@ def test_conv_csr_ragged(kind, slices):
     slot_of = torch.tensor(slot_of)
     nbr_slots = torch.zeros(E_slots, dtype=torch.int32)
     nbr_slots[slot_of] = torch.tensor(nbr, dtype=torch.int32)
+    scat_slots = torch.full((E_slots,), -1, dtype=torch.int32)
+    scat_slots[slot_of] = torch.tensor(scatter, dtype=torch.int32)
     emb = torch.randn(E_slots, 20, generator=g)
     sh = torch.randn(E_slots, 9, generator=g)
     sh[:, 0] = 1.0
@@ -99,7 +101,7 @@ def test_conv_csr_ragged(kind, slices):
     out = torch.full((N, dims["d_out"]), float("nan")).cuda()
     keep = []
     base = dict(kind=kind, mode=_lib.EDGES_CSR, B=B, slices=slices, scat_ptr=_dev(_i32(scat_ptr)),
-                rowptr=_dev(_i32(rowptr)), rowend=_dev(_i32(rowend)), nbr=_dev(nbr_slots),
+                rowptr=_dev(_i32(rowptr)), rowend=_dev(_i32(rowend)), nbr=_dev(nbr_slots), edge_scat=_dev(scat_slots),
                 gather_tab=_dev(h), gather_stride=dims["d_in"], attr1_tab=_dev(h), attr1_stride=dims["d_in"],
                 attr2_tab=_dev(h), attr2_stride=dims["d_in"], attr_swap=0, edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9,
                 w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]), bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]),
@@ -219,7 +221,7 @@ def test_conv_center_and_torsion_kinds():
     pk = packing.pack_conv(sd, "tor_bond_conv", 5)
     out = torch.full((nb, 40), float("nan")).cuda()
     _run(dict(kind=5, mode=_lib.EDGES_CSR, B=B, slices=1, scat_ptr=_dev(_i32(tor_ptr)), rowptr=_dev(_i32(rowptr)),
-              rowend=_dev(_i32(rowend)), nbr=_dev(_i32(nbr)), gather_tab=_dev(hl), gather_stride=100,
+              rowend=_dev(_i32(rowend)), nbr=_dev(_i32(nbr)), edge_scat=_dev(_i32(scat)), gather_tab=_dev(hl), gather_stride=100,
               attr1_tab=_dev(hl), attr1_stride=100, attr2_tab=_dev(hb), attr2_stride=20, attr_swap=1,
               edge_emb=_dev(temb), edge_sh=_dev(sh7), sh_stride=7, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]),
               bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]), out=out, out_stride=40, accumulate=0,
