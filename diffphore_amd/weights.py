@@ -23,9 +23,9 @@ def _linear(sd, prefix, fan_in, fan_out, g, bias=True, scale=1.0):
         sd[prefix + ".bias"] = (torch.rand(fan_out, generator=g) * 2 - 1) * bound * scale
 
 
-def _embedding(sd, prefix, num, dim, g):
+def _embedding(sd, prefix, num, dim, g, scale=1.0):
     bound = math.sqrt(6.0 / (num + dim))          # xavier_uniform (score_model_phore.py:57)
-    sd[prefix + ".weight"] = (torch.rand(num, dim, generator=g) * 2 - 1) * bound
+    sd[prefix + ".weight"] = (torch.rand(num, dim, generator=g) * 2 - 1) * bound * scale
 
 
 def _bn(sd, prefix, irreps, g):
@@ -44,7 +44,8 @@ def _conv(sd, prefix, n_edge, hidden, numel, out_irreps, g, w_gain):
     _bn(sd, prefix + ".batch_norm", out_irreps, g)
 
 
-def init_state_dict(seed: int = 20250321, cfg: C.ModelConfig = None, w_gain: float = 2.0) -> "OrderedDict[str, torch.Tensor]":
+def init_state_dict(seed: int = 20250321, cfg: C.ModelConfig = None, w_gain: float = 3.0,
+                    head_gain: float = 0.3, emb_gain: float = 0.25) -> "OrderedDict[str, torch.Tensor]":
     """Random weights in the reference layout (SURVEY.md §8d "Weights"); deterministic in `seed`."""
     cfg = cfg or C.ModelConfig()
     cfg.check_supported()
@@ -52,17 +53,20 @@ def init_state_dict(seed: int = 20250321, cfg: C.ModelConfig = None, w_gain: flo
     ns, sd_dim, dd = cfg.ns, cfg.sigma_embed_dim, cfg.distance_embed_dim
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     e = "encoder."
+    # Synthetic-weight conditioning (no trained checkpoint ships): the radial MLP makes the TP weights a function of the
+    # node scalars, so an un-normalised random net grows ~quadratically per layer.  Small node embeddings (emb_gain) keep
+    # the 4-layer stack and 20-step trajectories bounded; the TP weights get w_gain so messages still matter.
     for i in range(len(cfg.clash_cutoff)):
-        _embedding(sd, f"{e}boarder_embedding.atom_embedding_list.{i}", 2, ns, g)
-    _linear(sd, e + "boarder_embedding.linear", 1, ns, g)
+        _embedding(sd, f"{e}boarder_embedding.atom_embedding_list.{i}", 2, ns, g, scale=emb_gain)
+    _linear(sd, e + "boarder_embedding.linear", 1, ns, g, scale=0.05 * emb_gain)     # multiplies a distance in Angstrom
     for i, d in enumerate(C.LIG_FEATURE_DIMS):
-        _embedding(sd, f"{e}lig_node_embedding.atom_embedding_list.{i}", d, ns, g)
-    _linear(sd, e + "lig_node_embedding.linear", sd_dim, ns, g)
+        _embedding(sd, f"{e}lig_node_embedding.atom_embedding_list.{i}", d, ns, g, scale=emb_gain)
+    _linear(sd, e + "lig_node_embedding.linear", sd_dim, ns, g, scale=emb_gain)
     _linear(sd, e + "lig_edge_embedding.0", cfg.in_lig_edge_features + sd_dim + dd, ns, g)
     _linear(sd, e + "lig_edge_embedding.3", ns, ns, g)
     for i, d in enumerate(C.PHORE_FEATURE_DIMS):
-        _embedding(sd, f"{e}phore_node_embedding.atom_embedding_list.{i}", d, ns, g)
-    _linear(sd, e + "phore_node_embedding.linear", 2 + sd_dim, ns, g)
+        _embedding(sd, f"{e}phore_node_embedding.atom_embedding_list.{i}", d, ns, g, scale=2 * emb_gain)
+    _linear(sd, e + "phore_node_embedding.linear", 2 + sd_dim, ns, g, scale=emb_gain)
     _linear(sd, e + "phore_edge_embedding.0", sd_dim + dd, ns, g)
     _linear(sd, e + "phore_edge_embedding.3", ns, ns, g)
     _linear(sd, e + "cross_edge_embedding.0", sd_dim + cfg.cross_distance_embed_dim + 33, ns, g)
@@ -94,14 +98,15 @@ def init_state_dict(seed: int = 20250321, cfg: C.ModelConfig = None, w_gain: flo
     _linear(sd, "center_edge_embedding.3", ns, ns, g)
     _conv(sd, "final_conv", 2 * ns, 2 * ns, C.tp_paths(C.SEQ[3], C.SH, C.FINAL_OUT)[1], C.FINAL_OUT, g, w_gain)
     _linear(sd, "tr_final_layer.0", 1 + sd_dim, ns, g)
-    _linear(sd, "tr_final_layer.3", ns, 1, g)
+    # untrained score heads would throw the ligand tens of Angstrom per step (score ~ |MLP| / sigma): damp the synthetic heads
+    _linear(sd, "tr_final_layer.3", ns, 1, g, scale=head_gain)
     _linear(sd, "rot_final_layer.0", 1 + sd_dim, ns, g)
-    _linear(sd, "rot_final_layer.3", ns, 1, g)
+    _linear(sd, "rot_final_layer.3", ns, 1, g, scale=head_gain)
     _linear(sd, "final_edge_embedding.0", dd, ns, g)
     _linear(sd, "final_edge_embedding.3", ns, ns, g)
     _conv(sd, "tor_bond_conv", 3 * ns, 3 * ns, C.tp_paths(C.SEQ[3], C.TOR_SH, C.TOR_OUT)[1], C.TOR_OUT, g, w_gain)
     _linear(sd, "tor_final_layer.0", 2 * ns, ns, g, bias=False)
-    _linear(sd, "tor_final_layer.3", ns, 1, g, bias=False)
+    _linear(sd, "tor_final_layer.3", ns, 1, g, bias=False, scale=3 * head_gain)
     return sd
 
 
