@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py - DiffPhore reverse-diffusion hot path on MI355X.
+
+One "step" = one reverse-diffusion step (score-model forward + SDE perturbation + conformer update) over the whole
+per-GPU batch of poses, inputs resident in HBM.  Workload at N=1: BASELINE.json configs[1] - 512 synthetic
+ligand-pharmacophore pairs (30 atoms, 8 torsions, 32 pharmacophore nodes), fp32.  With --gpus N each rank runs its own
+512 poses (independent samples: no data-path collective; one RCCL broadcast of the weight blob at start-up), weak scaling.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused TP conv, layer-2 instantiation): algorithmic
+bytes of SURVEY.md 8d per launch / mean launch duration measured with HIP events recorded inside dp_forward on the
+launch stream during the timed steps.  `cpu_baseline` = this repo's CPU oracle (reference-style torch-CPU restatement,
+fp32) timed on a bounded sample of the same workload on the host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from diffphore_amd import config, synthetic, weights  # noqa: E402
+from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn  # noqa: E402
+
+ALG_BYTES_PER_EDGE = {0: 2516, 1: 4636, 2: 6756, 3: 9236}      # 4*(numel + D_in + 9) per edge-conv, fp32
+HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+PROF_LAYER, PROF_CONV = 2, 1                                     # layer-2 phore->ligand conv: dense cross edge set
+
+
+class HipEvents:
+    def __init__(self, n):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.ev = []
+        for _ in range(2 * n):
+            e = C.c_void_p()
+            assert self.hip.hipEventCreate(C.byref(e)) == 0
+            self.ev.append(e)
+
+    def pair(self, i):
+        return self.ev[2 * i], self.ev[2 * i + 1]
+
+    def ms(self, i):
+        a, b = self.pair(i)
+        self.hip.hipEventSynchronize(b)
+        out = C.c_float()
+        rc = self.hip.hipEventElapsedTime(C.byref(out), a, b)
+        return out.value if rc == 0 else float("nan")
+
+
+def cpu_baseline(graphs, sd, cfg, args, n_poses, n_steps):
+    """Reference-style CPU path (oracle, fp32, torch threads = all host cores) on a bounded sample of the workload."""
+    import copy
+    from oracle import sampler as osampler
+    from oracle.model import OracleScoreModel
+    from oracle.tables import load_tables
+    torch.set_num_threads(os.cpu_count() or 1)
+    om = OracleScoreModel(sd, cfg, dtype=torch.float32, tables=load_tables())
+    sample = copy.deepcopy(graphs[:n_poses])
+    sched = get_t_schedule(20)[:n_steps + 1]
+    t0 = time.perf_counter()
+    osampler.sampling_phore(sample, om, n_steps, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=20)
+    dt = time.perf_counter() - t0
+    return dict(value=n_poses * n_steps / dt, unit="pose-steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_poses} poses x {n_steps} steps of the same workload, oracle (torch-CPU fp32 restatement), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--poses", type=int, default=512, help="poses per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-poses", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)     # RCCL on ROCm
+
+    from diffphore_amd.engine import DeviceModel, Engine, PackedBatch
+    from diffphore_amd.sampling import _step_params
+    import types
+
+    cfg = config.ModelConfig()
+    margs = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                  "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    shape = synthetic.CONFIGS[a.config]
+    n_pairs = a.poses
+    graphs = synthetic.synthetic_pairs(a.config, n_pairs, shape["n_atoms"], shape["n_tor"], shape["n_phore"],
+                                       seed=synthetic.BASE_SEED + a.config + 1000 * rank)
+    sd = weights.init_state_dict()
+    model = DeviceModel(sd, cfg, dev)
+    if world > 1:
+        # the only collective of the job: weights from rank 0 to every GPU over xGMI
+        dist.broadcast(model.blob, src=0)
+        torch.cuda.synchronize()
+    # initial state: randomize_position on the device (same call the sampler's callers make, inference.py:185)
+    from diffphore_amd.sampling import randomize_position
+    np.random.seed(607201 + rank)
+    torch.manual_seed(607201 + rank)
+    randomize_position(graphs, False, False, cfg.tr_sigma_max, device=dev)
+    pb = PackedBatch(graphs, dev)
+    eng = Engine(model, pb)
+    S_total = 20
+    sched = get_t_schedule(S_total)
+    t2s = t_to_sigma_fn(margs)
+    gen = torch.Generator(device=dev).manual_seed(607201 + rank)
+    B, nT = pb.B, int(pb.tor_ptr[-1])
+    # pre-drawn noise resident in HBM (the reference draws it on the host inside the loop, sampling.py:230-243)
+    zs = [(torch.randn(B, 3, device=dev, generator=gen), torch.randn(B, 3, device=dev, generator=gen),
+           torch.randn(max(nT, 1), device=dev, generator=gen)) for _ in range(a.warmup + a.steps)]
+    ev = HipEvents(a.steps)
+
+    def step(i, prof_idx=None):
+        t_idx = i % S_total
+        sp = _step_params(t_idx, S_total, sched, sched, sched, t2s, margs, False, False)
+        pb.set_time(float(sched[t_idx]), float(sched[t_idx]), float(sched[t_idx]))
+        w = eng.ws.struct
+        if prof_idx is None:
+            w.prof_start, w.prof_stop = None, None
+        else:
+            s0, s1 = ev.pair(prof_idx)
+            w.prof_start, w.prof_stop, w.prof_layer, w.prof_conv = s0, s1, PROF_LAYER, PROF_CONV
+        z = zs[i]
+        eng.sample_step(sp, z[0], z[1], z[2] if nT else None)
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i, prof_idx=i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    bad = int((eng.ws.t["status"] != 0).sum().item())
+    finite = bool(torch.isfinite(pb.pos).all().item())
+
+    kern_ms = float(np.nanmean([ev.ms(i) for i in range(a.steps)]))
+    n_x = int(pb.x_ptr[-1])
+    alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else float("nan")
+
+    if rank == 0:
+        total_poses = B * world
+        out = {
+            "metric": "poses/sec (samples x steps) on the reverse-diffusion hot path",
+            "value": total_poses * a.steps / elapsed,
+            "unit": "pose-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{a.config}]: {B} synthetic lig-phore pairs per GPU "
+                                   f"({shape['n_atoms']} atoms, {shape['n_tor']} torsions, {shape['n_phore']} phore nodes), "
+                                   f"one reverse-diffusion step per bench step, fp32, random-init weights",
+                       "poses_per_gpu": B, "poses_per_sec_at_20_steps": total_poses * a.steps / elapsed / 20.0,
+                       "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
+                       "kabsch_flagged_poses": bad, "finite": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "dp::tp_conv_kernel<2> (layer-2 phore->ligand conv, dense cross edges)",
+                         "kernel_ms": kern_ms, "edges_per_launch": n_x, "alg_bytes_per_edge": ALG_BYTES_PER_EDGE[PROF_LAYER],
+                         "note": "per-edge TP weights are generated in-register by fp32 MFMA and never touch HBM; 'achieved' "
+                                 "prices the launch with the e3nn operator-boundary byte count (SURVEY.md 8d)",
+                         "mfma_fp32_tflops": (2 * (3600 + 60 * 1600) + 6400) * n_x / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(graphs, sd, cfg, margs, a.cpu_poses, a.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

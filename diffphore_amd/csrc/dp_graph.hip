@@ -587,6 +587,13 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   }
   int cur = 0;
   static const int D[5] = {20, 50, 80, 100, 100};
+  auto timed = [&](const DpConvArgs& c, int layer, int which) -> int {
+    const bool prof = k->prof_start && k->prof_stop && k->prof_layer == layer && k->prof_conv == which;
+    if (prof) hipEventRecord((hipEvent_t)k->prof_start, st);
+    const int r = dp_tp_conv(&c, st);
+    if (prof) hipEventRecord((hipEvent_t)k->prof_stop, st);
+    return r;
+  };
   for (int l = 0; l < 4; ++l) {
     const float* hl = k->h_l[cur];
     const float* hp = k->h_p[cur];
@@ -605,7 +612,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_scat = k->ll_src; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hl; c.edge_emb = k->ll_emb; c.edge_sh = k->ll_sh;
       c.w1p = w->lig_conv[l].w1p; c.w2p = w->lig_conv[l].w2p; c.bn_scale = w->lig_conv[l].bn_scale; c.bn_shift = w->lig_conv[l].bn_shift;
       c.out = hl2; c.accumulate = 0; c.resid = hl; c.resid_width = din;
-      if ((rc = dp_tp_conv(&c, st))) return rc;
+      if ((rc = timed(c, l, 0))) return rc;
     }
     for (int nv = 0; nv < 2; ++nv) {
       DpConvArgs c = a;
@@ -614,7 +621,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
-      if ((rc = dp_tp_conv(&c, st))) return rc;
+      if ((rc = timed(c, l, 1 + nv))) return rc;
     }
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
       {
@@ -623,7 +630,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_scat = b->pp_src; c.gather_tab = hp; c.attr1_tab = hp; c.attr2_tab = hp; c.edge_emb = k->pp_emb; c.edge_sh = k->pp_sh;
         c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
-        if ((rc = dp_tp_conv(&c, st))) return rc;
+        if ((rc = timed(c, l, 3))) return rc;
       }
       for (int nv = 0; nv < 2; ++nv) {
         DpConvArgs c = a;
@@ -632,7 +639,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
-        if ((rc = dp_tp_conv(&c, st))) return rc;
+        if ((rc = timed(c, l, 4 + nv))) return rc;
       }
     }
     cur ^= 1;

@@ -187,6 +187,11 @@ typedef struct DpWork {
   int32_t *t_rowptr, *t_rowend, *t_nbr, *t_src;   /* [n_tor], [n_tor], [n_tor*32], [n_tor*32] */
   float *t_emb, *t_sh, *t_hb, *t_q;               /* [n_tor*32,20], [n_tor*32,7], [n_tor,20], [n_tor,40] */
   int32_t* status;                  /* [B] 0 ok, bit0 Kabsch degenerate / non-finite */
+  /* optional timing hook: if prof_start/prof_stop are hipEvent_t handles, dp_forward records them on the launch stream
+   * immediately before / after the tensor-product conv (prof_layer, prof_conv); prof_conv: 0 lig-lig, 1 phore->lig,
+   * 2 phore->lig (normals), 3 phore-phore, 4 lig->phore, 5 lig->phore (normals). */
+  void *prof_start, *prof_stop;
+  int32_t prof_layer, prof_conv;
 } DpWork;
 
 typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */
