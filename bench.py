@@ -61,7 +61,7 @@ def cpu_baseline(graphs, sd, cfg, args, n_poses, n_steps):
     from oracle import sampler as osampler
     from oracle.model import OracleScoreModel
     from oracle.tables import load_tables
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads only add fork/join overhead on these small ops
     om = OracleScoreModel(sd, cfg, dtype=torch.float32, tables=load_tables())
     sample = copy.deepcopy(graphs[:n_poses])
     sched = get_t_schedule(20)[:n_steps + 1]
@@ -80,8 +80,8 @@ def main():
     ap.add_argument("--poses", type=int, default=512, help="poses per GPU")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-poses", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-poses", type=int, default=40)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -61,18 +61,17 @@ def gaussian_smearing(d: torch.Tensor, stop: float, n: int = 20) -> torch.Tensor
 
 def radius_neighbors(x: torch.Tensor, batch_x: torch.Tensor, y: torch.Tensor, batch_y: torch.Tensor, r: float,
                      max_num_neighbors: int):
-    """torch_cluster.radius (CUDA semantics): returns (row=y index, col=x index), y-major, x ascending, capped."""
-    rows, cols = [], []
-    r2 = r * r
-    for iy in range(y.shape[0]):
-        cand = torch.nonzero(batch_x == batch_y[iy]).flatten()
-        d2 = ((x[cand] - y[iy]) ** 2).sum(-1)
-        hit = cand[d2 < r2][:max_num_neighbors]
-        rows.append(torch.full_like(hit, iy))
-        cols.append(hit)
-    if not rows:
+    """torch_cluster.radius (CUDA semantics): returns (row=y index, col=x index), y-major, x ascending, capped.
+
+    Dense restatement: d^2 = ((x - y)^2).sum(-1) in the input precision, strict `<`, first `max_num_neighbors` hits per y
+    in x-index order."""
+    if y.shape[0] == 0 or x.shape[0] == 0:
         return torch.zeros(2, 0, dtype=torch.long)
-    return torch.stack([torch.cat(rows), torch.cat(cols)])
+    d2 = ((y[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+    hit = (d2 < r * r) & (batch_y[:, None] == batch_x[None, :])
+    hit = hit & (torch.cumsum(hit.to(torch.int64), dim=1) <= max_num_neighbors)
+    rows, cols = torch.nonzero(hit, as_tuple=True)
+    return torch.stack([rows, cols])
 
 
 def radius_graph(pos: torch.Tensor, r: float, batch: torch.Tensor, max_num_neighbors: int = 32) -> torch.Tensor:
@@ -231,11 +230,10 @@ class OracleScoreModel:
         dt = self.dtype
         lpos, ppos = L.pos.to(dt), P.pos.to(dt)
         is_ex = P.phoretype[:, -1] == 1
-        dis_min = torch.empty(lpos.shape[0], dtype=dt)
-        for i in range(lpos.shape[0]):
-            m = (P.batch == L.batch[i]) & is_ex
-            # reference: min over the padded dense row of (cdist + (1-mask)*1e9); >=1 padded/non-EX column always exists
-            dis_min[i] = (lpos[i] - ppos[m]).norm(dim=-1).min() if m.any() else 1e9
+        # reference: min over the padded dense row of (cdist + (1-mask)*1e9); a masked-out column always exists -> 1e9 cap
+        d = (lpos[:, None, :] - ppos[None, :, :]).norm(dim=-1)
+        m = (L.batch[:, None] == P.batch[None, :]) & is_ex[None, :]
+        dis_min = torch.where(m, d, torch.full_like(d, 1e9)).min(dim=1).values if ppos.shape[0] else torch.full((lpos.shape[0],), 1e9, dtype=dt)
         cut = torch.tensor(list(self.cfg.clash_cutoff), dtype=dt)
         clashed = dis_min[:, None] <= cut[None, :]
         return clashed, dis_min[:, None]
