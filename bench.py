@@ -28,6 +28,9 @@ from diffphore_amd import config, synthetic, weights  # noqa: E402
 from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn  # noqa: E402
 
 ALG_BYTES_PER_EDGE = {0: 2516, 1: 4636, 2: 6756, 3: 9236}      # 4*(numel + D_in + 9) per edge-conv, fp32
+ALG_FLOPS_PER_EDGE = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400}   # radial-MLP GEMM + TP
+MFMA_F32_PEAK_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+MEASURED_TRAFFIC_BYTES = int((2 * 37654.0 + 6000.0) * 1024)       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, cfg2, this kernel+slot
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 PROF_LAYER, PROF_CONV = 2, 1                                     # layer-2 phore->ligand conv: dense cross edge set
 
@@ -165,6 +168,8 @@ def main():
     kern_ms = float(np.nanmean([ev.ms(i) for i in range(a.steps)]))
     n_x = int(pb.x_ptr[-1])
     alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
+    flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * n_x
+    traffic = MEASURED_TRAFFIC_BYTES if (a.config == 2 and a.poses == 512) else None
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else float("nan")
 
     if rank == 0:
@@ -183,13 +188,20 @@ def main():
                        "poses_per_gpu": B, "poses_per_sec_at_20_steps": total_poses * a.steps / elapsed / 20.0,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
                        "kabsch_flagged_poses": bad, "finite": finite},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            # The dominant kernel generates the per-edge TP weights with fp32 MFMA in registers (they never reach HBM), so it is
+            # bound by the fp32 matrix pipe; SURVEY.md 8d asks for both views when the radial MLP is fused into the TP kernel.
+            "roofline": {"bound": "mfma", "achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None,
+                         "traffic": traffic,
                          "kernel": "dp::tp_conv_kernel<2> (layer-2 phore->ligand conv, dense cross edges)",
-                         "kernel_ms": kern_ms, "edges_per_launch": n_x, "alg_bytes_per_edge": ALG_BYTES_PER_EDGE[PROF_LAYER],
-                         "note": "per-edge TP weights are generated in-register by fp32 MFMA and never touch HBM; 'achieved' "
-                                 "prices the launch with the e3nn operator-boundary byte count (SURVEY.md 8d)",
-                         "mfma_fp32_tflops": (2 * (3600 + 60 * 1600) + 6400) * n_x / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None},
+                         "kernel_ms": kern_ms, "edges_per_launch": n_x,
+                         "alg_flops_per_edge": ALG_FLOPS_PER_EDGE[PROF_LAYER], "alg_bytes_per_edge": ALG_BYTES_PER_EDGE[PROF_LAYER],
+                         "hbm_equivalent": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                                            "note": "algorithmic bytes of the e3nn operator boundary (per-edge weights counted as "
+                                                    "HBM input, SURVEY.md 8d) / launch time; the metric's 'fused TP-scatter HBM GB/s'"},
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950 "
+                                         "correction), profiles/r1_conv_hbm_traffic.csv; null for non-default workloads"},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graphs, sd, cfg, margs, a.cpu_poses, a.cpu_steps)
