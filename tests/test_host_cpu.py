@@ -1,0 +1,111 @@
+"""Host-side logic on CPU: container, synthetic inputs, reference-layout weights, schedule helpers, step scalars."""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from diffphore_amd import config, diffusion, synthetic, weights
+from diffphore_amd.hetero import Batch
+
+
+def test_batch_roundtrip_and_offsets():
+    gs = synthetic.synthetic_pairs(3, 4, (8, 20), (0, 5), (6, 30))
+    b = Batch.from_data_list(gs)
+    assert b.num_graphs == 4
+    n = sum(g["ligand"].pos.shape[0] for g in gs)
+    assert b["ligand"].batch.shape[0] == n and int(b["ligand", "ligand"].edge_index.max()) < n
+    assert int(b["phore", "phore"].edge_index.max()) < b["phore"].pos.shape[0]
+    for a, c in zip(gs, b.to_data_list()):
+        for k in ("pos", "x", "norm", "phorefp", "edge_mask"):
+            assert torch.equal(torch.as_tensor(a["ligand"][k]), torch.as_tensor(c["ligand"][k]))
+        assert np.array_equal(a["ligand"].mask_rotate, c["ligand"].mask_rotate)
+        assert torch.equal(a["ligand", "ligand"].edge_index, c["ligand", "ligand"].edge_index)
+        assert torch.equal(a["phore", "phore"].edge_index, c["phore", "phore"].edge_index)
+        assert torch.equal(a["phore"].phoretype, c["phore"].phoretype)
+
+
+def test_synthetic_inputs_follow_reference_layout():
+    gs = synthetic.synthetic_pairs(2, 3, 30, 8, 32)
+    gs2 = synthetic.synthetic_pairs(2, 3, 30, 8, 32)
+    for g, h in zip(gs, gs2):
+        assert torch.equal(g["ligand"].pos, h["ligand"].pos)                    # deterministic in the seed
+        L, P = g["ligand"], g["phore"]
+        n = L.pos.shape[0]
+        assert L.x.shape == (n, 16) and L.norm.shape == (n, 33) and L.phorefp.shape == (n, 11)
+        assert int(L.edge_mask.sum()) == 8 and L.mask_rotate.shape == (8, n)
+        ei = g["ligand", "ligand"].edge_index
+        assert torch.equal(ei[:, 0::2], ei[:, 1::2].flip(0))                    # both directions adjacent (process_mols.py:270-274)
+        assert torch.all(g["ligand", "ligand"].edge_attr.sum(1) == 1)
+        rb = ei[:, L.edge_mask]
+        for k in range(8):                                                      # flagged direction: u outside, v inside (torsion.py:94-95)
+            assert not L.mask_rotate[k, int(rb[0, k])] and L.mask_rotate[k, int(rb[1, k])]
+            assert 2 <= L.mask_rotate[k].sum() <= n // 2
+        assert torch.all(L.phorefp[:, 10] == 0)
+        assert P.x.shape == (32, 5) and torch.all(P.phoretype.sum(1) == 1)
+        ex = P.phoretype[:, 10] == 1
+        assert torch.equal(P.x[:, 1] == 0, ex) and int(ex.sum()) == 26
+        assert torch.allclose(P.pos.mean(0), torch.zeros(3), atol=1e-5)         # centred on the phore centroid
+        nn_ = P.norm.norm(dim=1)
+        assert torch.all((nn_ < 1e-6) | ((nn_ - 1).abs() < 1e-5))
+
+
+def test_state_dict_layout_matches_parameter_inventory():
+    sd = weights.init_state_dict()
+    assert sd["encoder.lig_conv_layers.3.fc.3.weight"].shape == (2200, 60)
+    assert sd["encoder.phore_to_lig_norm_conv_layers.0.fc.3.weight"].shape == (600, 60)
+    assert sd["encoder.lig_to_phore_conv_layers.2.batch_norm.running_var"].shape == (60,)
+    assert sd["encoder.lig_conv_layers.0.batch_norm.running_mean"].shape == (20,)
+    assert sd["final_conv.batch_norm.running_mean"].shape == (0,) and sd["final_conv.batch_norm.weight"].shape == (4,)
+    assert sd["tor_bond_conv.fc.3.weight"].shape == (1600, 60) and sd["tor_final_layer.0.weight"].shape == (20, 40)
+    assert "tor_final_layer.0.bias" not in sd
+    assert sd["encoder.cross_edge_embedding.0.weight"].shape == (20, 73)
+    assert sd["encoder.lig_node_embedding.atom_embedding_list.0.weight"].shape == (119, 20)
+    n_par = sum(v.numel() for k, v in sd.items() if not k.endswith("offset") and "running" not in k)
+    assert 2.1e6 < n_par < 2.3e6                                               # SURVEY: ~2.2 M parameters
+    # tolerant loader: DataParallel prefix + e3nn-internal buffers are dropped, shapes are checked
+    noisy = {("module." + k): v for k, v in sd.items()}
+    noisy["module.encoder.lig_conv_layers.0.tp.weight"] = torch.zeros(0)
+    noisy["module.encoder.lig_conv_layers.0.tp.output_mask"] = torch.ones(50)
+    noisy["module.final_tp_tor.output_mask"] = torch.ones(45)
+    clean = weights.clean_state_dict(noisy)
+    assert list(clean.keys()) == list(sd.keys())
+    bad = dict(sd)
+    bad["tr_final_layer.0.weight"] = torch.zeros(20, 5)
+    with pytest.raises(ValueError):
+        weights.clean_state_dict(bad)
+    del bad["tr_final_layer.0.weight"]
+    with pytest.raises(KeyError):
+        weights.clean_state_dict(bad)
+
+
+def test_unsupported_configurations_are_rejected():
+    c = config.ModelConfig()
+    c.check_supported()
+    for k, v in (("ns", 16), ("use_att", True), ("use_second_order_repr", True), ("atom_weight", "softmax"), ("consider_norm", False)):
+        c2 = copy.deepcopy(c)
+        setattr(c2, k, v)
+        with pytest.raises(NotImplementedError):
+            c2.check_supported()
+    assert [config.layer_numel(l) for l in range(4)] == [600, 1100, 1600, 2200]
+
+
+def test_step_scalars_follow_the_reference_formulas():
+    from diffphore_amd.sampling import _step_params
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    sched = diffusion.get_t_schedule(20)
+    assert np.allclose(sched, np.linspace(1, 0.05, 20))
+    t2s = diffusion.t_to_sigma_fn(args)
+    sp = _step_params(0, 20, sched, sched, sched, t2s, args, False, False)
+    tr_g = 5.0 * np.sqrt(2 * np.log(50.0))                                      # sampling.py:223 at t = 1
+    assert abs(sp.tr_c1 - tr_g ** 2 * 0.05) < 1e-4 and abs(sp.tr_c2 - tr_g * np.sqrt(0.05)) < 1e-5
+    rot_g = 2 * 1.5 * np.sqrt(np.log(15.0))
+    assert abs(sp.rot_c1 - rot_g ** 2 * 0.05) < 1e-5
+    last = _step_params(19, 20, sched, sched, sched, t2s, args, False, True)    # dt = t on the last step; no_final_step_noise
+    assert last.tr_c2 == 0.0 and abs(last.tor_c1 - (t2s(0.05, 0.05, 0.05)[2] * np.sqrt(2 * np.log(100.0))) ** 2 * 0.05) < 1e-7
+    ode = _step_params(3, 20, sched, sched, sched, t2s, args, True, False)
+    sde = _step_params(3, 20, sched, sched, sched, t2s, args, False, False)
+    assert abs(ode.tr_c1 - 0.5 * sde.tr_c1) < 1e-7 and ode.tr_c2 == 0.0
