@@ -15,12 +15,14 @@ VOIDP = C.c_void_p
 DP_ABI_VERSION = 1
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
+PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
 EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER = range(4)
 
 
 class DpConvArgs(C.Structure):
     _fields_ = [
-        ("kind", c_i32), ("mode", c_i32), ("B", c_i32), ("slices", c_i32),
+        ("kind", c_i32), ("mode", c_i32), ("B", c_i32), ("slices", c_i32), ("precision", c_i32),
         ("scat_ptr", VOIDP), ("lig_ptr", VOIDP), ("ph_ptr", VOIDP), ("x_ptr", VOIDP),
         ("rowptr", VOIDP), ("rowend", VOIDP), ("nbr", VOIDP), ("edge_scat", VOIDP),
         ("gather_tab", VOIDP), ("gather_stride", c_i32),
@@ -62,11 +64,11 @@ def _declare(L):
     L.dp_tp_conv.restype = C.c_int
     L.dp_conv_w1p_floats.argtypes = [c_i32]
     L.dp_conv_w1p_floats.restype = C.c_int
-    L.dp_conv_w2p_floats.argtypes = [c_i32]
+    L.dp_conv_w2p_floats.argtypes = [c_i32, c_i32]
     L.dp_conv_w2p_floats.restype = C.c_int
     L.dp_conv_dims.argtypes = [c_i32] + [c_i32p] * 5
     L.dp_conv_dims.restype = C.c_int
-    L.dp_pack_conv_weights.argtypes = [c_i32, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP]
+    L.dp_pack_conv_weights.argtypes = [c_i32, c_i32, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP]
     L.dp_pack_conv_weights.restype = C.c_int
 
 

@@ -227,6 +227,214 @@ __device__ __forceinline__ void stage_phase(float (&acc)[NACC<KIND>], float* row
       ...);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// pieces shared by the fp32-MFMA kernel (PREC 0) and the split-bf16 kernels (PREC 2 / 3)
+// ---------------------------------------------------------------------------------------------------------------
+struct WgRange {
+  int pose, sc0, n_lo, n_hi, n_loc, l0, p0, NL, NP, x0, k_begin, k_end;
+};
+
+__device__ __forceinline__ WgRange wg_range(const DpConvArgs& a) {
+  WgRange r;
+  r.pose = blockIdx.x / a.slices;
+  const int slice = blockIdx.x % a.slices;
+  r.sc0 = a.scat_ptr[r.pose];
+  const int nsc = a.scat_ptr[r.pose + 1] - r.sc0;
+  r.n_lo = r.sc0 + (int)(((long long)nsc * slice) / a.slices);
+  r.n_hi = r.sc0 + (int)(((long long)nsc * (slice + 1)) / a.slices);
+  r.n_loc = r.n_hi - r.n_lo;
+  r.l0 = r.p0 = r.NL = r.NP = r.x0 = 0;
+  r.k_begin = r.k_end = 0;
+  if (r.n_loc <= 0) return r;
+  if (a.mode != DP_EDGES_CSR) {
+    r.l0 = a.lig_ptr[r.pose];
+    r.NL = a.lig_ptr[r.pose + 1] - r.l0;
+    if (a.mode != DP_EDGES_CENTER) {
+      r.p0 = a.ph_ptr[r.pose];
+      r.NP = a.ph_ptr[r.pose + 1] - r.p0;
+      r.x0 = a.x_ptr[r.pose];
+    }
+  }
+  if (a.mode == DP_EDGES_CSR) {
+    r.k_begin = a.rowptr[r.n_lo];
+    r.k_end = a.rowend[r.n_hi - 1];
+  } else if (a.mode == DP_EDGES_P2L) {
+    r.k_begin = (r.n_lo - r.sc0) * r.NP;
+    r.k_end = (r.n_hi - r.sc0) * r.NP;
+  } else if (a.mode == DP_EDGES_L2P) {
+    r.k_begin = (r.n_lo - r.sc0) * r.NL;
+    r.k_end = (r.n_hi - r.sc0) * r.NL;
+  } else {
+    r.k_begin = 0;
+    r.k_end = r.NL;
+  }
+  return r;
+}
+
+// sorted edge slot -> (scatter, gather, attr rows, feature row)
+__device__ __forceinline__ EdgeRef decode_edge(const DpConvArgs& a, const WgRange& r, int k) {
+  const bool valid = k < r.k_end;
+  EdgeRef e;
+  if (a.mode == DP_EDGES_CSR) {
+    const int kk = valid ? k : r.k_begin;
+    e.feat = kk;
+    e.gather = a.nbr[kk];
+    const int sabs = a.edge_scat[kk];
+    const bool in_rng = sabs >= r.n_lo && sabs < r.n_hi;
+    e.scat_local = (valid && in_rng) ? sabs - r.n_lo : -1;
+    const int sg = in_rng ? sabs : r.n_lo;
+    e.a1 = a.attr_swap ? e.gather : sg;
+    e.a2 = a.attr_swap ? sg : e.gather;
+  } else if (a.mode == DP_EDGES_P2L) {
+    const int kk = valid ? k : r.k_begin;
+    const int i = kk / r.NP, j = kk - i * r.NP;
+    e.feat = r.x0 + kk;
+    e.gather = r.p0 + j;
+    e.a1 = r.l0 + i;
+    e.a2 = r.p0 + j;
+    e.scat_local = valid ? (i - (r.n_lo - r.sc0)) : -1;
+  } else if (a.mode == DP_EDGES_L2P) {
+    const int kk = valid ? k : r.k_begin;
+    const int j = kk / r.NL, i = kk - j * r.NL;
+    e.feat = r.x0 + i * r.NP + j;
+    e.gather = r.l0 + i;
+    e.a1 = r.l0 + i;
+    e.a2 = r.p0 + j;
+    e.scat_local = valid ? (j - (r.n_lo - r.sc0)) : -1;
+  } else {
+    const int kk = valid ? k : 0;
+    e.feat = r.l0 + kk;
+    e.gather = r.l0 + kk;
+    e.a1 = r.l0 + kk;
+    e.a2 = 0;
+    e.scat_local = valid ? 0 : -1;
+  }
+  return e;
+}
+
+// gathered TP input (this lane half's in-channels), spherical harmonics, l=2 contraction matrix
+template <int KIND>
+__device__ __forceinline__ void load_tp_operands(const DpConvArgs& a, const EdgeRef& e, int half, float (&xr)[Spec<KIND>::D_IN / 2],
+                                                 float (&sh)[Spec<KIND>::SH_DIM], float (&M)[9]) {
+  using S = Spec<KIND>;
+  const float* px = a.gather_tab + (size_t)e.gather * a.gather_stride;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) xr[i] = px[half * 10 + i];                                   // 20x0e
+  if constexpr (S::D_IN >= 50) {
+#pragma unroll
+    for (int i = 0; i < 15; ++i) xr[10 + i] = px[20 + half * 15 + i];                       // 10x1o
+  }
+  if constexpr (S::D_IN >= 80) {
+#pragma unroll
+    for (int i = 0; i < 15; ++i) xr[25 + i] = px[50 + half * 15 + i];                       // 10x1e
+  }
+  if constexpr (S::D_IN >= 100) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) xr[40 + i] = px[80 + half * 10 + i];                       // 20x0o
+  }
+  const float* ps = a.edge_sh + (size_t)e.feat * a.sh_stride;
+#pragma unroll
+  for (int i = 0; i < S::SH_DIM; ++i) sh[i] = ps[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) M[i] = 0.f;
+  if constexpr (S::SH_DIM == 9) {              // sqrt(10) * sum_j sh2[j] C(1,2,1)[i,j,k]  (1/sqrt10 folded into W2p)
+    const float c = 0.57735026918962576451f * sh[6];
+    M[0] = -c - sh[8]; M[4] = 2.f * c; M[8] = -c + sh[8];
+    M[1] = M[3] = sh[5]; M[2] = M[6] = sh[4]; M[5] = M[7] = sh[7];
+  }
+}
+
+// GEMM1 (fp32 MFMA): hidden = relu(W1 [edge_emb | attr1[:20] | attr2[:20]] + b1); result = this lane's 32 D registers
+template <int KIND>
+__device__ __forceinline__ void gemm1_hidden(const DpConvArgs& a, const EdgeRef& e, int lane, float (&hid)[32]) {
+  using S = Spec<KIND>;
+  using G = Geo<KIND>;
+  const int half = lane >> 5;
+  float av[G::ABLK * 10];                      // this half's 10 floats of every 20-float attr block
+  {
+    const float* pe = a.edge_emb + (size_t)e.feat * 20 + half * 10;
+#pragma unroll
+    for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(pe + i); av[i] = v.x; av[i + 1] = v.y; }
+    const float* p1 = a.attr1_tab + (size_t)e.a1 * a.attr1_stride + half * 10;
+#pragma unroll
+    for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(p1 + i); av[10 + i] = v.x; av[11 + i] = v.y; }
+    if constexpr (G::ABLK == 3) {
+      const float* p2 = a.attr2_tab + (size_t)e.a2 * a.attr2_stride + half * 10;
+#pragma unroll
+      for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(p2 + i); av[20 + i] = v.x; av[21 + i] = v.y; }
+    }
+  }
+  gptr4 w1p_lane = (gptr4)a.w1p + lane;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f32x16 H = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G::K1P / 4; ++g) {
+      const vf4 w = w1p_lane[(t * (G::K1P / 4) + g) * 64];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int s = 4 * g + c;
+        float b;
+        if (s < S::N_ATTR / 2) b = av[s];
+        else if (s == S::N_ATTR / 2) b = half ? 0.f : 1.f;
+        else b = 0.f;
+        const float wa = c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w;
+        if (s < G::K1) H = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, b, H, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[t * 16 + r] = fmaxf(H[r], 0.f);
+  }
+}
+
+// ordered (deterministic) segmented sum of the chunk's staged messages into the LDS node accumulators
+template <int KIND, int CH>
+__device__ __forceinline__ void segmented_sum(const float* s_msg, const int* s_node, float* s_acc, int nedge) {
+  using S = Spec<KIND>;
+  using G = Geo<KIND>;
+  const int tid = threadIdx.x;
+  if (tid < S::D_OUT) {
+    float run = 0.f;
+    int cur = -1;
+    for (int ei = 0; ei < nedge; ++ei) {
+      const int n = s_node[ei];
+      if (n != cur) {
+        if (cur >= 0) s_acc[cur * S::D_OUT + tid] += run;
+        run = 0.f;
+        cur = n;
+      }
+      if (n >= 0) run += s_msg[ei * G::MSG_LD + tid];
+    }
+    if (cur >= 0) s_acc[cur * S::D_OUT + tid] += run;
+  }
+}
+
+// mean, BatchNorm affine, residual stream
+template <int KIND, int NTHREADS>
+__device__ __forceinline__ void conv_epilogue(const DpConvArgs& a, const WgRange& r, const float* s_acc) {
+  using S = Spec<KIND>;
+  for (int i = threadIdx.x; i < r.n_loc * S::D_OUT; i += NTHREADS) {
+    const int n = i / S::D_OUT, c = i - n * S::D_OUT;
+    const int node = r.n_lo + n;
+    int deg;
+    if (a.mode == DP_EDGES_CSR) deg = a.rowend[node] - a.rowptr[node];
+    else if (a.mode == DP_EDGES_P2L) deg = r.NP;
+    else deg = r.NL;
+    float v = s_acc[i] / (float)max(deg, 1);
+    v = v * a.bn_scale[c] + a.bn_shift[c];
+    float* o = a.out + (size_t)node * a.out_stride + c;
+    if (a.accumulate) {
+      *o += v;
+    } else {
+      if (a.resid != nullptr && c < a.resid_width) v += a.resid[(size_t)node * a.resid_stride + c];
+      *o = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PREC 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 4 waves / workgroup, W2p streamed from L2 per lane
+// ---------------------------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
   using S = Spec<KIND>;
@@ -236,152 +444,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
   __shared__ int s_node[CHUNK];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
-  const int pose = blockIdx.x / a.slices, slice = blockIdx.x % a.slices;
+  const WgRange r = wg_range(a);
+  if (r.n_loc <= 0) return;
+  for (int i = tid; i < r.n_loc * S::D_OUT; i += WAVES * 64) s_acc[i] = 0.f;
 
-  // ---- this workgroup's scatter-node range and sorted edge-slot range ----------------------------------------------
-  const int sc0 = a.scat_ptr[pose], sc1 = a.scat_ptr[pose + 1];
-  const int nsc = sc1 - sc0;
-  const int n_lo = sc0 + (int)(((long long)nsc * slice) / a.slices);
-  const int n_hi = sc0 + (int)(((long long)nsc * (slice + 1)) / a.slices);
-  const int n_loc = n_hi - n_lo;
-  if (n_loc <= 0) return;
-  int l0 = 0, p0 = 0, NL = 0, NP = 0, x0 = 0;
-  if (a.mode != DP_EDGES_CSR) {
-    l0 = a.lig_ptr[pose];
-    NL = a.lig_ptr[pose + 1] - l0;
-    if (a.mode != DP_EDGES_CENTER) {
-      p0 = a.ph_ptr[pose];
-      NP = a.ph_ptr[pose + 1] - p0;
-      x0 = a.x_ptr[pose];
-    }
-  }
-  int k_begin, k_end;   // sorted edge slots, local numbering depends on the mode
-  if (a.mode == DP_EDGES_CSR) {
-    k_begin = a.rowptr[n_lo];
-    k_end = a.rowend[n_hi - 1];
-  } else if (a.mode == DP_EDGES_P2L) {
-    k_begin = (n_lo - sc0) * NP;
-    k_end = (n_hi - sc0) * NP;
-  } else if (a.mode == DP_EDGES_L2P) {
-    k_begin = (n_lo - sc0) * NL;
-    k_end = (n_hi - sc0) * NL;
-  } else {
-    k_begin = 0;
-    k_end = NL;
-  }
-
-  for (int i = tid; i < n_loc * S::D_OUT; i += WAVES * 64) s_acc[i] = 0.f;
-
-  gptr4 w1p_lane = (gptr4)a.w1p + lane;
-
-  for (int kc = k_begin; kc < k_end; kc += CHUNK) {
-    const int k = kc + wave * 32 + ecol;
-    const bool valid = k < k_end;
-    EdgeRef e;
-    // ---- edge slot -> (scatter, gather, attr rows, feature row) -----------------------------------------------------
-    if (a.mode == DP_EDGES_CSR) {
-      const int kk = valid ? k : k_begin;
-      e.feat = kk;
-      e.gather = a.nbr[kk];
-      const int sabs = a.edge_scat[kk];
-      const bool in_rng = sabs >= n_lo && sabs < n_hi;
-      e.scat_local = (valid && in_rng) ? sabs - n_lo : -1;
-      const int sg = in_rng ? sabs : n_lo;
-      e.a1 = a.attr_swap ? e.gather : sg;
-      e.a2 = a.attr_swap ? sg : e.gather;
-    } else if (a.mode == DP_EDGES_P2L) {
-      const int kk = valid ? k : k_begin;
-      const int i = kk / NP, j = kk - i * NP;
-      e.feat = x0 + kk;
-      e.gather = p0 + j;
-      e.a1 = l0 + i;
-      e.a2 = p0 + j;
-      e.scat_local = valid ? (i - (n_lo - sc0)) : -1;
-    } else if (a.mode == DP_EDGES_L2P) {
-      const int kk = valid ? k : k_begin;
-      const int j = kk / NL, i = kk - j * NL;
-      e.feat = x0 + i * NP + j;
-      e.gather = l0 + i;
-      e.a1 = l0 + i;
-      e.a2 = p0 + j;
-      e.scat_local = valid ? (j - (n_lo - sc0)) : -1;
-    } else {
-      const int kk = valid ? k : 0;
-      e.feat = l0 + kk;
-      e.gather = l0 + kk;
-      e.a1 = l0 + kk;
-      e.a2 = 0;
-      e.scat_local = valid ? 0 : -1;
-    }
-
-    // ---- per-edge operands -------------------------------------------------------------------------------------------
-    float av[G::ABLK * 10];                      // this half's 10 floats of every 20-float attr block
-    {
-      const float* pe = a.edge_emb + (size_t)e.feat * 20 + half * 10;
-#pragma unroll
-      for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(pe + i); av[i] = v.x; av[i + 1] = v.y; }
-      const float* p1 = a.attr1_tab + (size_t)e.a1 * a.attr1_stride + half * 10;
-#pragma unroll
-      for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(p1 + i); av[10 + i] = v.x; av[11 + i] = v.y; }
-      if constexpr (G::ABLK == 3) {
-        const float* p2 = a.attr2_tab + (size_t)e.a2 * a.attr2_stride + half * 10;
-#pragma unroll
-        for (int i = 0; i < 10; i += 2) { const float2 v = *reinterpret_cast<const float2*>(p2 + i); av[20 + i] = v.x; av[21 + i] = v.y; }
-      }
-    }
-    float xr[S::D_IN / 2];                       // this half's in-channels: u = half*mul/2 + q for every in-slot
-    {
-      const float* px = a.gather_tab + (size_t)e.gather * a.gather_stride;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) xr[i] = px[half * 10 + i];                                   // 20x0e
-      if constexpr (S::D_IN >= 50) {
-#pragma unroll
-        for (int i = 0; i < 15; ++i) xr[10 + i] = px[20 + half * 15 + i];                       // 10x1o
-      }
-      if constexpr (S::D_IN >= 80) {
-#pragma unroll
-        for (int i = 0; i < 15; ++i) xr[25 + i] = px[50 + half * 15 + i];                       // 10x1e
-      }
-      if constexpr (S::D_IN >= 100) {
-#pragma unroll
-        for (int i = 0; i < 10; ++i) xr[40 + i] = px[80 + half * 10 + i];                       // 20x0o
-      }
-    }
-    float sh[S::SH_DIM];
-    {
-      const float* ps = a.edge_sh + (size_t)e.feat * a.sh_stride;
-#pragma unroll
-      for (int i = 0; i < S::SH_DIM; ++i) sh[i] = ps[i];
-    }
-    float M[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (S::SH_DIM == 9) {              // sqrt(10) * sum_j sh2[j] C(1,2,1)[i,j,k]  (1/sqrt10 folded into W2p)
-      const float c = 0.57735026918962576451f * sh[6];
-      M[0] = -c - sh[8]; M[4] = 2.f * c; M[8] = -c + sh[8];
-      M[1] = M[3] = sh[5]; M[2] = M[6] = sh[4]; M[5] = M[7] = sh[7];
-    }
-
-    // ---- GEMM1: hidden = relu(W1 attr + b1) --------------------------------------------------------------------------
-    float hid[32];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x16 H = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < G::K1P / 4; ++g) {
-        const vf4 w = w1p_lane[(t * (G::K1P / 4) + g) * 64];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int s = 4 * g + c;
-          float b;
-          if (s < S::N_ATTR / 2) b = av[s];
-          else if (s == S::N_ATTR / 2) b = half ? 0.f : 1.f;
-          else b = 0.f;
-          const float wa = c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w;
-          if (s < G::K1) H = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, b, H, 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hid[t * 16 + r] = fmaxf(H[r], 0.f);
-    }
+  for (int kc = r.k_begin; kc < r.k_end; kc += CHUNK) {
+    const EdgeRef e = decode_edge(a, r, kc + wave * 32 + ecol);
+    float xr[S::D_IN / 2], sh[S::SH_DIM], M[9], hid[32];
+    load_tp_operands<KIND>(a, e, half, xr, sh, M);
+    gemm1_hidden<KIND>(a, e, lane, hid);
 
     // ---- GEMM2 tiles + CG contraction, phase 0 (scalar outputs) then phase 1 (vector outputs) ----------------------
     __syncthreads();                              // previous chunk's segmented sum has finished reading s_msg
@@ -415,49 +486,218 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
       if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
     }
     __syncthreads();
-    // ---- ordered segmented sum over the chunk (deterministic: edge order) ------------------------------------------
-    if (tid < S::D_OUT) {
-      float run = 0.f;
-      int cur = -1;
-      const int nedge = min(CHUNK, k_end - kc);
-      for (int ei = 0; ei < nedge; ++ei) {
-        const int n = s_node[ei];
-        if (n != cur) {
-          if (cur >= 0) s_acc[cur * S::D_OUT + tid] += run;
-          run = 0.f;
-          cur = n;
-        }
-        if (n >= 0) run += s_msg[ei * G::MSG_LD + tid];
-      }
-      if (cur >= 0) s_acc[cur * S::D_OUT + tid] += run;
-    }
+    segmented_sum<KIND, CHUNK>(s_msg, s_node, s_acc, min(CHUNK, r.k_end - kc));
   }
   __syncthreads();
+  conv_epilogue<KIND, WAVES * 64>(a, r, s_acc);
+}
 
-  // ---- epilogue: mean, BatchNorm affine, residual stream --------------------------------------------------------------
-  for (int i = tid; i < n_loc * S::D_OUT; i += WAVES * 64) {
-    const int n = i / S::D_OUT, c = i - n * S::D_OUT;
-    const int node = n_lo + n;
-    int deg;
-    if (a.mode == DP_EDGES_CSR) deg = a.rowend[node] - a.rowptr[node];
-    else if (a.mode == DP_EDGES_P2L) deg = NP;
-    else deg = NL;
-    float v = s_acc[i] / (float)max(deg, 1);
-    v = v * a.bn_scale[c] + a.bn_shift[c];
-    float* o = a.out + (size_t)node * a.out_stride + c;
-    if (a.accumulate) {
-      *o += v;
-    } else {
-      if (a.resid != nullptr && c < a.resid_width) v += a.resid[(size_t)node * a.resid_stride + c];
-      *o = v;
+// ---------------------------------------------------------------------------------------------------------------
+// PREC 2 / 3: radial-MLP layer 2 on the bf16 matrix pipe with operand splitting (Ozaki-style error-free transformation)
+//   x = x_hi + x_mid (+ x_lo), each part a bf16;  w.h ~= sum of the NS*(NS+1)/2 largest cross products, fp32 accumulate.
+//   NS = 3 (6 products): relative error ~2^-24, i.e. fp32-grade;  NS = 2 (3 products): ~2^-17.
+//   v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate, so a tile costs 24 (or 12) x 32 cycles instead of 32 x 64.
+//   At that rate per-lane weight streaming from L2 would saturate the CU's L1/L2 path, so the 8 waves of a workgroup share
+//   each packed weight tile through a double-buffered LDS stage (register-staged, written after the MFMA phase).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
+constexpr int WAVES_B = 8;
+constexpr int CHUNK_B = WAVES_B * 32;
+
+template <int KIND> constexpr int NKB = (Spec<KIND>::HID + 1 + 15) / 16;            // 16-wide K blocks incl. the bias row
+template <int KIND, int NS> constexpr int TILE_QUADS = NKB<KIND> * NS * 64;         // uint4 per packed tile
+// hidden row held by lane half `half` at position j (0..7) of K block b: the D-fragment row of GEMM1 register 8*(b&1)+j, tile b>>1
+constexpr int hid_row_b(int b, int half, int j) {
+  const int r = 8 * (b & 1) + j;
+  return 32 * (b >> 1) + (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+
+__host__ __device__ inline unsigned short f32_to_bf16_rne(float x) {
+  unsigned int u = __builtin_bit_cast(unsigned int, x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned int)h << 16); }
+
+template <int KIND, int NS> void pack_w2_bf16(const float* fc3_w, const float* fc3_b, unsigned short* out) {
+  using G = Geo<KIND>;
+  using S = Spec<KIND>;
+  const size_t total = (size_t)G::NT * TILE_QUADS<KIND, NS> * 8;
+  for (size_t i = 0; i < total; ++i) out[i] = 0;
+  for (int tile = 0; tile < G::NT; ++tile)
+    for (int b = 0; b < NKB<KIND>; ++b)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int c = lane & 31, half = lane >> 5;
+        const int r = (c & 3) + 4 * (c >> 3), chalf = (c >> 2) & 1;
+        const Triple tr = triple_at<KIND>(tile * 16 + r);
+        if (!tr.valid) continue;
+        const PathC& p = S::P[tr.p];
+        const int u = chalf * (p.mul_in / 2) + tr.q;
+        const int widx = p.w_off + u * p.mul_out + tr.w;
+        const double scale = __builtin_sqrt((double)(2 * (d_out_of(p.ztype) == 3 ? 1 : 0) + 1) / (double)p.fan_in) * cg_const(p.ztype);
+        for (int j = 0; j < 8; ++j) {
+          const int hrow = hid_row_b(b, half, j);
+          float v = 0.f;
+          if (hrow < S::HID) v = (float)(scale * (double)fc3_w[widx * S::HID + hrow]);
+          else if (hrow == S::HID) v = (float)(scale * (double)fc3_b[widx]);
+          float rem = v;
+          for (int s = 0; s < NS; ++s) {
+            const unsigned short h = f32_to_bf16_rne(rem);
+            rem -= bf16_to_f32(h);
+            out[((((size_t)tile * NKB<KIND> + b) * NS + s) * 64 + lane) * 8 + j] = h;
+          }
+        }
+      }
+}
+
+template <int KIND, int NS> struct HidB { bf16x8 v[NKB<KIND>][NS]; };
+
+template <int KIND, int NS>
+__device__ __forceinline__ void split_hidden(const float (&hid)[32], HidB<KIND, NS>& hb) {
+#pragma unroll
+  for (int b = 0; b < NKB<KIND>; ++b) {
+    unsigned short q[NS][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float rem = hid[8 * b + j];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const unsigned short h = f32_to_bf16_rne(rem);
+        rem -= bf16_to_f32(h);
+        q[s][j] = h;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      vu4 pk;
+      pk.x = q[s][0] | ((unsigned)q[s][1] << 16);
+      pk.y = q[s][2] | ((unsigned)q[s][3] << 16);
+      pk.z = q[s][4] | ((unsigned)q[s][5] << 16);
+      pk.w = q[s][6] | ((unsigned)q[s][7] << 16);
+      hb.v[b][s] = __builtin_bit_cast(bf16x8, pk);
     }
   }
 }
 
+typedef const __attribute__((address_space(1))) vu4* gptrq;
+
+template <int KIND, int NS, int TILE>
+struct StageB {
+  static __device__ __forceinline__ void run(gptrq wp, int tid, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
+                                             const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
+                                             const float (&M)[9], float (&acc)[NACC<KIND>], float* row, int half) {
+    using G = Geo<KIND>;
+    constexpr int NT0 = n_tiles_phase<KIND>(0);
+    constexpr int NQ = TILE_QUADS<KIND, NS>;
+    constexpr int NPRE = (NQ + WAVES_B * 64 - 1) / (WAVES_B * 64);
+    if constexpr (TILE < G::NT) {
+      if constexpr (TILE == NT0 && NT0 > 0) {      // phase boundary: scalar outputs done
+        stage_phase<KIND, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0)>{});
+#pragma unroll
+        for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
+      }
+      // issue the global loads of the NEXT tile now; they land while this tile's MFMAs run (written to LDS below)
+      vu4 pre[NPRE];
+      wp += NQ;
+      asm volatile("" : "+s"(wp));
+      if constexpr (TILE + 1 < G::NT) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q)
+          if (tid + q * WAVES_B * 64 < NQ) pre[q] = wp[tid + q * WAVES_B * 64];
+      }
+      const vu4* buf = s_w + (TILE & 1) * NQ;
+      f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < NKB<KIND>; ++b) {
+        bf16x8 W[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) W[s] = __builtin_bit_cast(bf16x8, buf[(b * NS + s) * 64 + lane]);
+        // smallest cross terms first
+        if constexpr (NS == 3) {
+          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[b][1], D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[b][0], D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][2], D, 0, 0, 0);
+        }
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[b][0], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][1], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][0], D, 0, 0, 0);
+      }
+      contract_tile<KIND, TILE>(D, xr, sh, M, acc, std::make_integer_sequence<int, 16>{});
+      if constexpr (TILE + 1 < G::NT) {
+        vu4* nbuf = s_w + ((TILE + 1) & 1) * NQ;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q)
+          if (tid + q * WAVES_B * 64 < NQ) nbuf[tid + q * WAVES_B * 64] = pre[q];
+      }
+      __syncthreads();          // next tile's weights visible; everyone is done reading this tile's buffer
+      __builtin_amdgcn_sched_barrier(0);
+      StageB<KIND, NS, TILE + 1>::run(wp, tid, lane, s_w, hb, xr, sh, M, acc, row, half);
+    } else {
+      if constexpr (n_tiles_phase<KIND>(1) > 0)
+        stage_phase<KIND, 1>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(1)>{});
+      else
+        stage_phase<KIND, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0)>{});
+    }
+  }
+};
+
+template <int KIND, int NS>
+__global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArgs a) {
+  using S = Spec<KIND>;
+  using G = Geo<KIND>;
+  constexpr int NQ = TILE_QUADS<KIND, NS>;
+  __shared__ float s_msg[CHUNK_B * G::MSG_LD];
+  __shared__ float s_acc[MAX_NODES * S::D_OUT];
+  __shared__ int s_node[CHUNK_B];
+  __shared__ vu4 s_w[2 * NQ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
+  const WgRange r = wg_range(a);
+  if (r.n_loc <= 0) return;
+  for (int i = tid; i < r.n_loc * S::D_OUT; i += WAVES_B * 64) s_acc[i] = 0.f;
+
+  for (int kc = r.k_begin; kc < r.k_end; kc += CHUNK_B) {
+    const EdgeRef e = decode_edge(a, r, kc + wave * 32 + ecol);
+    float xr[S::D_IN / 2], sh[S::SH_DIM], M[9];
+    HidB<KIND, NS> hb;
+    {
+      float hid[32];
+      gemm1_hidden<KIND>(a, e, lane, hid);
+      split_hidden<KIND, NS>(hid, hb);
+    }
+    load_tp_operands<KIND>(a, e, half, xr, sh, M);
+    __syncthreads();                              // previous chunk: segmented sum done with s_msg, s_w free
+    gptrq wp = (gptrq)a.w2p;
+    for (int q = tid; q < NQ; q += WAVES_B * 64) s_w[q] = wp[q];      // tile 0
+    float* row = s_msg + (size_t)(wave * 32 + ecol) * G::MSG_LD;
+    float acc[NACC<KIND>];
+#pragma unroll
+    for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
+    __syncthreads();
+    StageB<KIND, NS, 0>::run(wp, tid, lane, s_w, hb, xr, sh, M, acc, row, half);
+    if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
+    __syncthreads();
+    segmented_sum<KIND, CHUNK_B>(s_msg, s_node, s_acc, min(CHUNK_B, r.k_end - kc));
+  }
+  __syncthreads();
+  conv_epilogue<KIND, WAVES_B * 64>(a, r, s_acc);
+}
+
 template <int KIND> int launch(const DpConvArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)(a.B * a.slices)), block(WAVES * 64);
-  hipLaunchKernelGGL(tp_conv_kernel<KIND>, grid, block, 0, st, a);
+  dim3 grid((unsigned)(a.B * a.slices));
+  if (a.precision == DP_PREC_F32) hipLaunchKernelGGL(tp_conv_kernel<KIND>, grid, dim3(WAVES * 64), 0, st, a);
+  else if (a.precision == DP_PREC_BF16X6) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 3>), grid, dim3(WAVES_B * 64), 0, st, a);
+  else if (a.precision == DP_PREC_BF16X3) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2>), grid, dim3(WAVES_B * 64), 0, st, a);
+  else return DP_E_BADARG;
   return (int)hipGetLastError();
+}
+
+template <int KIND> int w2p_floats(int prec) {
+  if (prec == DP_PREC_F32) return Geo<KIND>::W2P_FLOATS;
+  if (prec == DP_PREC_BF16X6) return Geo<KIND>::NT * TILE_QUADS<KIND, 3> * 4;
+  if (prec == DP_PREC_BF16X3) return Geo<KIND>::NT * TILE_QUADS<KIND, 2> * 4;
+  return DP_E_BADARG;
 }
 
 }  // namespace dp
@@ -489,21 +729,28 @@ int dp_conv_w1p_floats(int32_t kind) {
     default: return DP_E_BADARG;
   }
 }
-int dp_conv_w2p_floats(int32_t kind) {
+int dp_conv_w2p_floats(int32_t kind, int32_t precision) {
   switch (kind) {
-    case 0: return dp::Geo<0>::W2P_FLOATS; case 1: return dp::Geo<1>::W2P_FLOATS; case 2: return dp::Geo<2>::W2P_FLOATS;
-    case 3: return dp::Geo<3>::W2P_FLOATS; case 4: return dp::Geo<4>::W2P_FLOATS; case 5: return dp::Geo<5>::W2P_FLOATS;
+    case 0: return dp::w2p_floats<0>(precision); case 1: return dp::w2p_floats<1>(precision); case 2: return dp::w2p_floats<2>(precision);
+    case 3: return dp::w2p_floats<3>(precision); case 4: return dp::w2p_floats<4>(precision); case 5: return dp::w2p_floats<5>(precision);
     default: return DP_E_BADARG;
   }
 }
 
 // HOST pointers in, HOST pointers out: re-orders one TensorProductConvLayer's `fc` parameters (reference layout:
 // fc.0.weight [HID, N_ATTR], fc.0.bias [HID], fc.3.weight [numel, HID], fc.3.bias [numel]) into MFMA operand order.
-int dp_pack_conv_weights(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
-                         float* w1p, float* w2p) {
+int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, const float* fc0_b, const float* fc3_w,
+                         const float* fc3_b, float* w1p, float* w2p) {
   if (!fc0_w || !fc0_b || !fc3_w || !fc3_b || !w1p || !w2p) return DP_E_BADARG;
+  if (precision != DP_PREC_F32 && precision != DP_PREC_BF16X6 && precision != DP_PREC_BF16X3) return DP_E_BADARG;
   switch (kind) {
-#define DP_CASE(K) case K: dp::pack_w1<K>(fc0_w, fc0_b, w1p); dp::pack_w2<K>(fc3_w, fc3_b, w2p); return DP_OK;
+#define DP_CASE(K)                                                                                            \
+  case K:                                                                                                     \
+    dp::pack_w1<K>(fc0_w, fc0_b, w1p);                                                                        \
+    if (precision == DP_PREC_F32) dp::pack_w2<K>(fc3_w, fc3_b, w2p);                                          \
+    else if (precision == DP_PREC_BF16X6) dp::pack_w2_bf16<K, 3>(fc3_w, fc3_b, (unsigned short*)w2p);         \
+    else dp::pack_w2_bf16<K, 2>(fc3_w, fc3_b, (unsigned short*)w2p);                                          \
+    return DP_OK;
     DP_CASE(0) DP_CASE(1) DP_CASE(2) DP_CASE(3) DP_CASE(4) DP_CASE(5)
 #undef DP_CASE
     default: return DP_E_BADARG;

@@ -603,7 +603,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     DpConvArgs a;
     // ligand side: lig_conv (+ residual stream), phore_to_lig, phore_to_lig_norm      (:678-689, :703-706)
     memset(&a, 0, sizeof(a));
-    a.kind = l; a.B = B; a.slices = slices; a.lig_ptr = b->lig_ptr; a.ph_ptr = b->ph_ptr; a.x_ptr = b->x_ptr;
+    a.kind = l; a.B = B; a.slices = slices; a.precision = w->precision; a.lig_ptr = b->lig_ptr; a.ph_ptr = b->ph_ptr; a.x_ptr = b->x_ptr;
     a.sh_stride = 9; a.out_stride = 100; a.resid_stride = 100;
     a.gather_stride = a.attr1_stride = a.attr2_stride = 100;
     {
@@ -650,7 +650,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   {
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
-    c.kind = DP_CONV_FINAL; c.mode = DP_EDGES_CENTER; c.B = B; c.slices = 1; c.scat_ptr = b->pose_ptr; c.lig_ptr = b->lig_ptr;
+    c.kind = DP_CONV_FINAL; c.mode = DP_EDGES_CENTER; c.B = B; c.slices = 1; c.precision = w->precision; c.scat_ptr = b->pose_ptr; c.lig_ptr = b->lig_ptr;
     c.gather_tab = hl; c.gather_stride = 100; c.attr1_tab = hl; c.attr1_stride = 100;
     c.edge_emb = k->c_emb; c.edge_sh = k->c_sh; c.sh_stride = 9;
     c.w1p = w->final_conv.w1p; c.w2p = w->final_conv.w2p; c.bn_scale = w->final_conv.bn_scale; c.bn_shift = w->final_conv.bn_shift;
@@ -663,7 +663,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k, hl);
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
-    c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr;
+    c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr; c.precision = w->precision;
     c.slices = 1;
     while ((b->max_t + c.slices - 1) / c.slices > 64) ++c.slices;
     c.rowptr = k->t_rowptr; c.rowend = k->t_rowend; c.nbr = k->t_nbr; c.edge_scat = k->t_src;

@@ -31,7 +31,7 @@ def bn_affine(sd: Dict[str, torch.Tensor], prefix: str, irreps, eps: float = 1e-
     return torch.cat(scale).float().contiguous(), torch.cat(shift).float().contiguous()
 
 
-def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int) -> Dict[str, torch.Tensor]:
+def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: int = 0) -> Dict[str, torch.Tensor]:
     """fc.0 / fc.3 / batch_norm of one TensorProductConvLayer -> MFMA operand order (host tensors)."""
     L = _lib.lib()
     dims = _lib.conv_dims(kind)
@@ -42,8 +42,8 @@ def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int) -> Dict[str, 
     assert tuple(fc0_w.shape) == (dims["hidden"], dims["n_attr"]), (prefix, fc0_w.shape, dims)
     assert tuple(fc3_w.shape) == (dims["numel"], dims["hidden"]), (prefix, fc3_w.shape, dims)
     w1p = torch.empty(L.dp_conv_w1p_floats(kind), dtype=torch.float32)
-    w2p = torch.empty(L.dp_conv_w2p_floats(kind), dtype=torch.float32)
-    _lib.check(L.dp_pack_conv_weights(kind, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
+    w2p = torch.empty(L.dp_conv_w2p_floats(kind, precision), dtype=torch.float32)
+    _lib.check(L.dp_pack_conv_weights(kind, precision, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
                                       w1p.data_ptr(), w2p.data_ptr()), "dp_pack_conv_weights")
     scale, shift = bn_affine(sd, prefix + ".batch_norm", _OUT_IRREPS[kind])
     return dict(w1p=w1p, w2p=w2p, bn_scale=scale, bn_shift=shift)

@@ -50,11 +50,19 @@ enum DpEdgeMode {
   DP_EDGES_CENTER = 3   /* scatter = pose, one edge per ligand atom                         (:381-406) */
 };
 
+/* arithmetic of the radial-MLP second layer (the 60 x numel contraction that dominates the path) */
+enum DpPrecision {
+  DP_PREC_F32 = 0,      /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+  DP_PREC_BF16X6 = 3,   /* 3-way bf16 operand split, 6 cross products, fp32 accumulate: ~2^-24 relative, fp32-grade */
+  DP_PREC_BF16X3 = 2    /* 2-way bf16 split, 3 cross products: ~2^-17 relative */
+};
+
 typedef struct DpConvArgs {
   int32_t kind;          /* DpConvKind */
   int32_t mode;          /* DpEdgeMode */
   int32_t B;             /* poses */
   int32_t slices;        /* workgroups per pose (>=1); scatter nodes of a pose are split evenly between them */
+  int32_t precision;     /* DpPrecision; must match the precision w2p was packed for */
   /* pose CSRs (B+1 entries each) */
   const int32_t* scat_ptr;   /* scatter-node offsets per pose (ligand atoms / phore nodes / rotatable bonds / poses) */
   const int32_t* lig_ptr;    /* ligand atom offsets per pose */
@@ -98,11 +106,11 @@ int dp_tp_conv(const DpConvArgs* args, void* stream);
 
 /* numbers the host packer needs */
 int dp_conv_w1p_floats(int32_t kind);
-int dp_conv_w2p_floats(int32_t kind);
+int dp_conv_w2p_floats(int32_t kind, int32_t precision);
 int dp_conv_dims(int32_t kind, int32_t* d_in, int32_t* d_out, int32_t* numel, int32_t* n_attr, int32_t* hidden);
 /* HOST pointers: reorder one TensorProductConvLayer's fc parameters (reference state_dict layout) into MFMA operand order */
-int dp_pack_conv_weights(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
-                         float* w1p, float* w2p);
+int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, const float* fc0_b, const float* fc3_w,
+                         const float* fc3_b, float* w1p, float* w2p);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Packed batch of B poses (struct of arrays, CSR offsets per pose).  One "pose" = one (ligand conformer, pharmacophore)
@@ -162,6 +170,7 @@ typedef struct DpWeights {
   float scaler;                /* 100.0 */
   float tr_smin, tr_smax, rot_smin, rot_smax, tor_smin, tor_smax;
   float emb_scale;             /* 10000 */
+  int32_t precision;           /* DpPrecision the conv weights were packed for */
 } DpWeights;
 
 /* Caller-owned scratch; sizes in floats/ints are given by dp_work_sizes(). */

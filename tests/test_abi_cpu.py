@@ -38,7 +38,7 @@ def test_bad_arguments_are_rejected_not_crashed():
     assert L.dp_tp_conv(C.byref(a), None) == -1
     engine._declare()
     assert L.dp_forward(None, None, None, None, None, None, None) == -1
-    assert L.dp_pack_conv_weights(99, None, None, None, None, None, None) == -1
+    assert L.dp_pack_conv_weights(99, 0, None, None, None, None, None, None) == -1
 
 
 def test_product_fails_loudly_without_gpu_or_library(monkeypatch):

@@ -22,10 +22,11 @@ def main():
     ap.add_argument("--slices", type=int, default=1)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="p2l")
+    ap.add_argument("--prec", default="f32")
     a = ap.parse_args()
     dims = _lib.conv_dims(a.kind)
     sd = weights.init_state_dict(1)
-    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind)
+    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PRECISIONS[a.prec])
     B, NL, NP = a.B, a.nl, a.np
     dev = "cuda"
     lig_ptr = torch.arange(B + 1, dtype=torch.int32) * NL
@@ -42,6 +43,7 @@ def main():
     keep.update(lig_ptr=lig_ptr.to(dev), ph_ptr=ph_ptr.to(dev), x_ptr=x_ptr.to(dev))
     args = _lib.DpConvArgs()
     args.kind, args.B, args.slices = a.kind, B, a.slices
+    args.precision = _lib.PRECISIONS[a.prec]
     args.mode = _lib.EDGES_P2L if a.mode == "p2l" else _lib.EDGES_L2P
     args.scat_ptr = keep["lig_ptr"].data_ptr() if a.mode == "p2l" else keep["ph_ptr"].data_ptr()
     args.lig_ptr, args.ph_ptr, args.x_ptr = keep["lig_ptr"].data_ptr(), keep["ph_ptr"].data_ptr(), keep["x_ptr"].data_ptr()
@@ -65,7 +67,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    print(json.dumps(dict(kind=a.kind, mode=a.mode, B=B, edges=E, ms=ms, ns_per_edge=ms * 1e6 / E,
+    print(json.dumps(dict(kind=a.kind, prec=a.prec, mode=a.mode, B=B, edges=E, ms=ms, ns_per_edge=ms * 1e6 / E,
                           alg_GBps=E * ALG_BYTES[a.kind] / ms / 1e6, TFLOPs=E * FLOPS[a.kind] / ms / 1e9)))
 
 
