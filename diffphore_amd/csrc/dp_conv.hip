@@ -582,31 +582,88 @@ __device__ __forceinline__ void split_hidden(const float (&hid)[32], HidB<KIND, 
 
 typedef const __attribute__((address_space(1))) vu4* gptrq;
 
+// tiles staged per LDS buffer: the workgroup barrier is taken once per KT tiles, so inside a group the two waves of a SIMD
+// drift apart and one wave's VALU contraction overlaps the other's MFMA chain (a barrier per tile keeps them in lock-step).
+template <int NS> constexpr int KT = NS == 3 ? 2 : 3;
+template <int KIND> constexpr int MSG_LD_B = (n_acc_phase<KIND>(0) > n_acc_phase<KIND>(1) ? n_acc_phase<KIND>(0) : n_acc_phase<KIND>(1)) + 1;
+
+template <int KIND, int PH> struct ChanLut {
+  static constexpr int N = n_acc_phase<KIND>(PH) > 0 ? n_acc_phase<KIND>(PH) : 1;
+  int v[N];
+  constexpr ChanLut() : v{} {
+    for (int i = 0; i < n_acc_phase<KIND>(PH); ++i) v[i] = channel_of<KIND>(PH, i);
+  }
+};
+template <int KIND, int PH> __device__ constexpr ChanLut<KIND, PH> kChanLut{};
+
+// cross-half sum of one phase's accumulators, staged COMPACTLY (phase-local channel index) into the LDS message row
+template <int KIND, int PH, int... CI>
+__device__ __forceinline__ void stage_phase_compact(float (&acc)[NACC<KIND>], float* row, int half, std::integer_sequence<int, CI...>) {
+  (
+      [&] {
+        const float other = __shfl_xor(acc[CI], 32, 64);
+        if ((CI & 1) == half) row[CI] = acc[CI] + other;
+      }(),
+      ...);
+}
+
+// ordered segmented sum of one phase's staged messages
+template <int KIND, int PH>
+__device__ __forceinline__ void segmented_sum_phase(const float* s_msg, const int* s_node, float* s_acc, int nedge) {
+  using S = Spec<KIND>;
+  constexpr int NA = n_acc_phase<KIND>(PH);
+  const int tid = threadIdx.x;
+  if (tid < NA) {
+    const int ch = kChanLut<KIND, PH>.v[tid];
+    float run = 0.f;
+    int cur = -1;
+    for (int ei = 0; ei < nedge; ++ei) {
+      const int n = s_node[ei];
+      if (n != cur) {
+        if (cur >= 0) s_acc[cur * S::D_OUT + ch] += run;
+        run = 0.f;
+        cur = n;
+      }
+      if (n >= 0) run += s_msg[ei * MSG_LD_B<KIND> + tid];
+    }
+    if (cur >= 0) s_acc[cur * S::D_OUT + ch] += run;
+  }
+}
+
 template <int KIND, int NS, int TILE>
 struct StageB {
   static __device__ __forceinline__ void run(gptrq wp, int tid, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
                                              const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
-                                             const float (&M)[9], float (&acc)[NACC<KIND>], float* row, int half) {
+                                             const float (&M)[9], float (&acc)[NACC<KIND>], float* row, int half,
+                                             const float* s_msg, const int* s_node, float* s_acc, int nedge,
+                                             vu4 (&pre)[KT<NS> * ((TILE_QUADS<KIND, NS> + WAVES_B * 64 - 1) / (WAVES_B * 64))]) {
     using G = Geo<KIND>;
     constexpr int NT0 = n_tiles_phase<KIND>(0);
     constexpr int NQ = TILE_QUADS<KIND, NS>;
     constexpr int NPRE = (NQ + WAVES_B * 64 - 1) / (WAVES_B * 64);
+    constexpr int K = KT<NS>;
+    constexpr int GRP = TILE / K, POS = TILE % K;
     if constexpr (TILE < G::NT) {
-      if constexpr (TILE == NT0 && NT0 > 0) {      // phase boundary: scalar outputs done
-        stage_phase<KIND, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0)>{});
+      if constexpr (TILE == NT0 && NT0 > 0) {      // phase boundary: scalar outputs done -> stage, reduce, restart accumulators
+        stage_phase_compact<KIND, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0)>{});
+        __syncthreads();
+        segmented_sum_phase<KIND, 0>(s_msg, s_node, s_acc, nedge);
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
       }
-      // issue the global loads of the NEXT tile now; they land while this tile's MFMAs run (written to LDS below)
-      vu4 pre[NPRE];
-      wp += NQ;
-      asm volatile("" : "+s"(wp));
-      if constexpr (TILE + 1 < G::NT) {
+      if constexpr (POS == 0 && (GRP + 1) * K < G::NT) {
+        // issue the global loads of the NEXT group of tiles; they land while this group's MFMAs run
+        wp += K * NQ;
+        asm volatile("" : "+s"(wp));
+        constexpr int NTN = ((GRP + 2) * K <= G::NT) ? K : (G::NT - (GRP + 1) * K);
 #pragma unroll
-        for (int q = 0; q < NPRE; ++q)
-          if (tid + q * WAVES_B * 64 < NQ) pre[q] = wp[tid + q * WAVES_B * 64];
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+          for (int q = 0; q < NPRE; ++q)
+            if (tid + q * WAVES_B * 64 < NQ) pre[t * NPRE + q] = wp[t * NQ + tid + q * WAVES_B * 64];
       }
-      const vu4* buf = s_w + (TILE & 1) * NQ;
+      const vu4* buf = s_w + ((GRP & 1) * K + POS) * NQ;
       f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int b = 0; b < NKB<KIND>; ++b) {
@@ -624,20 +681,24 @@ struct StageB {
         D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][0], D, 0, 0, 0);
       }
       contract_tile<KIND, TILE>(D, xr, sh, M, acc, std::make_integer_sequence<int, 16>{});
-      if constexpr (TILE + 1 < G::NT) {
-        vu4* nbuf = s_w + ((TILE + 1) & 1) * NQ;
+      if constexpr ((POS == K - 1 || TILE + 1 == G::NT) && (GRP + 1) * K < G::NT) {
+        // end of the group: publish the prefetched next group into the other LDS buffer
+        constexpr int NTN = ((GRP + 2) * K <= G::NT) ? K : (G::NT - (GRP + 1) * K);
+        vu4* nbuf = s_w + (((GRP + 1) & 1) * K) * NQ;
 #pragma unroll
-        for (int q = 0; q < NPRE; ++q)
-          if (tid + q * WAVES_B * 64 < NQ) nbuf[tid + q * WAVES_B * 64] = pre[q];
+        for (int t = 0; t < NTN; ++t)
+#pragma unroll
+          for (int q = 0; q < NPRE; ++q)
+            if (tid + q * WAVES_B * 64 < NQ) nbuf[t * NQ + tid + q * WAVES_B * 64] = pre[t * NPRE + q];
+        __syncthreads();          // next group's weights visible; everyone is done reading this group's buffer
       }
-      __syncthreads();          // next tile's weights visible; everyone is done reading this tile's buffer
       __builtin_amdgcn_sched_barrier(0);
-      StageB<KIND, NS, TILE + 1>::run(wp, tid, lane, s_w, hb, xr, sh, M, acc, row, half);
+      StageB<KIND, NS, TILE + 1>::run(wp, tid, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_node, s_acc, nedge, pre);
     } else {
-      if constexpr (n_tiles_phase<KIND>(1) > 0)
-        stage_phase<KIND, 1>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(1)>{});
-      else
-        stage_phase<KIND, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0)>{});
+      constexpr int PHL = n_tiles_phase<KIND>(1) > 0 ? 1 : 0;
+      stage_phase_compact<KIND, PHL>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(PHL)>{});
+      __syncthreads();
+      segmented_sum_phase<KIND, PHL>(s_msg, s_node, s_acc, nedge);
     }
   }
 };
@@ -647,10 +708,12 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
   using S = Spec<KIND>;
   using G = Geo<KIND>;
   constexpr int NQ = TILE_QUADS<KIND, NS>;
-  __shared__ float s_msg[CHUNK_B * G::MSG_LD];
+  constexpr int K = KT<NS>;
+  constexpr int NPRE = (NQ + WAVES_B * 64 - 1) / (WAVES_B * 64);
+  __shared__ float s_msg[CHUNK_B * MSG_LD_B<KIND>];
   __shared__ float s_acc[MAX_NODES * S::D_OUT];
   __shared__ int s_node[CHUNK_B];
-  __shared__ vu4 s_w[2 * NQ];
+  __shared__ vu4 s_w[2 * K * NQ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
   const WgRange r = wg_range(a);
@@ -667,18 +730,19 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
       split_hidden<KIND, NS>(hid, hb);
     }
     load_tp_operands<KIND>(a, e, half, xr, sh, M);
-    __syncthreads();                              // previous chunk: segmented sum done with s_msg, s_w free
+    __syncthreads();                              // previous chunk: last segmented sum done with s_msg / s_node, s_w free
     gptrq wp = (gptrq)a.w2p;
-    for (int q = tid; q < NQ; q += WAVES_B * 64) s_w[q] = wp[q];      // tile 0
-    float* row = s_msg + (size_t)(wave * 32 + ecol) * G::MSG_LD;
+    constexpr int NT_FIRST = K < G::NT ? K : G::NT;
+    for (int q = tid; q < NT_FIRST * NQ; q += WAVES_B * 64) s_w[q] = wp[q];      // first group of tiles
+    if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
+    float* row = s_msg + (size_t)(wave * 32 + ecol) * MSG_LD_B<KIND>;
     float acc[NACC<KIND>];
 #pragma unroll
     for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
+    vu4 pre[K * NPRE];
     __syncthreads();
-    StageB<KIND, NS, 0>::run(wp, tid, lane, s_w, hb, xr, sh, M, acc, row, half);
-    if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
-    __syncthreads();
-    segmented_sum<KIND, CHUNK_B>(s_msg, s_node, s_acc, min(CHUNK_B, r.k_end - kc));
+    StageB<KIND, NS, 0>::run(wp, tid, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_node, s_acc,
+                             min(CHUNK_B, r.k_end - kc), pre);
   }
   __syncthreads();
   conv_epilogue<KIND, WAVES_B * 64>(a, r, s_acc);
