@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WAVES = 4;            // waves per workgroup
 constexpr int CHUNK = WAVES * 32;   // edges per workgroup iteration
-constexpr int MAX_NODES = 64;       // scatter nodes per workgroup (host picks `slices` accordingly)
+constexpr int MAX_NODES = 48;       // scatter nodes per workgroup (host picks `slices` accordingly)
 
 template <int KIND> struct Geo {
   using S = Spec<KIND>;
@@ -497,12 +497,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
 //   x = x_hi + x_mid (+ x_lo), each part a bf16;  w.h ~= sum of the NS*(NS+1)/2 largest cross products, fp32 accumulate.
 //   NS = 3 (6 products): relative error ~2^-24, i.e. fp32-grade;  NS = 2 (3 products): ~2^-17.
 //   v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate, so a tile costs 24 (or 12) x 32 cycles instead of 32 x 64.
-//   At that rate per-lane weight streaming from L2 would saturate the CU's L1/L2 path, so the 8 waves of a workgroup share
-//   each packed weight tile through a double-buffered LDS stage (register-staged, written after the MFMA phase).
+//   At that rate per-lane weight streaming from L2 would saturate the CU's L1/L2 path, so the 4 waves of a workgroup share
+//   each packed weight tile through a double-buffered LDS stage (register-staged, written after the MFMA phase).  Two
+//   workgroups run per CU; inside one the waves are barrier-coupled per tile, across the two they are not, which is what lets
+//   one wave's VALU / LDS / memory phases overlap the other's MFMA chain on the same SIMD.
 // ---------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
-constexpr int WAVES_B = 8;
+constexpr int WAVES_B = 4;        // two such workgroups share a CU: their waves are not barrier-coupled, so one hides the other
 constexpr int CHUNK_B = WAVES_B * 32;
 
 template <int KIND> constexpr int NKB = (Spec<KIND>::HID + 1 + 15) / 16;            // 16-wide K blocks incl. the bias row
@@ -584,7 +586,7 @@ typedef const __attribute__((address_space(1))) vu4* gptrq;
 
 // tiles staged per LDS buffer: the workgroup barrier is taken once per KT tiles, so inside a group the two waves of a SIMD
 // drift apart and one wave's VALU contraction overlaps the other's MFMA chain (a barrier per tile keeps them in lock-step).
-template <int NS> constexpr int KT = NS == 3 ? 2 : 3;
+template <int NS> constexpr int KT = 1;
 template <int KIND> constexpr int MSG_LD_B = (n_acc_phase<KIND>(0) > n_acc_phase<KIND>(1) ? n_acc_phase<KIND>(0) : n_acc_phase<KIND>(1)) + 1;
 
 template <int KIND, int PH> struct ChanLut {
