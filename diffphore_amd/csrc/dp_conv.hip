@@ -25,6 +25,10 @@
 #include "../../include/diffphore_amd.h"
 #include "dp_spec.h"
 
+#ifndef DP_ABLATE
+#define DP_ABLATE 0
+#endif
+
 namespace dp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -508,7 +512,7 @@ constexpr int WAVES_B = 4;        // two such workgroups share a CU: their waves
 constexpr int CHUNK_B = WAVES_B * 32;
 
 template <int KIND> constexpr int NKB = (Spec<KIND>::HID + 1 + 15) / 16;            // 16-wide K blocks incl. the bias row
-template <int KIND, int NS> constexpr int TILE_QUADS = NKB<KIND> * NS * 64;         // uint4 per packed tile
+template <int KIND, int NS> constexpr int TILE_QUADS = (NKB<KIND> * NS * 64 + 255) / 256 * 256;   // uint4 per packed tile, padded to whole 4-wave DMA rounds
 // hidden row held by lane half `half` at position j (0..7) of K block b: the D-fragment row of GEMM1 register 8*(b&1)+j, tile b>>1
 constexpr int hid_row_b(int b, int half, int j) {
   const int r = 8 * (b & 1) + j;
@@ -547,7 +551,7 @@ template <int KIND, int NS> void pack_w2_bf16(const float* fc3_w, const float* f
           for (int s = 0; s < NS; ++s) {
             const unsigned short h = f32_to_bf16_rne(rem);
             rem -= bf16_to_f32(h);
-            out[((((size_t)tile * NKB<KIND> + b) * NS + s) * 64 + lane) * 8 + j] = h;
+            out[((size_t)tile * TILE_QUADS<KIND, NS> + ((size_t)b * NS + s) * 64 + lane) * 8 + j] = h;
           }
         }
       }
@@ -632,19 +636,34 @@ __device__ __forceinline__ void segmented_sum_phase(const float* s_msg, const in
   }
 }
 
+typedef __attribute__((address_space(3))) vu4* lptrq;
+constexpr int MAX_NODES_B = 32;                                   // LDS budget: two workgroups per CU
+template <int NS> constexpr int RING = NS == 3 ? 3 : 4;           // weight-tile ring depth (tiles in flight = RING-1)
+template <int KIND, int NS> constexpr int PIECES = TILE_QUADS<KIND, NS> / (WAVES_B * 64);   // 1-KiB DMA pieces per wave per tile
+
+// asynchronous L2 -> LDS copy of one packed weight tile (buffer_load...lds / global_load_lds_dwordx4: no VGPRs, counted on vmcnt)
+template <int KIND, int NS>
+__device__ __forceinline__ void dma_tile(gptrq src_tile, vu4* slot, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < PIECES<KIND, NS>; ++i)
+    __builtin_amdgcn_global_load_lds(src_tile + i * WAVES_B * 64 + wave * 64 + lane, (lptrq)(slot + i * WAVES_B * 64 + wave * 64), 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Stage TILE of the split-bf16 pipeline.  The packed weights stream L2 -> LDS through a RING-deep ring filled by LDS-DMA
+// RING-1 tiles ahead (an L2 round trip under load is ~2k cycles, longer than one bf16 tile), so a tile costs:
+//   issue DMA(tile+RING-1) | ds_read operands | 12 or 24 bf16 MFMAs | VALU contraction | counted vmcnt | s_barrier.
 template <int KIND, int NS, int TILE>
 struct StageB {
-  static __device__ __forceinline__ void run(gptrq wp, int tid, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
+  static __device__ __forceinline__ void run(gptrq w2p, int wave, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
                                              const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
                                              const float (&M)[9], float (&acc)[NACC<KIND>], float* row, int half,
-                                             const float* s_msg, const int* s_node, float* s_acc, int nedge,
-                                             vu4 (&pre)[KT<NS> * ((TILE_QUADS<KIND, NS> + WAVES_B * 64 - 1) / (WAVES_B * 64))]) {
+                                             const float* s_msg, const int* s_node, float* s_acc, int nedge) {
     using G = Geo<KIND>;
     constexpr int NT0 = n_tiles_phase<KIND>(0);
     constexpr int NQ = TILE_QUADS<KIND, NS>;
-    constexpr int NPRE = (NQ + WAVES_B * 64 - 1) / (WAVES_B * 64);
-    constexpr int K = KT<NS>;
-    constexpr int GRP = TILE / K, POS = TILE % K;
+    constexpr int R = RING<NS>;
     if constexpr (TILE < G::NT) {
       if constexpr (TILE == NT0 && NT0 > 0) {      // phase boundary: scalar outputs done -> stage, reduce, restart accumulators
         stage_phase_compact<KIND, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0)>{});
@@ -654,24 +673,31 @@ struct StageB {
 #pragma unroll
         for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
       }
-      if constexpr (POS == 0 && (GRP + 1) * K < G::NT) {
-        // issue the global loads of the NEXT group of tiles; they land while this group's MFMAs run
-        wp += K * NQ;
-        asm volatile("" : "+s"(wp));
-        constexpr int NTN = ((GRP + 2) * K <= G::NT) ? K : (G::NT - (GRP + 1) * K);
-#pragma unroll
-        for (int t = 0; t < NTN; ++t)
-#pragma unroll
-          for (int q = 0; q < NPRE; ++q)
-            if (tid + q * WAVES_B * 64 < NQ) pre[t * NPRE + q] = wp[t * NQ + tid + q * WAVES_B * 64];
+      if constexpr (TILE + R - 1 < G::NT) {        // slot (TILE-1)%R was released by the barrier that ended stage TILE-1
+#if DP_ABLATE == 5
+        gptrq src = w2p;                                        // every tile from the same 8-12 KB: L1/L2-hot source
+#else
+        gptrq src = w2p + (size_t)(TILE + R - 1) * NQ;
+#endif
+        asm volatile("" : "+s"(src));
+        dma_tile<KIND, NS>(src, s_w + ((TILE + R - 1) % R) * NQ, wave, lane);
       }
-      const vu4* buf = s_w + ((GRP & 1) * K + POS) * NQ;
+      const vu4* buf = s_w + (TILE % R) * NQ;
       f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if DP_ABLATE == 2
+      for (int r_ = 0; r_ < 16; ++r_) D[r_] = hb.v[0][0][0] == (__bf16)123.f ? 1.f : 0.5f;
+#else
+      // NB (measured, profiles/r1_bf16_ablation.md): the ds_read_b128 operand fetches are what bounds this kernel (~50-60 B/clk/CU
+      // effective); issuing them all up front or double-buffering them per block made no difference at 256 VGPRs.
 #pragma unroll
       for (int b = 0; b < NKB<KIND>; ++b) {
         bf16x8 W[NS];
 #pragma unroll
+#if DP_ABLATE == 3
+        for (int s = 0; s < NS; ++s) W[s] = hb.v[b][s];
+#else
         for (int s = 0; s < NS; ++s) W[s] = __builtin_bit_cast(bf16x8, buf[(b * NS + s) * 64 + lane]);
+#endif
         // smallest cross terms first
         if constexpr (NS == 3) {
           D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[b][1], D, 0, 0, 0);
@@ -682,20 +708,21 @@ struct StageB {
         D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][1], D, 0, 0, 0);
         D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][0], D, 0, 0, 0);
       }
+#endif
+#if DP_ABLATE == 1
+      for (int r_ = 0; r_ < 16; ++r_) asm volatile("" ::"v"(D[r_]));
+#else
       contract_tile<KIND, TILE>(D, xr, sh, M, acc, std::make_integer_sequence<int, 16>{});
-      if constexpr ((POS == K - 1 || TILE + 1 == G::NT) && (GRP + 1) * K < G::NT) {
-        // end of the group: publish the prefetched next group into the other LDS buffer
-        constexpr int NTN = ((GRP + 2) * K <= G::NT) ? K : (G::NT - (GRP + 1) * K);
-        vu4* nbuf = s_w + (((GRP + 1) & 1) * K) * NQ;
-#pragma unroll
-        for (int t = 0; t < NTN; ++t)
-#pragma unroll
-          for (int q = 0; q < NPRE; ++q)
-            if (tid + q * WAVES_B * 64 < NQ) nbuf[t * NQ + tid + q * WAVES_B * 64] = pre[t * NPRE + q];
-        __syncthreads();          // next group's weights visible; everyone is done reading this group's buffer
+#endif
+      if constexpr (TILE + 1 < G::NT) {
+        // tile TILE+1 must have landed; tiles TILE+2 .. min(TILE+R-1, NT-1) may stay in flight across the barrier
+        constexpr int last = (TILE + R - 1 < G::NT - 1) ? (TILE + R - 1) : (G::NT - 1);
+        wait_vmcnt<(last - (TILE + 1)) * PIECES<KIND, NS>>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's ds_reads of the slot about to be recycled are done
+        __builtin_amdgcn_s_barrier();
       }
       __builtin_amdgcn_sched_barrier(0);
-      StageB<KIND, NS, TILE + 1>::run(wp, tid, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_node, s_acc, nedge, pre);
+      StageB<KIND, NS, TILE + 1>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_node, s_acc, nedge);
     } else {
       constexpr int PHL = n_tiles_phase<KIND>(1) > 0 ? 1 : 0;
       stage_phase_compact<KIND, PHL>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(PHL)>{});
@@ -710,17 +737,18 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
   using S = Spec<KIND>;
   using G = Geo<KIND>;
   constexpr int NQ = TILE_QUADS<KIND, NS>;
-  constexpr int K = KT<NS>;
-  constexpr int NPRE = (NQ + WAVES_B * 64 - 1) / (WAVES_B * 64);
+  constexpr int R = RING<NS>;
+  static_assert(NQ % (WAVES_B * 64) == 0, "a packed tile must be a whole number of 1-KiB DMA pieces per wave");
+  __shared__ __attribute__((aligned(16))) vu4 s_w[R * NQ];       // first: the DMA destination must be 16-byte aligned
   __shared__ float s_msg[CHUNK_B * MSG_LD_B<KIND>];
-  __shared__ float s_acc[MAX_NODES * S::D_OUT];
+  __shared__ float s_acc[MAX_NODES_B * S::D_OUT];
   __shared__ int s_node[CHUNK_B];
-  __shared__ vu4 s_w[2 * K * NQ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
   const WgRange r = wg_range(a);
   if (r.n_loc <= 0) return;
   for (int i = tid; i < r.n_loc * S::D_OUT; i += WAVES_B * 64) s_acc[i] = 0.f;
+  gptrq w2p = (gptrq)a.w2p;
 
   for (int kc = r.k_begin; kc < r.k_end; kc += CHUNK_B) {
     const EdgeRef e = decode_edge(a, r, kc + wave * 32 + ecol);
@@ -732,19 +760,21 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
       split_hidden<KIND, NS>(hid, hb);
     }
     load_tp_operands<KIND>(a, e, half, xr, sh, M);
-    __syncthreads();                              // previous chunk: last segmented sum done with s_msg / s_node, s_w free
-    gptrq wp = (gptrq)a.w2p;
-    constexpr int NT_FIRST = K < G::NT ? K : G::NT;
-    for (int q = tid; q < NT_FIRST * NQ; q += WAVES_B * 64) s_w[q] = wp[q];      // first group of tiles
+    // keep the gathered operands in registers NOW: no ordinary global load may be pending once the DMA ring is running
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                              // previous chunk: last segmented sum done with s_msg / s_node, ring free
+    constexpr int NPRO = (R - 1 < G::NT) ? (R - 1) : G::NT;
+#pragma unroll
+    for (int t = 0; t < NPRO; ++t) dma_tile<KIND, NS>(w2p + (size_t)t * NQ, s_w + t * NQ, wave, lane);
     if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
     float* row = s_msg + (size_t)(wave * 32 + ecol) * MSG_LD_B<KIND>;
     float acc[NACC<KIND>];
 #pragma unroll
     for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
-    vu4 pre[K * NPRE];
-    __syncthreads();
-    StageB<KIND, NS, 0>::run(wp, tid, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_node, s_acc,
-                             min(CHUNK_B, r.k_end - kc), pre);
+    wait_vmcnt<(NPRO - 1) * PIECES<KIND, NS>>();   // tile 0 landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    StageB<KIND, NS, 0>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_node, s_acc, min(CHUNK_B, r.k_end - kc));
   }
   __syncthreads();
   conv_epilogue<KIND, WAVES_B * 64>(a, r, s_acc);
@@ -771,6 +801,8 @@ template <int KIND> int w2p_floats(int prec) {
 extern "C" {
 
 int dp_abi_version(void) { return DP_ABI_VERSION; }
+
+int dp_conv_max_nodes(int32_t precision) { return precision == DP_PREC_F32 ? dp::MAX_NODES : dp::MAX_NODES_B; }
 
 int dp_conv_dims(int32_t kind, int32_t* d_in, int32_t* d_out, int32_t* numel, int32_t* n_attr, int32_t* hidden) {
 #define DP_CASE(K)                                                                        \
@@ -833,12 +865,16 @@ int dp_tp_conv(const DpConvArgs* a, void* stream) {
   if (a->kind != DP_CONV_FINAL && !a->attr2_tab) return DP_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   switch (a->kind) {
+#ifdef DP_ONLY_KIND3                       // ablation / tuning builds: one instantiation compiles in seconds
+    case 3: return dp::launch<3>(*a, st);
+#else
     case 0: return dp::launch<0>(*a, st);
     case 1: return dp::launch<1>(*a, st);
     case 2: return dp::launch<2>(*a, st);
     case 3: return dp::launch<3>(*a, st);
     case 4: return dp::launch<4>(*a, st);
     case 5: return dp::launch<5>(*a, st);
+#endif
     default: return DP_E_BADARG;
   }
 }

@@ -582,7 +582,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   int slices = 1;
   {
     const int mx = b->max_nl > b->max_np ? b->max_nl : b->max_np;
-    while ((mx + slices - 1) / slices > 48) ++slices;
+    while ((mx + slices - 1) / slices > dp_conv_max_nodes(w->precision)) ++slices;
     while (B * slices < 512 && slices < 8) ++slices;
   }
   int cur = 0;
@@ -665,7 +665,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     memset(&c, 0, sizeof(c));
     c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr; c.precision = w->precision;
     c.slices = 1;
-    while ((b->max_t + c.slices - 1) / c.slices > 48) ++c.slices;
+    while ((b->max_t + c.slices - 1) / c.slices > dp_conv_max_nodes(w->precision)) ++c.slices;
     c.rowptr = k->t_rowptr; c.rowend = k->t_rowend; c.nbr = k->t_nbr; c.edge_scat = k->t_src;
     c.gather_tab = hl; c.gather_stride = 100; c.attr1_tab = hl; c.attr1_stride = 100; c.attr2_tab = k->t_hb; c.attr2_stride = 20;
     c.attr_swap = 1; c.edge_emb = k->t_emb; c.edge_sh = k->t_sh; c.sh_stride = 7;

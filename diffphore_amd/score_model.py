@@ -28,7 +28,7 @@ _KW = {"lig_max_radius": "lig_max_radius", "num_conv_layers": "num_conv_layers",
 
 
 class TensorProductScoreModel:
-    def __init__(self, t_to_sigma=None, device="cuda", timestep_emb_func=None, sigma_args=None, **kwargs):
+    def __init__(self, t_to_sigma=None, device="cuda", timestep_emb_func=None, sigma_args=None, precision=None, **kwargs):
         cfg = cfgmod.ModelConfig()
         if "clash_cutoff" in kwargs:
             cfg.clash_cutoff = tuple(float(x) for x in kwargs.pop("clash_cutoff"))
@@ -44,6 +44,7 @@ class TensorProductScoreModel:
                 setattr(cfg, k, float(getattr(a, k)))
         cfg.check_supported()
         self.cfg = cfg
+        self.precision = precision        # None -> $DIFFPHORE_PRECISION or engine.DEFAULT_PRECISION ("f32" | "bf16x6" | "bf16x3")
         self.t_to_sigma = t_to_sigma
         self.device = torch.device(device)
         self.no_torsion = cfg.no_torsion
@@ -56,7 +57,7 @@ class TensorProductScoreModel:
     # ---- nn.Module-like surface used by the reference callers (inference.py:437-443) --------------------------------------
     def load_state_dict(self, state_dict, strict=True):
         self._sd = state_dict
-        self._dev = DeviceModel(state_dict, self.cfg, self.device)
+        self._dev = DeviceModel(state_dict, self.cfg, self.device, precision=self.precision)
         self._engine = None
         return self
 

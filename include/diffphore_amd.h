@@ -104,6 +104,8 @@ typedef struct DpConvArgs {
  * Replaces TensorProductConvLayer.forward, score_model_phore.py:134-149. */
 int dp_tp_conv(const DpConvArgs* args, void* stream);
 
+/* scatter nodes one workgroup can own: callers of dp_tp_conv pick `slices` so that ceil(nodes per pose / slices) <= this */
+int dp_conv_max_nodes(int32_t precision);
 /* numbers the host packer needs */
 int dp_conv_w1p_floats(int32_t kind);
 int dp_conv_w2p_floats(int32_t kind, int32_t precision);

@@ -23,7 +23,10 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="p2l")
     ap.add_argument("--prec", default="f32")
+    ap.add_argument("--lib", default=None, help="alternative libdiffphore_hip.so (ablation builds)")
     a = ap.parse_args()
+    if a.lib:
+        _lib.LIB_PATH = a.lib
     dims = _lib.conv_dims(a.kind)
     sd = weights.init_state_dict(1)
     pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PRECISIONS[a.prec])
