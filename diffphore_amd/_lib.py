@@ -22,7 +22,7 @@ EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER = range(4)
 
 class DpConvArgs(C.Structure):
     _fields_ = [
-        ("kind", c_i32), ("mode", c_i32), ("B", c_i32), ("slices", c_i32), ("precision", c_i32),
+        ("kind", c_i32), ("mode", c_i32), ("B", c_i32), ("slices", c_i32), ("precision", c_i32), ("max_scatter", c_i32),
         ("scat_ptr", VOIDP), ("lig_ptr", VOIDP), ("ph_ptr", VOIDP), ("x_ptr", VOIDP),
         ("rowptr", VOIDP), ("rowend", VOIDP), ("nbr", VOIDP), ("edge_scat", VOIDP),
         ("gather_tab", VOIDP), ("gather_stride", c_i32),

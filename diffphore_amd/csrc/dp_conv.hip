@@ -863,6 +863,8 @@ int dp_tp_conv(const DpConvArgs* a, void* stream) {
   if (a->mode != DP_EDGES_CSR && !a->lig_ptr) return DP_E_BADARG;
   if ((a->mode == DP_EDGES_P2L || a->mode == DP_EDGES_L2P) && (!a->ph_ptr || !a->x_ptr)) return DP_E_BADARG;
   if (a->kind != DP_CONV_FINAL && !a->attr2_tab) return DP_E_BADARG;
+  if (a->max_scatter <= 0) return DP_E_BADARG;
+  if ((a->max_scatter + a->slices - 1) / a->slices > dp_conv_max_nodes(a->precision)) return DP_E_TOOLARGE;
   hipStream_t st = (hipStream_t)stream;
   switch (a->kind) {
 #ifdef DP_ONLY_KIND3                       // ablation / tuning builds: one instantiation compiles in seconds

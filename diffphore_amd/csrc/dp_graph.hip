@@ -608,7 +608,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     a.gather_stride = a.attr1_stride = a.attr2_stride = 100;
     {
       DpConvArgs c = a;
-      c.mode = DP_EDGES_CSR; c.scat_ptr = b->lig_ptr; c.rowptr = k->ll_rowptr; c.rowend = k->ll_rowend; c.nbr = k->ll_nbr;
+      c.mode = DP_EDGES_CSR; c.scat_ptr = b->lig_ptr; c.max_scatter = b->max_nl; c.rowptr = k->ll_rowptr; c.rowend = k->ll_rowend; c.nbr = k->ll_nbr;
       c.edge_scat = k->ll_src; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hl; c.edge_emb = k->ll_emb; c.edge_sh = k->ll_sh;
       c.w1p = w->lig_conv[l].w1p; c.w2p = w->lig_conv[l].w2p; c.bn_scale = w->lig_conv[l].bn_scale; c.bn_shift = w->lig_conv[l].bn_shift;
       c.out = hl2; c.accumulate = 0; c.resid = hl; c.resid_width = din;
@@ -617,7 +617,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     for (int nv = 0; nv < 2; ++nv) {
       DpConvArgs c = a;
       const DpConvW& cw = nv ? w->p2l_norm_conv[l] : w->p2l_conv[l];
-      c.mode = DP_EDGES_P2L; c.scat_ptr = b->lig_ptr; c.gather_tab = hp; c.attr1_tab = hl; c.attr2_tab = hp;
+      c.mode = DP_EDGES_P2L; c.scat_ptr = b->lig_ptr; c.max_scatter = b->max_nl; c.gather_tab = hp; c.attr1_tab = hl; c.attr2_tab = hp;
       c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
@@ -626,7 +626,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
       {
         DpConvArgs c = a;
-        c.mode = DP_EDGES_CSR; c.scat_ptr = b->ph_ptr; c.rowptr = b->pp_rowptr; c.rowend = b->pp_rowend; c.nbr = b->pp_dst;
+        c.mode = DP_EDGES_CSR; c.scat_ptr = b->ph_ptr; c.max_scatter = b->max_np; c.rowptr = b->pp_rowptr; c.rowend = b->pp_rowend; c.nbr = b->pp_dst;
         c.edge_scat = b->pp_src; c.gather_tab = hp; c.attr1_tab = hp; c.attr2_tab = hp; c.edge_emb = k->pp_emb; c.edge_sh = k->pp_sh;
         c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
@@ -635,7 +635,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       for (int nv = 0; nv < 2; ++nv) {
         DpConvArgs c = a;
         const DpConvW& cw = nv ? w->l2p_norm_conv[l] : w->l2p_conv[l];
-        c.mode = DP_EDGES_L2P; c.scat_ptr = b->ph_ptr; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hp;
+        c.mode = DP_EDGES_L2P; c.scat_ptr = b->ph_ptr; c.max_scatter = b->max_np; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hp;
         c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
@@ -650,7 +650,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   {
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
-    c.kind = DP_CONV_FINAL; c.mode = DP_EDGES_CENTER; c.B = B; c.slices = 1; c.precision = w->precision; c.scat_ptr = b->pose_ptr; c.lig_ptr = b->lig_ptr;
+    c.kind = DP_CONV_FINAL; c.mode = DP_EDGES_CENTER; c.B = B; c.slices = 1; c.precision = w->precision; c.max_scatter = 1; c.scat_ptr = b->pose_ptr; c.lig_ptr = b->lig_ptr;
     c.gather_tab = hl; c.gather_stride = 100; c.attr1_tab = hl; c.attr1_stride = 100;
     c.edge_emb = k->c_emb; c.edge_sh = k->c_sh; c.sh_stride = 9;
     c.w1p = w->final_conv.w1p; c.w2p = w->final_conv.w2p; c.bn_scale = w->final_conv.bn_scale; c.bn_shift = w->final_conv.bn_shift;
@@ -663,7 +663,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k, hl);
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
-    c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr; c.precision = w->precision;
+    c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr; c.precision = w->precision; c.max_scatter = b->max_t > 0 ? b->max_t : 1;
     c.slices = 1;
     while ((b->max_t + c.slices - 1) / c.slices > dp_conv_max_nodes(w->precision)) ++c.slices;
     c.rowptr = k->t_rowptr; c.rowend = k->t_rowend; c.nbr = k->t_nbr; c.edge_scat = k->t_src;

@@ -63,6 +63,7 @@ typedef struct DpConvArgs {
   int32_t B;             /* poses */
   int32_t slices;        /* workgroups per pose (>=1); scatter nodes of a pose are split evenly between them */
   int32_t precision;     /* DpPrecision; must match the precision w2p was packed for */
+  int32_t max_scatter;   /* largest number of scatter nodes of any pose; ceil(max_scatter / slices) must be <= dp_conv_max_nodes() */
   /* pose CSRs (B+1 entries each) */
   const int32_t* scat_ptr;   /* scatter-node offsets per pose (ligand atoms / phore nodes / rotatable bonds / poses) */
   const int32_t* lig_ptr;    /* ligand atom offsets per pose */

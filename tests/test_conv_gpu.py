@@ -102,7 +102,7 @@ def test_conv_csr_ragged(kind, slices, prec):
     resid = torch.randn(N, dims["d_in"], generator=g)
     out = torch.full((N, dims["d_out"]), float("nan")).cuda()
     keep = []
-    base = dict(kind=kind, mode=_lib.EDGES_CSR, B=B, slices=slices, precision=_lib.PRECISIONS[prec], scat_ptr=_dev(_i32(scat_ptr)),
+    base = dict(kind=kind, mode=_lib.EDGES_CSR, B=B, slices=slices, precision=_lib.PRECISIONS[prec], max_scatter=max(n_nodes), scat_ptr=_dev(_i32(scat_ptr)),
                 rowptr=_dev(_i32(rowptr)), rowend=_dev(_i32(rowend)), nbr=_dev(nbr_slots), edge_scat=_dev(scat_slots),
                 gather_tab=_dev(h), gather_stride=dims["d_in"], attr1_tab=_dev(h), attr1_stride=dims["d_in"],
                 attr2_tab=_dev(h), attr2_stride=dims["d_in"], attr_swap=0, edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9,
@@ -157,7 +157,7 @@ def test_conv_dense_cross(kind, mode, prec):
     pk = packing.pack_conv(sd, prefix, kind, _lib.PRECISIONS[prec])
     out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
     keep = []
-    _run(dict(kind=kind, mode=m, B=B, slices=2, precision=_lib.PRECISIONS[prec], scat_ptr=_dev(_i32(scat_ptr)), lig_ptr=_dev(_i32(lig_ptr)),
+    _run(dict(kind=kind, mode=m, B=B, slices=3, precision=_lib.PRECISIONS[prec], max_scatter=max(NL) if mode == "p2l" else max(NP), scat_ptr=_dev(_i32(scat_ptr)), lig_ptr=_dev(_i32(lig_ptr)),
               ph_ptr=_dev(_i32(ph_ptr)), x_ptr=_dev(_i32(x_ptr)), gather_tab=_dev(gt), gather_stride=dims["d_in"],
               attr1_tab=_dev(hl), attr1_stride=dims["d_in"], attr2_tab=_dev(hp), attr2_stride=dims["d_in"], attr_swap=0,
               edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]),
@@ -188,7 +188,7 @@ def test_conv_center_and_torsion_kinds(prec):
     pk = packing.pack_conv(sd, "final_conv", 4, _lib.PRECISIONS[prec])
     out = torch.full((B, 12), float("nan")).cuda()
     keep = []
-    _run(dict(kind=4, mode=_lib.EDGES_CENTER, B=B, slices=1, precision=_lib.PRECISIONS[prec], scat_ptr=_dev(_i32(np.arange(B + 1))), lig_ptr=_dev(_i32(lig_ptr)),
+    _run(dict(kind=4, mode=_lib.EDGES_CENTER, B=B, slices=1, precision=_lib.PRECISIONS[prec], max_scatter=1, scat_ptr=_dev(_i32(np.arange(B + 1))), lig_ptr=_dev(_i32(lig_ptr)),
               gather_tab=_dev(hl), gather_stride=100, attr1_tab=_dev(hl), attr1_stride=100, attr2_tab=None, attr2_stride=0,
               attr_swap=0, edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]),
               bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]), out=out, out_stride=12, accumulate=0,
@@ -224,7 +224,7 @@ def test_conv_center_and_torsion_kinds(prec):
     ref = _oracle_conv(sd, "tor_bond_conv", 5, hl[nbr_t], attr, sh45, scat_t, nb)
     pk = packing.pack_conv(sd, "tor_bond_conv", 5, _lib.PRECISIONS[prec])
     out = torch.full((nb, 40), float("nan")).cuda()
-    _run(dict(kind=5, mode=_lib.EDGES_CSR, B=B, slices=1, precision=_lib.PRECISIONS[prec], scat_ptr=_dev(_i32(tor_ptr)), rowptr=_dev(_i32(rowptr)),
+    _run(dict(kind=5, mode=_lib.EDGES_CSR, B=B, slices=1, precision=_lib.PRECISIONS[prec], max_scatter=max(T), scat_ptr=_dev(_i32(tor_ptr)), rowptr=_dev(_i32(rowptr)),
               rowend=_dev(_i32(rowend)), nbr=_dev(_i32(nbr)), edge_scat=_dev(_i32(scat)), gather_tab=_dev(hl), gather_stride=100,
               attr1_tab=_dev(hl), attr1_stride=100, attr2_tab=_dev(hb), attr2_stride=20, attr_swap=1,
               edge_emb=_dev(temb), edge_sh=_dev(sh7), sh_stride=7, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]),
@@ -234,3 +234,15 @@ def test_conv_center_and_torsion_kinds(prec):
     assert torch.isfinite(got).all()
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < TOL[prec], (prec, err)
+
+
+def test_conv_rejects_too_many_nodes_per_workgroup():
+    a = _lib.DpConvArgs()
+    dummy = torch.zeros(16, device="cuda")
+    for f in ("scat_ptr", "gather_tab", "attr1_tab", "attr2_tab", "edge_emb", "edge_sh", "w1p", "w2p", "bn_scale", "bn_shift", "out",
+              "lig_ptr", "ph_ptr", "x_ptr"):
+        setattr(a, f, dummy.data_ptr())
+    a.kind, a.mode, a.B, a.slices, a.precision, a.max_scatter = 0, _lib.EDGES_P2L, 1, 1, _lib.PREC_BF16X6, 79
+    assert _lib.lib().dp_tp_conv(C.byref(a), None) == -3          # DP_E_TOOLARGE: 79 nodes > 32 per workgroup
+    a.max_scatter = 0
+    assert _lib.lib().dp_tp_conv(C.byref(a), None) == -1

@@ -47,6 +47,7 @@ def main():
     args = _lib.DpConvArgs()
     args.kind, args.B, args.slices = a.kind, B, a.slices
     args.precision = _lib.PRECISIONS[a.prec]
+    args.max_scatter = NL if a.mode == "p2l" else NP
     args.mode = _lib.EDGES_P2L if a.mode == "p2l" else _lib.EDGES_L2P
     args.scat_ptr = keep["lig_ptr"].data_ptr() if a.mode == "p2l" else keep["ph_ptr"].data_ptr()
     args.lig_ptr, args.ph_ptr, args.x_ptr = keep["lig_ptr"].data_ptr(), keep["ph_ptr"].data_ptr(), keep["x_ptr"].data_ptr()
