@@ -214,10 +214,11 @@ def test_sampler_trajectory_matches_oracle(ode, prec):
     assert np.quantile(r, 0.9) < 1e-3 or (r < 1e-3).sum() >= len(r) - 1, r
 
 
-@pytest.mark.parametrize("shape", [(20, 5, 79), (80, 25, 32), (3, 0, 4)])
+@pytest.mark.parametrize("shape", [(20, 5, 79), (80, 25, 32), (3, 0, 8)])
 def test_forward_other_baseline_shapes(shape):
     """BASELINE configs[0]-like (20 atoms x 79 phore nodes: 3 workgroup slices per pose), configs[2] (80 atoms, 25 torsions: the
-    32-neighbour cap binds), and a degenerate 3-atom ligand without torsions."""
+    32-neighbour cap binds), and a degenerate 3-atom ligand without torsions (the phore keeps >=1 exclusion sphere: without one
+    the reference feeds d_min = 1e9 into a Linear layer, :912, and overflows)."""
     from diffphore_amd.score_model import TensorProductScoreModel
     from oracle import sampler as osampler
     nl, nt, npn = shape
