@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--poses", type=int, default=512, help="poses per GPU")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3"],
+                    help="arithmetic of the radial-MLP contraction; the headline value uses exact fp32 MFMA")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational bf16x6 pass")
     ap.add_argument("--cpu-poses", type=int, default=40)
     ap.add_argument("--cpu-steps", type=int, default=4)
     a = ap.parse_args()
@@ -109,7 +112,7 @@ def main():
     graphs = synthetic.synthetic_pairs(a.config, n_pairs, shape["n_atoms"], shape["n_tor"], shape["n_phore"],
                                        seed=synthetic.BASE_SEED + a.config + 1000 * rank)
     sd = weights.init_state_dict()
-    model = DeviceModel(sd, cfg, dev)
+    model = DeviceModel(sd, cfg, dev, precision=a.precision)
     if world > 1:
         # the only collective of the job: weights from rank 0 to every GPU over xGMI
         dist.broadcast(model.blob, src=0)
@@ -119,57 +122,75 @@ def main():
     np.random.seed(607201 + rank)
     torch.manual_seed(607201 + rank)
     randomize_position(graphs, False, False, cfg.tr_sigma_max, device=dev)
-    pb = PackedBatch(graphs, dev)
-    eng = Engine(model, pb)
+    pb0 = PackedBatch(graphs, dev)
+    pos0, norm0 = pb0.pos.clone(), pb0.norm.clone()
     S_total = 20
     sched = get_t_schedule(S_total)
     t2s = t_to_sigma_fn(margs)
     gen = torch.Generator(device=dev).manual_seed(607201 + rank)
-    B, nT = pb.B, int(pb.tor_ptr[-1])
+    B, nT = pb0.B, int(pb0.tor_ptr[-1])
     # pre-drawn noise resident in HBM (the reference draws it on the host inside the loop, sampling.py:230-243)
     zs = [(torch.randn(B, 3, device=dev, generator=gen), torch.randn(B, 3, device=dev, generator=gen),
            torch.randn(max(nT, 1), device=dev, generator=gen)) for _ in range(a.warmup + a.steps)]
-    ev = HipEvents(a.steps)
 
-    def step(i, prof_idx=None):
-        t_idx = i % S_total
-        sp = _step_params(t_idx, S_total, sched, sched, sched, t2s, margs, False, False)
-        pb.set_time(float(sched[t_idx]), float(sched[t_idx]), float(sched[t_idx]))
-        w = eng.ws.struct
-        if prof_idx is None:
-            w.prof_start, w.prof_stop = None, None
-        else:
-            s0, s1 = ev.pair(prof_idx)
-            w.prof_start, w.prof_stop, w.prof_layer, w.prof_conv = s0, s1, PROF_LAYER, PROF_CONV
-        z = zs[i]
-        eng.sample_step(sp, z[0], z[1], z[2] if nT else None)
+    def timed_run(mdl):
+        pb = pb0
+        pb.pos.copy_(pos0)
+        pb.norm.copy_(norm0)
+        eng = Engine(mdl, pb)
+        ev = HipEvents(a.steps)
 
-    for i in range(a.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i, prof_idx=i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    bad = int((eng.ws.t["status"] != 0).sum().item())
-    finite = bool(torch.isfinite(pb.pos).all().item())
+        def step(i, prof_idx=None):
+            t_idx = i % S_total
+            sp = _step_params(t_idx, S_total, sched, sched, sched, t2s, margs, False, False)
+            pb.set_time(float(sched[t_idx]), float(sched[t_idx]), float(sched[t_idx]))
+            w = eng.ws.struct
+            if prof_idx is None:
+                w.prof_start, w.prof_stop = None, None
+            else:
+                s0, s1 = ev.pair(prof_idx)
+                w.prof_start, w.prof_stop, w.prof_layer, w.prof_conv = s0, s1, PROF_LAYER, PROF_CONV
+            z = zs[i]
+            eng.sample_step(sp, z[0], z[1], z[2] if nT else None)
 
-    kern_ms = float(np.nanmean([ev.ms(i) for i in range(a.steps)]))
+        for i in range(a.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + i, prof_idx=i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        nbad = int((eng.ws.t["status"] != 0).sum().item())
+        fin = bool(torch.isfinite(pb.pos).all().item())
+        return el, float(np.nanmean([ev.ms(i) for i in range(a.steps)])), nbad, fin
+
+    elapsed, kern_ms, bad, finite = timed_run(model)
+    pb = pb0
+    alt = None
+    if not a.no_alt and a.precision == "f32":
+        alt_model = DeviceModel(sd, cfg, dev, precision="bf16x6")
+        if world > 1:
+            dist.broadcast(alt_model.blob, src=0)
+        el2, k2, bad2, fin2 = timed_run(alt_model)
+        alt = {"precision": "bf16x6 (3-way bf16 operand split, 6 products, fp32 accumulate; passes the same parity tolerances)",
+               "value": B * world * a.steps / el2, "ms_per_step": el2 / a.steps * 1e3, "kernel_ms": k2, "finite": fin2,
+               "kabsch_flagged_poses": bad2}
+
     n_x = int(pb.x_ptr[-1])
     alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
     flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * n_x
-    traffic = MEASURED_TRAFFIC_BYTES if (a.config == 2 and a.poses == 512) else None
+    traffic = MEASURED_TRAFFIC_BYTES if (a.config == 2 and a.poses == 512 and a.precision == "f32") else None
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else float("nan")
 
     if rank == 0:
@@ -181,13 +202,14 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.precision == "f32" else a.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{a.config}]: {B} synthetic lig-phore pairs per GPU "
                                    f"({shape['n_atoms']} atoms, {shape['n_tor']} torsions, {shape['n_phore']} phore nodes), "
                                    f"one reverse-diffusion step per bench step, fp32, random-init weights",
                        "poses_per_gpu": B, "poses_per_sec_at_20_steps": total_poses * a.steps / elapsed / 20.0,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
-                       "kabsch_flagged_poses": bad, "finite": finite},
+                       "kabsch_flagged_poses": bad, "finite": finite, "precision": a.precision,
+                       "alt_precision_run": alt},
             # The dominant kernel generates the per-edge TP weights with fp32 MFMA in registers (they never reach HBM), so it is
             # bound by the fp32 matrix pipe; SURVEY.md 8d asks for both views when the radial MLP is fused into the TP kernel.
             "roofline": {"bound": "mfma", "achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
