@@ -41,7 +41,8 @@ template <int KIND> struct Geo {
   using S = Spec<KIND>;
   static constexpr int K1 = k1_steps<KIND>();
   static constexpr int K1P = k1_steps_pad<KIND>();
-  static constexpr int K2 = k2_steps<KIND>();
+  static constexpr int K2S = k2_steps<KIND>();       // fp32 K-steps actually executed per tile
+  static constexpr int K2 = k2_steps_pad<KIND>();    // padded to whole dwordx4 operand loads
   static constexpr int NT = n_tiles<KIND>();
   static constexpr int NTRI = n_triples<KIND>();
   static constexpr int ABLK = S::N_ATTR / 20;        // attr blocks of 20 (edge emb, attr1, attr2)
@@ -62,14 +63,15 @@ template <int KIND> void pack_w1(const float* fc0_w, const float* fc0_b, float* 
   for (int t = 0; t < 2; ++t)
     for (int s = 0; s < G::K1; ++s)
       for (int lane = 0; lane < 64; ++lane) {
-        int row = t * 32 + (lane & 31), half = lane >> 5;
+        const int row = t * 32 + (lane & 31), half = lane >> 5;
+        const int unit = unit_of_row<KIND>(row);
         float v = 0.f;
         if (s < S::N_ATTR / 2) {
           int k = (s / 10) * 20 + half * 10 + (s % 10);
-          if (row < S::HID) v = fc0_w[row * S::N_ATTR + k];
+          if (unit >= 0 && unit < S::HID) v = fc0_w[unit * S::N_ATTR + k];
         } else if (half == 0) {                       // bias step: attr value 1.0
-          if (row < S::HID) v = fc0_b[row];
-          else if (row == S::HID) v = 1.f;            // constant-one hidden unit that carries fc.3's bias through GEMM2
+          if (unit >= 0 && unit < S::HID) v = fc0_b[unit];
+          else if (unit == S::HID) v = 1.f;           // constant-one hidden unit that carries fc.3's bias through GEMM2
         }
         // layout [t][s/4][lane][s%4]  -> one dwordx4 per lane per 4 MFMAs
         w1p[((t * (G::K1P / 4) + s / 4) * 64 + lane) * 4 + (s & 3)] = v;
@@ -93,9 +95,9 @@ template <int KIND> void pack_w2(const float* fc3_w, const float* fc3_b, float* 
           int u = chalf * (p.mul_in / 2) + tr.q;
           int widx = p.w_off + u * p.mul_out + tr.w;
           double scale = __builtin_sqrt((double)(2 * (d_out_of(p.ztype) == 3 ? 1 : 0) + 1) / (double)p.fan_in) * cg_const(p.ztype);
-          int hrow = hid_row(sg, half);
-          if (hrow < S::HID) v = (float)(scale * (double)fc3_w[widx * S::HID + hrow]);
-          else if (hrow == S::HID) v = (float)(scale * (double)fc3_b[widx]);
+          const int unit = unit_of_row<KIND>(hid_row(sg, half));
+          if (unit >= 0 && unit < S::HID) v = (float)(scale * (double)fc3_w[widx * S::HID + unit]);
+          else if (unit == S::HID) v = (float)(scale * (double)fc3_b[widx]);
         }
         w2p[((tile * (G::K2 / 4) + sg / 4) * 64 + lane) * 4 + (sg & 3)] = v;
       }
@@ -191,10 +193,10 @@ __device__ __forceinline__ f32x16 mfma_tile(WTile<KIND>& w, gptr4 wp_next, int l
   f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < G::K2 / 4; ++g) {
-    D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].x, hid[4 * g + 0], D, 0, 0, 0);
-    D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].y, hid[4 * g + 1], D, 0, 0, 0);
-    D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].z, hid[4 * g + 2], D, 0, 0, 0);
-    D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].w, hid[4 * g + 3], D, 0, 0, 0);
+    if (4 * g + 0 < G::K2S) D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].x, hid[4 * g + 0], D, 0, 0, 0);
+    if (4 * g + 1 < G::K2S) D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].y, hid[4 * g + 1], D, 0, 0, 0);
+    if (4 * g + 2 < G::K2S) D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].z, hid[4 * g + 2], D, 0, 0, 0);
+    if (4 * g + 3 < G::K2S) D = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[g].w, hid[4 * g + 3], D, 0, 0, 0);
     if constexpr (PREFETCH) w.v[g] = wp_next[g * 64 + lane];
   }
   return D;
@@ -511,7 +513,7 @@ typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
 constexpr int WAVES_B = 4;        // two such workgroups share a CU: their waves are not barrier-coupled, so one hides the other
 constexpr int CHUNK_B = WAVES_B * 32;
 
-template <int KIND> constexpr int NKB = (Spec<KIND>::HID + 1 + 15) / 16;            // 16-wide K blocks incl. the bias row
+template <int KIND> constexpr int NKB = (Spec<KIND>::HID == 60 ? 62 : Spec<KIND>::HID + 1 + 15) / 16 + (Spec<KIND>::HID == 60 ? 1 : 0);   // 16-row K blocks covering every non-padding row
 template <int KIND, int NS> constexpr int TILE_QUADS = (NKB<KIND> * NS * 64 + 255) / 256 * 256;   // uint4 per packed tile, padded to whole 4-wave DMA rounds
 // hidden row held by lane half `half` at position j (0..7) of K block b: the D-fragment row of GEMM1 register 8*(b&1)+j, tile b>>1
 constexpr int hid_row_b(int b, int half, int j) {
@@ -543,10 +545,10 @@ template <int KIND, int NS> void pack_w2_bf16(const float* fc3_w, const float* f
         const int widx = p.w_off + u * p.mul_out + tr.w;
         const double scale = __builtin_sqrt((double)(2 * (d_out_of(p.ztype) == 3 ? 1 : 0) + 1) / (double)p.fan_in) * cg_const(p.ztype);
         for (int j = 0; j < 8; ++j) {
-          const int hrow = hid_row_b(b, half, j);
+          const int unit = unit_of_row<KIND>(hid_row_b(b, half, j));
           float v = 0.f;
-          if (hrow < S::HID) v = (float)(scale * (double)fc3_w[widx * S::HID + hrow]);
-          else if (hrow == S::HID) v = (float)(scale * (double)fc3_b[widx]);
+          if (unit >= 0 && unit < S::HID) v = (float)(scale * (double)fc3_w[widx * S::HID + unit]);
+          else if (unit == S::HID) v = (float)(scale * (double)fc3_b[widx]);
           float rem = v;
           for (int s = 0; s < NS; ++s) {
             const unsigned short h = f32_to_bf16_rne(rem);

@@ -171,11 +171,27 @@ template <int KIND> constexpr int k1_steps() { return Spec<KIND>::N_ATTR / 2 + 1
 template <int KIND> constexpr int k1_steps_pad() { return (k1_steps<KIND>() + 3) / 4 * 4; }
 // hidden rows live in two 32-row MFMA D tiles; K-step sigma of GEMM2 pairs rows rho(sigma) (lane half 0) and rho+4 (half 1)
 constexpr int hid_row(int sigma, int half) { return 32 * (sigma >> 4) + ((sigma & 15) & 3) + 8 * ((sigma & 15) >> 2) + 4 * half; }
-template <int KIND> constexpr int k2_steps() {   // number of sigma steps that touch a real hidden row or the bias row (index HID)
+// Which hidden unit sits in D-tile row `row`:  0..HID-1 = unit, HID = the constant-one unit that carries fc.3's bias, -1 = padding.
+// For HID = 60 unit 59 is moved to row 61 so that rows 59 and 63 - the pair consumed by K-step 31 - are both padding and the
+// step can be dropped (31 instead of 32 fp32 MFMAs per tile).
+template <int KIND> constexpr int unit_of_row(int row) {
+  constexpr int H = Spec<KIND>::HID;
+  if (H == 60) {
+    if (row < 59) return row;
+    if (row == 60) return H;
+    if (row == 61) return 59;
+    return -1;
+  }
+  if (row < H) return row;
+  if (row == H) return H;
+  return -1;
+}
+template <int KIND> constexpr int k2_steps() {   // number of leading sigma steps that touch a non-padding row
   int last = 0;
   for (int s = 0; s < 32; ++s)
-    if (hid_row(s, 0) <= Spec<KIND>::HID || hid_row(s, 1) <= Spec<KIND>::HID) last = s + 1;
-  return (last + 3) / 4 * 4;
+    if (unit_of_row<KIND>(hid_row(s, 0)) >= 0 || unit_of_row<KIND>(hid_row(s, 1)) >= 0) last = s + 1;
+  return last;
 }
+template <int KIND> constexpr int k2_steps_pad() { return (k2_steps<KIND>() + 3) / 4 * 4; }
 
 }  // namespace dp
