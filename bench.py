@@ -93,12 +93,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if local >= ndev and os.environ.get("DIFFPHORE_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+    local = local % max(ndev, 1)                            # (gloo smoke runs may put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # RCCL on ROCm
+        backend = os.environ.get("DIFFPHORE_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from diffphore_amd.engine import DeviceModel, Engine, PackedBatch
     from diffphore_amd.sampling import _step_params
