@@ -57,16 +57,33 @@ def _draw_reference_order(N, T_per_pose: np.ndarray, batch_size: int):
 def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
                    no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
                    confidence_model_args=None, batch_size=20, no_final_step_noise=False, noise=None, engine: Optional[Engine] = None,
-                   write_back=True):
+                   write_back=True, max_poses: int = 8192):
     if confidence_model is not None:
         raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
     N = len(data_list)
+    if N > max_poses and engine is None:
+        # Device-batch the pose list.  Poses are independent, so results are unchanged; with noise=None the global RNG stream
+        # is consumed chunk-major instead of step-major (the reference never runs more than `--sample_per_complex` poses at once).
+        if visualization_list is not None:
+            raise NotImplementedError("visualization_list with more than max_poses poses")
+        t_off = 0
+        for lo in range(0, N, max_poses):
+            part = data_list[lo:lo + max_poses]
+            nt_part = sum(int(torch.as_tensor(g["ligand"].edge_mask).sum()) for g in part)
+            sub = None if noise is None else {"tr": noise["tr"][:, lo:lo + max_poses], "rot": noise["rot"][:, lo:lo + max_poses],
+                                              "tor": noise["tor"][:, t_off:t_off + nt_part]}
+            sampling_phore(part, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
+                           no_random=no_random, ode=ode, batch_size=batch_size, no_final_step_noise=no_final_step_noise, noise=sub,
+                           write_back=write_back, max_poses=max_poses)
+            t_off += nt_part
+        return data_list, None
     eng = engine if engine is not None else Engine(model.device_model, PackedBatch(data_list, device))
     pb = eng.pb
     dev = pb.device
     if engine is not None:   # caller-managed engine: refresh the diffusion state from data_list
         pb.set_state(torch.cat([g["ligand"].pos for g in data_list]), torch.cat([g["ligand"].norm.reshape(-1, 33) for g in data_list]))
     no_torsion = bool(getattr(model_args, "no_torsion", False))
+    keep_update = bool(getattr(model_args, "keep_update", False))
     for t_idx in range(inference_steps):
         last = t_idx == inference_steps - 1
         zero = no_random or (no_final_step_noise and last)
@@ -82,6 +99,8 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             z_rot = z_rot.to(dev, torch.float32).contiguous()
             z_tor = z_tor.to(dev, torch.float32).contiguous() if (not no_torsion and z_tor.numel()) else None
         eng.sample_step(sp, z_tr, z_rot, z_tor)
+        if keep_update:
+            _record_updates(data_list, eng, sp, z_tr, z_rot, z_tor, no_torsion)
         if visualization_list is not None:
             pos = pb.pos.cpu()
             for idx, vis in enumerate(visualization_list):
@@ -98,6 +117,25 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             g["ligand"].pos = pos[lo:hi].clone()
             g["ligand"].norm = norm[lo:hi].clone()
     return data_list, None
+
+
+def _record_updates(data_list, eng, sp, z_tr, z_rot, z_tor, no_torsion):
+    """model_args.keep_update bookkeeping of modify_conformer (diffusion_utils.py:71-77): per-step perturbations and poses."""
+    ws, pb = eng.ws, eng.pb
+    tr = sp.tr_c1 * ws.tr + (sp.tr_c2 * z_tr if z_tr is not None else 0)
+    rot = sp.rot_c1 * ws.rot + (sp.rot_c2 * z_rot if z_rot is not None else 0)
+    tor = None
+    if not no_torsion and ws.n_tor:
+        tor = sp.tor_c1 * ws.tor[:ws.n_tor] + (sp.tor_c2 * z_tor[:ws.n_tor] if z_tor is not None else 0)
+        tor = tor.cpu().numpy()
+    tr, rot, pos = tr.cpu().numpy(), rot.cpu().numpy(), pb.pos.cpu().numpy()
+    for i, g in enumerate(data_list):
+        lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
+        t0, t1 = int(pb.tor_ptr[i]), int(pb.tor_ptr[i + 1])
+        for name, val in (("rvs_rot_update", rot[i]), ("rvs_tr_update", tr[i:i + 1]),
+                          ("rvs_tor_update", tor[t0:t1] if tor is not None else None), ("docked_poses", pos[lo:hi].copy())):
+            prev = getattr(g, name) if name in g else []
+            setattr(g, name, prev + [val])
 
 
 def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, keep_update=False, device="cuda", draws=None):

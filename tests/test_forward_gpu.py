@@ -234,3 +234,28 @@ def test_forward_other_baseline_shapes(shape):
         assert _rel(tr, tr_o) < 2e-4 and _rel(rot, rot_o) < 2e-4, (prec, _rel(tr, tr_o), _rel(rot, rot_o))
         if tor_o.numel():
             assert _rel(tor, tor_o) < 2e-4, (prec, _rel(tor, tor_o))
+
+
+def test_sampler_chunking_and_keep_update():
+    """Device-batching the pose list (max_poses) must not change any pose; keep_update records what modify_conformer records."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+    gs = synthetic.synthetic_pairs(99, 7, (10, 18), (0, 4), (8, 16))
+    S = 3
+    sched = get_t_schedule(S)
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False, keep_update=True)
+    gen = torch.Generator().manual_seed(3)
+    nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
+    noise = dict(tr=torch.randn(S, len(gs), 3, generator=gen), rot=torch.randn(S, len(gs), 3, generator=gen),
+                 tor=torch.randn(S, nT, generator=gen))
+    sd = weights.init_state_dict()
+    m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+    a, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise)
+    b, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise, max_poses=3)
+    for x, y in zip(a, b):
+        assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
+        assert len(x.docked_poses) == S and len(x.rvs_tr_update) == S and x.rvs_tr_update[0].shape == (1, 3)
+        np.testing.assert_array_equal(x.docked_poses[-1], x["ligand"].pos.numpy())
