@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void conformer_update_kernel(DpBatch b, DpStep
     }
   }
   __syncthreads();
-  if (tid == 0 && status) status[p] = s_flag;
+  if (tid == 0 && status && s_flag) status[p] |= s_flag;     // sticky across the steps of a run; the caller zeroes it
 }
 
 }  // namespace dp
