@@ -213,8 +213,12 @@ struct Stage {
     if constexpr (TILE < TEND) {
       wp += (G::K2 / 4) * 64;
       asm volatile("" : "+s"(wp));
-      const f32x16 D = mfma_tile<KIND, (TILE + 1 < TEND)>(w, wp, lane, hid);
+      const f32x16 D = mfma_tile<KIND, (TILE + 1 < TEND) && DP_ABLATE != 13>(w, wp, lane, hid);
+#if DP_ABLATE == 11
+      for (int r_ = 0; r_ < 16; ++r_) asm volatile("" ::"v"(D[r_]));
+#else
       contract_tile<KIND, TILE>(D, xr, sh, M, acc, std::make_integer_sequence<int, 16>{});
+#endif
       __builtin_amdgcn_sched_barrier(0);
       Stage<KIND, TILE + 1, TEND>::run(wp, lane, w, hid, xr, sh, M, acc);
     }
@@ -492,7 +496,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
       if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
     }
     __syncthreads();
+#if DP_ABLATE != 16
     segmented_sum<KIND, CHUNK>(s_msg, s_node, s_acc, min(CHUNK, r.k_end - kc));
+#endif
   }
   __syncthreads();
   conv_epilogue<KIND, WAVES * 64>(a, r, s_acc);
