@@ -31,7 +31,7 @@ def test_toy_phore_graph():
     ei = set(map(tuple, g["edge_index"].T.tolist()))
     assert {(0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)} <= ei      # features fully connected
     assert (3, 0) in ei and (3, 1) in ei and (3, 2) in ei and (3, 4) not in ei   # EX -> everything within 5 A
-    assert [e for e in ei if e[0] == 4] == [(4, 3)]                      # isolated EX: nearest-neighbour fallback
+    assert [e for e in ei if e[0] == 4] == [(4, 2)]                      # isolated EX: nearest-neighbour fallback (node 2 is closest)
     # plugs straight into the complex builder used for the synthetic workloads
     lig = synthetic.make_ligand(np.random.default_rng(0), 12, 2)
     c = synthetic.make_complex(lig, g)
