@@ -109,3 +109,14 @@ def test_step_scalars_follow_the_reference_formulas():
     ode = _step_params(3, 20, sched, sched, sched, t2s, args, True, False)
     sde = _step_params(3, 20, sched, sched, sched, t2s, args, False, False)
     assert abs(ode.tr_c1 - 0.5 * sde.tr_c1) < 1e-7 and ode.tr_c2 == 0.0
+
+
+def test_pose_limits_are_enforced_before_any_launch():
+    """>256 atoms / >128 torsions per pose are rejected by the packer (kernel LDS limits), on any machine."""
+    from diffphore_amd.engine import PackedBatch
+    g = synthetic.synthetic_pairs(5, 1, 12, 2, 10)[0]
+    big = copy.deepcopy(g)
+    n = 257
+    big["ligand"].pos = torch.zeros(n, 3)
+    with pytest.raises(ValueError):
+        PackedBatch([big], "cpu")
