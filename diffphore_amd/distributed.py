@@ -60,3 +60,41 @@ def gather_positions(local_idx: Sequence[int], local_pos: Sequence[torch.Tensor]
         for i, p in zip(idx, pos):
             out[i] = p
     return out
+
+
+def fit_complexes(graphs: Sequence, model, args, samples_per_complex: int = 40, device="cuda", batch_size: int = 20,
+                  max_poses: int = 8192):
+    """The sampler-facing part of `inference.py::fit` (:139-228) on this rank's share of `graphs`:
+
+        data_list = [deepcopy(graph) x N] ; randomize_position(...) ; sampling_phore(...) ; collect ligand_pos
+
+    for every complex, but with ALL complexes x samples of the rank batched into device-resident launches instead of one
+    40-pose call per complex.  Returns (indices of the complexes this rank owns, list of [N, n_atoms, 3] arrays in that order).
+    Scoring / SDF writing (AncPhore, RDKit) stay with the caller.  `args` needs the reference's fields: inference_steps,
+    tr/rot/tor_sigma_min/max, no_torsion, no_random, ode, no_final_step_noise (missing ones default like inference.py:54-96).
+    """
+    import copy
+
+    import torch.distributed as dist
+
+    from .diffusion import get_t_schedule, t_to_sigma_fn
+    from .sampling import randomize_position, sampling_phore
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    idx, mine = shard_poses(graphs, rank, world)
+    steps = int(getattr(args, "inference_steps", 20))
+    sched = get_t_schedule(steps)
+    out = []
+    # keep whole complexes together in a device batch
+    per = max(1, max_poses // samples_per_complex)
+    for lo in range(0, len(mine), per):
+        block = mine[lo:lo + per]
+        data_list = [copy.deepcopy(g) for g in block for _ in range(samples_per_complex)]
+        randomize_position(data_list, getattr(args, "no_torsion", False), False, args.tr_sigma_max, device=device)
+        sampling_phore(data_list, model, steps, sched, sched, sched, device, t_to_sigma_fn(args), args,
+                       no_random=getattr(args, "no_random", False), ode=getattr(args, "ode", False), batch_size=batch_size,
+                       no_final_step_noise=getattr(args, "no_final_step_noise", False), max_poses=max(max_poses, len(data_list)))
+        for c in range(len(block)):
+            poses = data_list[c * samples_per_complex:(c + 1) * samples_per_complex]
+            out.append(torch.stack([p["ligand"].pos for p in poses]).numpy())
+    return idx, out

@@ -259,3 +259,27 @@ def test_sampler_chunking_and_keep_update():
         assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
         assert len(x.docked_poses) == S and len(x.rvs_tr_update) == S and x.rvs_tr_update[0].shape == (1, 3)
         np.testing.assert_array_equal(x.docked_poses[-1], x["ligand"].pos.numpy())
+
+
+def test_fit_complexes_driver_single_rank():
+    """inference.py::fit's sampler-facing loop: N samples per complex, randomised start, poses returned per complex."""
+    from diffphore_amd.distributed import fit_complexes
+    from diffphore_amd.score_model import TensorProductScoreModel
+    gs = synthetic.synthetic_pairs(120, 3, (12, 20), (1, 4), (10, 20))
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False, inference_steps=4)
+    m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+    torch.manual_seed(0)
+    np.random.seed(0)
+    idx, poses = fit_complexes(gs, m, args, samples_per_complex=5, max_poses=10)
+    assert idx == [0, 1, 2] and len(poses) == 3
+    for g, p in zip(gs, poses):
+        assert p.shape == (5, g["ligand"].pos.shape[0], 3) and np.isfinite(p).all()
+        # samples of one complex differ (random start + noise) but keep the bonded geometry: torsion moves preserve bond lengths
+        ei = g["ligand", "ligand"].edge_index.numpy()
+        d0 = np.linalg.norm(g["ligand"].pos.numpy()[ei[0]] - g["ligand"].pos.numpy()[ei[1]], axis=1)
+        for s in range(5):
+            ds = np.linalg.norm(p[s][ei[0]] - p[s][ei[1]], axis=1)
+            np.testing.assert_allclose(ds, d0, atol=2e-4)
+        assert np.abs(p[0] - p[1]).max() > 1e-2
