@@ -28,6 +28,25 @@
 #ifndef DP_ABLATE
 #define DP_ABLATE 0
 #endif
+#ifdef DP_PROF   // cycle-stamp breakdown of the bf16 kernel (ablation builds only; tools/bench_conv.py --prof)
+__device__ unsigned long long dp_prof[16];
+__shared__ unsigned long long s_prof_prev;
+__device__ __forceinline__ void prof_mark(int seg) {
+  if (threadIdx.x == 0) {
+    const unsigned long long now = clock64();
+    if (seg >= 0) atomicAdd(&dp_prof[seg], now - s_prof_prev);
+    s_prof_prev = now;
+  }
+}
+#define PROF_MARK(seg) prof_mark(seg)
+extern "C" int dp_debug_prof(unsigned long long* host16, int reset) {
+  if (host16 && hipMemcpyFromSymbol(host16, HIP_SYMBOL(dp_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(dp_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define PROF_MARK(seg)
+#endif
 
 namespace dp {
 
@@ -225,14 +244,29 @@ struct Stage {
   }
 };
 
-// cross-half sum of one phase's accumulators + staging into the LDS message row at the real channel positions
-template <int KIND, int PH, int... CI>
-__device__ __forceinline__ void stage_phase(float (&acc)[NACC<KIND>], float* row, int half, std::integer_sequence<int, CI...>) {
+// phase-local accumulator index -> output channel
+template <int KIND, int PH> struct ChanLut {
+  static constexpr int N = n_acc_phase<KIND>(PH) > 0 ? n_acc_phase<KIND>(PH) : 1;
+  int v[N];
+  constexpr ChanLut() : v{} {
+    for (int i = 0; i < n_acc_phase<KIND>(PH); ++i) v[i] = channel_of<KIND>(PH, i);
+  }
+};
+template <int KIND, int PH> __device__ constexpr ChanLut<KIND, PH> kChanLut{};
+
+// Cross-half sum of one phase's accumulators + staging into the LDS message row (column COL0 + phase-local index).
+// The two lane halves hold partial sums over disjoint in-channels of the SAME edge.  v_permlane32_swap exchanges the upper half of
+// one register with the lower half of another, so for an accumulator pair (a, b) one swap + one add leaves total(a) in the lower
+// half and total(b) in the upper half; each half then stores its own column: NA/2 swaps, adds and ds_write_b32, no LDS permutes.
+template <int KIND, int PH, int COL0, int... PI>
+__device__ __forceinline__ void stage_phase(float (&acc)[NACC<KIND>], float* row, int half, std::integer_sequence<int, PI...>) {
+  static_assert(n_acc_phase<KIND>(PH) % 2 == 0, "accumulators are staged in pairs");
+  float* dst = row + COL0 + half;
   (
       [&] {
-        constexpr int ch = channel_of<KIND>(PH, CI);
-        const float other = __shfl_xor(acc[CI], 32, 64);
-        if ((CI & 1) == half) row[ch] = acc[CI] + other;   // halves split the stores
+        float x = acc[2 * PI], y = acc[2 * PI + 1];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));   // x = [x.lo, y.lo], y = [x.hi, y.hi]
+        dst[2 * PI] = x + y;
       }(),
       ...);
 }
@@ -397,25 +431,63 @@ __device__ __forceinline__ void gemm1_hidden(const DpConvArgs& a, const EdgeRef&
   }
 }
 
-// ordered (deterministic) segmented sum of the chunk's staged messages into the LDS node accumulators
-template <int KIND, int CH>
-__device__ __forceinline__ void segmented_sum(const float* s_msg, const int* s_node, float* s_acc, int nedge) {
-  using S = Spec<KIND>;
-  using G = Geo<KIND>;
-  const int tid = threadIdx.x;
-  if (tid < S::D_OUT) {
+// Deterministic segmented sum of staged messages into the LDS node accumulators, one wave per 32-edge tile.
+//   Every wave reduces the 32 message rows IT staged (so no workgroup barrier sits between staging and reduction): lane l owns
+//   message column l (+64 per pass) and walks the 32 edges; the scatter node of edge ei lives in lane ei's register and is
+//   broadcast with v_readlane, so segment boundaries are scalar branches.  A node that starts strictly inside the tile is
+//   added to s_acc directly (exactly one wave can do that for a given node); the tile's FIRST segment may continue a node begun by
+//   an earlier wave, so its sum is parked in the wave's own (now dead) row 0 and merged by wave 0 after a barrier, in wave
+//   order (merge_wave_partials).  The summation tree depends only on the pose's own edge list: reruns are bit-identical.
+template <int D_OUT, int NCOL, typename ChanFn>
+__device__ __forceinline__ void wave_segsum(float* rows, int ld, int lane, int scat_local, float* s_acc, int* s_pnode_w, ChanFn chan) {
+  const int first_node = __builtin_amdgcn_readlane(scat_local, 0);
+  if (lane == 0) *s_pnode_w = first_node;
+#pragma unroll
+  for (int p = 0; p < (NCOL + 63) / 64; ++p) {
+    const int col = lane + 64 * p;
+    const bool active = col < NCOL;
+    const int ch = active ? chan(col) : 0;
+    float v[32];
+#pragma unroll
+    for (int ei = 0; ei < 32; ++ei) v[ei] = active ? rows[ei * ld + col] : 0.f;
+    int cur = first_node;
+    bool first = true;
     float run = 0.f;
-    int cur = -1;
-    for (int ei = 0; ei < nedge; ++ei) {
-      const int n = s_node[ei];
-      if (n != cur) {
-        if (cur >= 0) s_acc[cur * S::D_OUT + tid] += run;
+#pragma unroll
+    for (int ei = 0; ei < 32; ++ei) {
+      const int n = __builtin_amdgcn_readlane(scat_local, ei);
+      if (n != cur) {                                    // uniform
+        if (cur >= 0 && active) {
+          if (first) rows[col] = run;
+          else s_acc[cur * D_OUT + ch] += run;
+        }
+        first = false;
         run = 0.f;
         cur = n;
       }
-      if (n >= 0) run += s_msg[ei * G::MSG_LD + tid];
+      if (n >= 0) run += v[ei];                          // padding edges (-1) only trail the pose's edge list
     }
-    if (cur >= 0) s_acc[cur * S::D_OUT + tid] += run;
+    if (cur >= 0 && active) {
+      if (first) rows[col] = run;
+      else s_acc[cur * D_OUT + ch] += run;
+    }
+  }
+}
+
+// second half of the above: wave 0 folds the NW parked first-segment sums into s_acc in wave order (call after a barrier)
+template <int D_OUT, int NCOL, int NW, typename ChanFn>
+__device__ __forceinline__ void merge_wave_partials(const float* s_msg, int ld, int lane, const int* s_pnode, float* s_acc, ChanFn chan) {
+#pragma unroll
+  for (int p = 0; p < (NCOL + 63) / 64; ++p) {
+    const int col = lane + 64 * p;
+    if (col < NCOL) {
+      const int ch = chan(col);
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const int node = s_pnode[q];
+        if (node >= 0) s_acc[node * D_OUT + ch] += s_msg[(size_t)q * 32 * ld + col];
+      }
+    }
   }
 }
 
@@ -451,12 +523,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
   using G = Geo<KIND>;
   __shared__ float s_msg[CHUNK * G::MSG_LD];
   __shared__ float s_acc[MAX_NODES * S::D_OUT];
-  __shared__ int s_node[CHUNK];
+  __shared__ int s_pnode[WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
   const WgRange r = wg_range(a);
   if (r.n_loc <= 0) return;
   for (int i = tid; i < r.n_loc * S::D_OUT; i += WAVES * 64) s_acc[i] = 0.f;
+  constexpr int NA0_ = n_acc_phase<KIND>(0);
+  const auto chan = [](int c) { return c < NA0_ ? kChanLut<KIND, 0>.v[c < NA0_ ? c : 0] : kChanLut<KIND, 1>.v[c < NA0_ ? 0 : c - NA0_]; };
 
   for (int kc = r.k_begin; kc < r.k_end; kc += CHUNK) {
     const EdgeRef e = decode_edge(a, r, kc + wave * 32 + ecol);
@@ -465,7 +539,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
     gemm1_hidden<KIND>(a, e, lane, hid);
 
     // ---- GEMM2 tiles + CG contraction, phase 0 (scalar outputs) then phase 1 (vector outputs) ----------------------
-    __syncthreads();                              // previous chunk's segmented sum has finished reading s_msg
+    __syncthreads();                              // previous chunk's partial sums have been merged (first pass: s_acc zeroed)
     float* row = s_msg + (size_t)(wave * 32 + ecol) * G::MSG_LD;
     {
       constexpr int NT0 = n_tiles_phase<KIND>(0), NT1 = n_tiles_phase<KIND>(1);
@@ -479,7 +553,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
         load_wtile<KIND>(wp, lane, w0);
         __builtin_amdgcn_sched_barrier(0);
         Stage<KIND, 0, NT0>::run(wp, lane, w0, hid, xr, sh, M, acc);
-        stage_phase<KIND, 0>(acc, row, half, std::make_integer_sequence<int, NA0>{});
+        stage_phase<KIND, 0, 0>(acc, row, half, std::make_integer_sequence<int, NA0 / 2>{});
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (NT1 > 0) {
@@ -491,13 +565,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
         load_wtile<KIND>(wp, lane, w0);
         __builtin_amdgcn_sched_barrier(0);
         Stage<KIND, NT0, NT0 + NT1>::run(wp, lane, w0, hid, xr, sh, M, acc);
-        stage_phase<KIND, 1>(acc, row, half, std::make_integer_sequence<int, NA1>{});
+        stage_phase<KIND, 1, NA0>(acc, row, half, std::make_integer_sequence<int, NA1 / 2>{});
       }
-      if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
     }
-    __syncthreads();
 #if DP_ABLATE != 16
-    segmented_sum<KIND, CHUNK>(s_msg, s_node, s_acc, min(CHUNK, r.k_end - kc));
+    wave_segsum<S::D_OUT, S::D_OUT>(s_msg + (size_t)wave * 32 * G::MSG_LD, G::MSG_LD, lane, e.scat_local, s_acc, &s_pnode[wave], chan);
+    __syncthreads();
+    if (wave == 0) merge_wave_partials<S::D_OUT, S::D_OUT, WAVES>(s_msg, G::MSG_LD, lane, s_pnode, s_acc, chan);
 #endif
   }
   __syncthreads();
@@ -601,49 +675,6 @@ typedef const __attribute__((address_space(1))) vu4* gptrq;
 template <int NS> constexpr int KT = 1;
 template <int KIND> constexpr int MSG_LD_B = (n_acc_phase<KIND>(0) > n_acc_phase<KIND>(1) ? n_acc_phase<KIND>(0) : n_acc_phase<KIND>(1)) + 1;
 
-template <int KIND, int PH> struct ChanLut {
-  static constexpr int N = n_acc_phase<KIND>(PH) > 0 ? n_acc_phase<KIND>(PH) : 1;
-  int v[N];
-  constexpr ChanLut() : v{} {
-    for (int i = 0; i < n_acc_phase<KIND>(PH); ++i) v[i] = channel_of<KIND>(PH, i);
-  }
-};
-template <int KIND, int PH> __device__ constexpr ChanLut<KIND, PH> kChanLut{};
-
-// cross-half sum of one phase's accumulators, staged COMPACTLY (phase-local channel index) into the LDS message row
-template <int KIND, int PH, int... CI>
-__device__ __forceinline__ void stage_phase_compact(float (&acc)[NACC<KIND>], float* row, int half, std::integer_sequence<int, CI...>) {
-  (
-      [&] {
-        const float other = __shfl_xor(acc[CI], 32, 64);
-        if ((CI & 1) == half) row[CI] = acc[CI] + other;
-      }(),
-      ...);
-}
-
-// ordered segmented sum of one phase's staged messages
-template <int KIND, int PH>
-__device__ __forceinline__ void segmented_sum_phase(const float* s_msg, const int* s_node, float* s_acc, int nedge) {
-  using S = Spec<KIND>;
-  constexpr int NA = n_acc_phase<KIND>(PH);
-  const int tid = threadIdx.x;
-  if (tid < NA) {
-    const int ch = kChanLut<KIND, PH>.v[tid];
-    float run = 0.f;
-    int cur = -1;
-    for (int ei = 0; ei < nedge; ++ei) {
-      const int n = s_node[ei];
-      if (n != cur) {
-        if (cur >= 0) s_acc[cur * S::D_OUT + ch] += run;
-        run = 0.f;
-        cur = n;
-      }
-      if (n >= 0) run += s_msg[ei * MSG_LD_B<KIND> + tid];
-    }
-    if (cur >= 0) s_acc[cur * S::D_OUT + ch] += run;
-  }
-}
-
 typedef __attribute__((address_space(3))) vu4* lptrq;
 constexpr int MAX_NODES_B = 32;                                   // LDS budget: two workgroups per CU
 template <int NS> constexpr int RING = NS == 3 ? 3 : 4;           // weight-tile ring depth (tiles in flight = RING-1)
@@ -659,6 +690,63 @@ __device__ __forceinline__ void dma_tile(gptrq src_tile, vu4* slot, int wave, in
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// One tile's operand stream: NKB K-blocks x NS weight splits, each a 1-KiB lane-contiguous ds_read_b128.  Split s of block b+1
+// is requested as soon as the last MFMA that consumes split s of block b has been issued, so NS reads stay in flight behind the
+// matrix pipe with only NS operand registers.  The reads are inline asm (see StageB) and therefore waited for by hand:
+// LDS returns in order, so "at most NS-1 outstanding" == "the oldest request has landed".
+__device__ __forceinline__ void lds_read_q(bf16x8& dst, unsigned addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+template <int N> __device__ __forceinline__ void lds_landed(bf16x8& w) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(N)); }
+
+template <int KIND, int NS, int B>
+struct OperandPipe {
+  static __device__ __forceinline__ void run(unsigned la, bf16x8 (&W)[NS], const HidB<KIND, NS>& hb, f32x16& D) {
+    constexpr int NB = NKB<KIND>;
+    if constexpr (B < NB) {
+      constexpr bool more = B + 1 < NB;
+      if constexpr (B == 0) {
+#pragma unroll
+        for (int s = NS - 1; s >= 0; --s) lds_read_q(W[s], la, s * 1024);      // request order = consumption order: last split first
+      }
+      // smallest cross terms first; a split's register is re-requested right after its last use
+      if constexpr (NS == 3) {
+        lds_landed<NS - 1>(W[2]);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[B][0], D, 0, 0, 0);
+        bf16x8 n2;
+        if constexpr (more) lds_read_q(n2, la, ((B + 1) * NS + 2) * 1024);
+        lds_landed<more ? NS - 1 : 1>(W[1]);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][1], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][0], D, 0, 0, 0);
+        bf16x8 n1;
+        if constexpr (more) lds_read_q(n1, la, ((B + 1) * NS + 1) * 1024);
+        lds_landed<more ? NS - 1 : 0>(W[0]);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][2], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][1], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][0], D, 0, 0, 0);
+        if constexpr (more) {
+          lds_read_q(W[0], la, ((B + 1) * NS + 0) * 1024);
+          W[2] = n2;
+          W[1] = n1;
+        }
+      } else {
+        lds_landed<NS - 1>(W[1]);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][0], D, 0, 0, 0);
+        bf16x8 n1;
+        if constexpr (more) lds_read_q(n1, la, ((B + 1) * NS + 1) * 1024);
+        lds_landed<more ? NS - 1 : 0>(W[0]);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][1], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][0], D, 0, 0, 0);
+        if constexpr (more) {
+          lds_read_q(W[0], la, ((B + 1) * NS + 0) * 1024);
+          W[1] = n1;
+        }
+      }
+      OperandPipe<KIND, NS, B + 1>::run(la, W, hb, D);
+    }
+  }
+};
+
 // Stage TILE of the split-bf16 pipeline.  The packed weights stream L2 -> LDS through a RING-deep ring filled by LDS-DMA
 // RING-1 tiles ahead (an L2 round trip under load is ~2k cycles, longer than one bf16 tile), so a tile costs:
 //   issue DMA(tile+RING-1) | ds_read operands | 12 or 24 bf16 MFMAs | VALU contraction | counted vmcnt | s_barrier.
@@ -667,19 +755,24 @@ struct StageB {
   static __device__ __forceinline__ void run(gptrq w2p, int wave, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
                                              const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
                                              const float (&M)[9], float (&acc)[NACC<KIND>], float* row, int half,
-                                             const float* s_msg, const int* s_node, float* s_acc, int nedge) {
+                                             float* s_msg, int* s_pnode, float* s_acc, int scat_local) {
     using G = Geo<KIND>;
     constexpr int NT0 = n_tiles_phase<KIND>(0);
     constexpr int NQ = TILE_QUADS<KIND, NS>;
     constexpr int R = RING<NS>;
     if constexpr (TILE < G::NT) {
       if constexpr (TILE == NT0 && NT0 > 0) {      // phase boundary: scalar outputs done -> stage, reduce, restart accumulators
-        stage_phase_compact<KIND, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0)>{});
-        __syncthreads();
-        segmented_sum_phase<KIND, 0>(s_msg, s_node, s_acc, nedge);
-        __syncthreads();
+        PROF_MARK(3);
+        stage_phase<KIND, 0, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0) / 2>{});
+        const auto chan0 = [](int c) { return kChanLut<KIND, 0>.v[c]; };
+        wave_segsum<Spec<KIND>::D_OUT, n_acc_phase<KIND>(0)>(s_msg + (size_t)wave * 32 * MSG_LD_B<KIND>, MSG_LD_B<KIND>, lane, scat_local,
+                                                             s_acc, &s_pnode[wave], chan0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS only: the weight ring's DMA stays in flight across this barrier
+        __builtin_amdgcn_s_barrier();                          // (phase-1 tiles end in barriers: rows are not restaged before wave 0 is done)
+        if (wave == 0) merge_wave_partials<Spec<KIND>::D_OUT, n_acc_phase<KIND>(0), WAVES_B>(s_msg, MSG_LD_B<KIND>, lane, s_pnode, s_acc, chan0);
 #pragma unroll
         for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
+        PROF_MARK(4);
       }
       if constexpr (TILE + R - 1 < G::NT) {        // slot (TILE-1)%R was released by the barrier that ended stage TILE-1
 #if DP_ABLATE == 5
@@ -690,32 +783,33 @@ struct StageB {
         asm volatile("" : "+s"(src));
         dma_tile<KIND, NS>(src, s_w + ((TILE + R - 1) % R) * NQ, wave, lane);
       }
-      const vu4* buf = s_w + (TILE % R) * NQ;
+      const unsigned lds_w = (unsigned)(__UINTPTR_TYPE__)(lptrq)s_w + lane * 16;   // LDS byte address of this lane's quad
       f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if DP_ABLATE == 2
       for (int r_ = 0; r_ < 16; ++r_) D[r_] = hb.v[0][0][0] == (__bf16)123.f ? 1.f : 0.5f;
 #else
-      // NB (measured, profiles/r1_bf16_ablation.md): the ds_read_b128 operand fetches are what bounds this kernel (~50-60 B/clk/CU
-      // effective); issuing them all up front or double-buffering them per block made no difference at 256 VGPRs.
+#if DP_ABLATE == 3
 #pragma unroll
       for (int b = 0; b < NKB<KIND>; ++b) {
-        bf16x8 W[NS];
-#pragma unroll
-#if DP_ABLATE == 3
-        for (int s = 0; s < NS; ++s) W[s] = hb.v[b][s];
-#else
-        for (int s = 0; s < NS; ++s) W[s] = __builtin_bit_cast(bf16x8, buf[(b * NS + s) * 64 + lane]);
-#endif
-        // smallest cross terms first
         if constexpr (NS == 3) {
-          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[b][1], D, 0, 0, 0);
-          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[b][0], D, 0, 0, 0);
-          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][2], D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][2], hb.v[b][0], D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][1], hb.v[b][1], D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][0], hb.v[b][2], D, 0, 0, 0);
         }
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[b][0], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][1], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[b][0], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][1], hb.v[b][0], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][0], hb.v[b][1], D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][0], hb.v[b][0], D, 0, 0, 0);
       }
+#else
+      {
+        // A-operand fetches as raw ds_read_b128 + hand-counted lgkmcnt.  With ordinary LDS loads the compiler cannot prove that
+        // they do not alias the LDS-DMA destinations and puts an s_waitcnt vmcnt(0) in front of the first read of every tile,
+        // i.e. a full L2 round trip for the tile that was JUST requested (measured: 0.88 -> see profiles/r1_bf16_ablation.md).
+        bf16x8 W[NS];
+        const unsigned la = lds_w + (TILE % R) * NQ * 16;
+        OperandPipe<KIND, NS, 0>::run(la, W, hb, D);
+      }
+#endif
 #endif
 #if DP_ABLATE == 1
       for (int r_ = 0; r_ < 16; ++r_) asm volatile("" ::"v"(D[r_]));
@@ -730,12 +824,18 @@ struct StageB {
         __builtin_amdgcn_s_barrier();
       }
       __builtin_amdgcn_sched_barrier(0);
-      StageB<KIND, NS, TILE + 1>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_node, s_acc, nedge);
+      StageB<KIND, NS, TILE + 1>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local);
     } else {
       constexpr int PHL = n_tiles_phase<KIND>(1) > 0 ? 1 : 0;
-      stage_phase_compact<KIND, PHL>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(PHL)>{});
+      PROF_MARK(5);
+      if constexpr (PHL == 1 && n_tiles_phase<KIND>(1) < 2 && n_tiles_phase<KIND>(0) > 0) __syncthreads();   // wave 0 may still be merging phase 0
+      stage_phase<KIND, PHL, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(PHL) / 2>{});
+      const auto chanl = [](int c) { return kChanLut<KIND, PHL>.v[c]; };
+      wave_segsum<Spec<KIND>::D_OUT, n_acc_phase<KIND>(PHL)>(s_msg + (size_t)wave * 32 * MSG_LD_B<KIND>, MSG_LD_B<KIND>, lane, scat_local,
+                                                             s_acc, &s_pnode[wave], chanl);
       __syncthreads();
-      segmented_sum_phase<KIND, PHL>(s_msg, s_node, s_acc, nedge);
+      if (wave == 0) merge_wave_partials<Spec<KIND>::D_OUT, n_acc_phase<KIND>(PHL), WAVES_B>(s_msg, MSG_LD_B<KIND>, lane, s_pnode, s_acc, chanl);
+      PROF_MARK(6);
     }
   }
 };
@@ -750,7 +850,7 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
   __shared__ __attribute__((aligned(16))) vu4 s_w[R * NQ];       // first: the DMA destination must be 16-byte aligned
   __shared__ float s_msg[CHUNK_B * MSG_LD_B<KIND>];
   __shared__ float s_acc[MAX_NODES_B * S::D_OUT];
-  __shared__ int s_node[CHUNK_B];
+  __shared__ int s_pnode[WAVES_B];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
   const WgRange r = wg_range(a);
@@ -758,6 +858,7 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
   for (int i = tid; i < r.n_loc * S::D_OUT; i += WAVES_B * 64) s_acc[i] = 0.f;
   gptrq w2p = (gptrq)a.w2p;
 
+  PROF_MARK(-1);
   for (int kc = r.k_begin; kc < r.k_end; kc += CHUNK_B) {
     const EdgeRef e = decode_edge(a, r, kc + wave * 32 + ecol);
     float xr[S::D_IN / 2], sh[S::SH_DIM], M[9];
@@ -767,14 +868,15 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
       gemm1_hidden<KIND>(a, e, lane, hid);
       split_hidden<KIND, NS>(hid, hb);
     }
+    PROF_MARK(0);
     load_tp_operands<KIND>(a, e, half, xr, sh, M);
     // keep the gathered operands in registers NOW: no ordinary global load may be pending once the DMA ring is running
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                              // previous chunk: last segmented sum done with s_msg / s_node, ring free
+    __syncthreads();                              // previous chunk: partial sums merged, s_msg rows and the ring are free
+    PROF_MARK(1);
     constexpr int NPRO = (R - 1 < G::NT) ? (R - 1) : G::NT;
 #pragma unroll
     for (int t = 0; t < NPRO; ++t) dma_tile<KIND, NS>(w2p + (size_t)t * NQ, s_w + t * NQ, wave, lane);
-    if (half == 0) s_node[wave * 32 + ecol] = e.scat_local;
     float* row = s_msg + (size_t)(wave * 32 + ecol) * MSG_LD_B<KIND>;
     float acc[NACC<KIND>];
 #pragma unroll
@@ -782,10 +884,12 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
     wait_vmcnt<(NPRO - 1) * PIECES<KIND, NS>>();   // tile 0 landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    StageB<KIND, NS, 0>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_node, s_acc, min(CHUNK_B, r.k_end - kc));
+    PROF_MARK(2);
+    StageB<KIND, NS, 0>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local);
   }
   __syncthreads();
   conv_epilogue<KIND, WAVES_B * 64>(a, r, s_acc);
+  PROF_MARK(7);
 }
 
 template <int KIND> int launch(const DpConvArgs& a, hipStream_t st) {

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="p2l")
     ap.add_argument("--prec", default="f32")
+    ap.add_argument("--prof", action="store_true", help="print the cycle-stamp breakdown (library built with -DDP_PROF)")
     ap.add_argument("--lib", default=None, help="alternative libdiffphore_hip.so (ablation builds)")
     a = ap.parse_args()
     if a.lib:
@@ -71,6 +72,16 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
+    if a.prof:
+        buf = (C.c_ulonglong * 16)()
+        L.dp_debug_prof(None, 1)
+        L.dp_tp_conv(C.byref(args), st)
+        torch.cuda.synchronize()
+        L.dp_debug_prof(buf, 0)
+        tot = sum(buf[:8]) or 1
+        names = ["gemm1+split", "operands+sync", "ring prologue", "tiles ph0", "segsum ph0", "tiles ph1", "segsum ph1", "epilogue"]
+        for n, v in zip(names, buf[:8]):
+            print(f"  {n:14s} {v:14d} ticks  {100.0 * v / tot:5.1f} %")
     print(json.dumps(dict(kind=a.kind, prec=a.prec, mode=a.mode, B=B, edges=E, ms=ms, ns_per_edge=ms * 1e6 / E,
                           alg_GBps=E * ALG_BYTES[a.kind] / ms / 1e6, TFLOPs=E * FLOPS[a.kind] / ms / 1e9)))
 
