@@ -532,6 +532,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
   constexpr int NA0_ = n_acc_phase<KIND>(0);
   const auto chan = [](int c) { return c < NA0_ ? kChanLut<KIND, 0>.v[c < NA0_ ? c : 0] : kChanLut<KIND, 1>.v[c < NA0_ ? 0 : c - NA0_]; };
 
+  PROF_MARK(-1);
   for (int kc = r.k_begin; kc < r.k_end; kc += CHUNK) {
     const EdgeRef e = decode_edge(a, r, kc + wave * 32 + ecol);
     float xr[S::D_IN / 2], sh[S::SH_DIM], M[9], hid[32];
@@ -539,7 +540,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
     gemm1_hidden<KIND>(a, e, lane, hid);
 
     // ---- GEMM2 tiles + CG contraction, phase 0 (scalar outputs) then phase 1 (vector outputs) ----------------------
+    PROF_MARK(0);
     __syncthreads();                              // previous chunk's partial sums have been merged (first pass: s_acc zeroed)
+    PROF_MARK(1);
     float* row = s_msg + (size_t)(wave * 32 + ecol) * G::MSG_LD;
     {
       constexpr int NT0 = n_tiles_phase<KIND>(0), NT1 = n_tiles_phase<KIND>(1);
@@ -553,7 +556,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
         load_wtile<KIND>(wp, lane, w0);
         __builtin_amdgcn_sched_barrier(0);
         Stage<KIND, 0, NT0>::run(wp, lane, w0, hid, xr, sh, M, acc);
+        PROF_MARK(3);
         stage_phase<KIND, 0, 0>(acc, row, half, std::make_integer_sequence<int, NA0 / 2>{});
+        PROF_MARK(4);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (NT1 > 0) {
@@ -565,6 +570,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
         load_wtile<KIND>(wp, lane, w0);
         __builtin_amdgcn_sched_barrier(0);
         Stage<KIND, NT0, NT0 + NT1>::run(wp, lane, w0, hid, xr, sh, M, acc);
+        PROF_MARK(5);
         stage_phase<KIND, 1, NA0>(acc, row, half, std::make_integer_sequence<int, NA1 / 2>{});
       }
     }
@@ -573,9 +579,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
     __syncthreads();
     if (wave == 0) merge_wave_partials<S::D_OUT, S::D_OUT, WAVES>(s_msg, G::MSG_LD, lane, s_pnode, s_acc, chan);
 #endif
+    PROF_MARK(6);
   }
   __syncthreads();
   conv_epilogue<KIND, WAVES * 64>(a, r, s_acc);
+  PROF_MARK(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
