@@ -175,3 +175,161 @@ def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, keep_upda
         lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
         g["ligand"].pos = pos[lo:hi].clone()
         g["ligand"].norm = norm[lo:hi].clone()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the single-step API and the best-of-R branching sampler
+# ---------------------------------------------------------------------------------------------------------------------------
+def _g_params(model_args, tr_sigma, rot_sigma, tor_sigma):
+    tr_g = float(tr_sigma) * np.sqrt(2 * np.log(model_args.tr_sigma_max / model_args.tr_sigma_min))
+    rot_g = 2 * float(rot_sigma) * np.sqrt(np.log(model_args.rot_sigma_max / model_args.rot_sigma_min))
+    tor_g = float(tor_sigma) * np.sqrt(2 * np.log(model_args.tor_sigma_max / model_args.tor_sigma_min))
+    return tr_g, rot_g, tor_g
+
+
+def _perturbations(eng, sp, z_tr, z_rot, z_tor, no_torsion):
+    """What the step applied: c1*score + c2*z, as CPU tensors / numpy in the reference's return types."""
+    ws = eng.ws
+    tr = (sp.tr_c1 * ws.tr + (sp.tr_c2 * z_tr if z_tr is not None else 0)).cpu()
+    rot = (sp.rot_c1 * ws.rot + (sp.rot_c2 * z_rot if z_rot is not None else 0)).cpu()
+    tor = None
+    if not no_torsion:
+        tor = (sp.tor_c1 * ws.tor[:ws.n_tor] + (sp.tor_c2 * z_tor[:ws.n_tor] if z_tor is not None else 0)).cpu().numpy()
+    return tr, rot, tor
+
+
+def sample_step(complex_graph_batch, model, model_args, tr_sigma, rot_sigma, tor_sigma, delta_t=0.05, no_random=False, ode=False,
+                noise=None):
+    """`src/utils/sampling.py:501-559`: ONE reverse step on a collated batch whose `complex_t` is already set (the calibrated
+    training sampler's entry point).  Returns `(data_list, tor_perturb, tr_perturb, rot_perturb)` like the reference;
+    `noise = (z_tr [b,3], z_rot [b,3], z_tor [sum T])` overrides the global-generator draws (tr, rot, tor order, :530-546)."""
+    eng = model.engine_for(complex_graph_batch)
+    pb = eng.pb
+    pb.set_state(torch.as_tensor(complex_graph_batch["ligand"].pos), torch.as_tensor(complex_graph_batch["ligand"].norm))
+    ct = complex_graph_batch.complex_t
+    pb.set_time(ct["tr"], ct["rot"], ct["tor"])
+    no_torsion = bool(getattr(model_args, "no_torsion", False))
+    tr_g, rot_g, tor_g = _g_params(model_args, tr_sigma, rot_sigma, tor_sigma)
+    sp = DpStepParams()
+    half = 0.5 if ode else 1.0
+    sp.tr_c1, sp.rot_c1, sp.tor_c1 = half * tr_g ** 2 * delta_t, half * rot_g ** 2 * delta_t, half * tor_g ** 2 * delta_t
+    nz = 0.0 if (ode or no_random) else 1.0
+    sp.tr_c2, sp.rot_c2, sp.tor_c2 = nz * tr_g * np.sqrt(delta_t), nz * rot_g * np.sqrt(delta_t), nz * tor_g * np.sqrt(delta_t)
+    sp.no_torsion = 1 if no_torsion else 0
+    b, nT = pb.B, int(pb.tor_ptr[-1])
+    z_tr = z_rot = z_tor = None
+    if nz:
+        if noise is not None:
+            z_tr, z_rot, z_tor = noise
+        else:
+            z_tr, z_rot = torch.normal(mean=0, std=1, size=(b, 3)), torch.normal(mean=0, std=1, size=(b, 3))
+            z_tor = torch.normal(mean=0, std=1, size=(nT,)) if not no_torsion else None
+        z_tr, z_rot = z_tr.to(pb.device, torch.float32).contiguous(), z_rot.to(pb.device, torch.float32).contiguous()
+        z_tor = z_tor.to(pb.device, torch.float32).contiguous() if (z_tor is not None and not no_torsion and nT) else None
+    eng.sample_step(sp, z_tr, z_rot, z_tor)
+    status = eng.ws.t["status"].cpu()
+    if bool((status != 0).any()):
+        raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status).flatten().tolist()}")
+    tr_p, rot_p, tor_p = _perturbations(eng, sp, z_tr, z_rot, z_tor, no_torsion)
+    data_list = complex_graph_batch.to_data_list()
+    pos, norm = pb.pos.cpu(), pb.norm.cpu()
+    for i, g in enumerate(data_list):
+        lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
+        g["ligand"].pos = pos[lo:hi].clone()
+        g["ligand"].norm = norm[lo:hi].clone()
+    if getattr(model_args, "keep_update", False):
+        _record_updates(data_list, eng, sp, z_tr, z_rot, z_tor, no_torsion)
+    return data_list, tor_p, tr_p, rot_p
+
+
+def sampling_phore_with_fitscore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
+                                 no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
+                                 confidence_model_args=None, batch_size=32, no_final_step_noise=False, fitscore_fn=None, noise=None):
+    """`src/utils/sampling.py:283-444`: reverse diffusion where every step draws `model_args.random_samples` noise candidates
+    per pose and keeps the one with the best pharmacophore fit score.
+
+    The score model runs ONCE per step; the R candidate conformer updates are R launches of `dp_conformer_update` from the same
+    saved state (the reference deep-copies the graph R times and runs `modify_conformer` in Python for each).
+    `fitscore_fn(dock_pose [b*R, n_heavy, 3] (pose-major, candidate-minor), data_list) -> b*R scores` replaces the AncPhore
+    call (`calculate_fitscore`, :447-498, closed binary); it is required when `random_samples > 1`.
+    Deliberate deviations: (1) candidate selection is per pose (the reference's `view(random_samples, -1)` indexing, :413,
+    is only consistent for batches of one pose); (2) `ode=True` with torsions dies with NameError in the reference (:372-378
+    use `tor_z` that the ODE branch never defines) and raises NotImplementedError here; (3) the ODE translation update of the
+    reference is `0.5*g*sqrt(dt)*score` (:344, not squared) - reproduced.
+    With `random_samples <= 1`, `no_random` or on the noise-free last step this is `sampling_phore`'s update.
+    `noise` = {'tr': [S,R,N,3], 'rot': [S,R,N,3], 'tor': [S,R,sum T]} overrides the generator (R = 1 when not branching)."""
+    if confidence_model is not None:
+        raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
+    N = len(data_list)
+    R = int(getattr(model_args, "random_samples", 0) or 0)
+    no_torsion = bool(getattr(model_args, "no_torsion", False))
+    if ode and not no_torsion:
+        raise NotImplementedError("sampling_phore_with_fitscore(ode=True) with torsions is undefined in the reference (NameError at sampling.py:378)")
+    if R > 1 and not no_random and fitscore_fn is None:
+        raise ValueError("random_samples > 1 needs fitscore_fn (the reference calls the AncPhore binary here)")
+    eng = Engine(model.device_model, PackedBatch(data_list, device))
+    pb = eng.pb
+    dev = pb.device
+    nT = int(pb.tor_ptr[-1])
+    heavy = torch.cat([torch.not_equal(torch.as_tensor(g["ligand"].x)[:, 0], 0) for g in data_list]).numpy()
+    centers = np.concatenate([np.repeat(torch.as_tensor(g.original_center).reshape(1, 3).numpy() if "original_center" in g
+                                        else np.zeros((1, 3)), int(pb.nl[i]), 0) for i, g in enumerate(data_list)])
+    for t_idx in range(inference_steps):
+        last = no_final_step_noise and t_idx == inference_steps - 1
+        branching = (not no_random) and R > 1 and not last
+        sp = _step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, no_random or last)
+        if ode:   # :344 - the reference's ODE translation coefficient is not squared
+            dt_tr = tr_schedule[t_idx] - tr_schedule[t_idx + 1] if t_idx < inference_steps - 1 else tr_schedule[t_idx]
+            tr_g, _, _ = _g_params(model_args, *t_to_sigma(tr_schedule[t_idx], rot_schedule[t_idx], tor_schedule[t_idx]))
+            sp.tr_c1 = 0.5 * tr_g * np.sqrt(dt_tr)
+        pb.set_time(float(tr_schedule[t_idx]), float(rot_schedule[t_idx]), float(tor_schedule[t_idx]))
+        eng.forward()
+        reps = R if branching else 1
+        noisy = not (ode or no_random or last)
+        cand_pos, cand_norm = [], []
+        pos0, norm0 = pb.pos.clone(), pb.norm.clone()
+        for j in range(reps):
+            z_tr = z_rot = z_tor = None
+            if noisy:
+                if noise is not None:
+                    z_tr, z_rot, z_tor = noise["tr"][t_idx][j], noise["rot"][t_idx][j], noise["tor"][t_idx][j]
+                else:
+                    z_tr, z_rot = torch.normal(mean=0, std=1, size=(N, 3)), torch.normal(mean=0, std=1, size=(N, 3))
+                    z_tor = torch.normal(mean=0, std=1, size=(nT,))
+                z_tr, z_rot = z_tr.to(dev, torch.float32).contiguous(), z_rot.to(dev, torch.float32).contiguous()
+                z_tor = z_tor.to(dev, torch.float32).contiguous() if (not no_torsion and nT) else None
+            if j:
+                pb.pos.copy_(pos0)
+                pb.norm.copy_(norm0)
+            eng.update(sp, z_tr, z_rot, z_tor)
+            if branching:
+                cand_pos.append(pb.pos.clone())
+                cand_norm.append(pb.norm.clone())
+        if branching:
+            P = torch.stack(cand_pos, 0)                                   # [R, sum N_l, 3]
+            dock = []
+            Pn = P.cpu().numpy()
+            for i in range(N):
+                lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
+                for j in range(R):
+                    dock.append((Pn[j, lo:hi] + centers[lo:hi])[heavy[lo:hi]])
+            scores = torch.as_tensor(np.asarray(fitscore_fn(dock, data_list), dtype=np.float64)).view(N, R)
+            best = scores.argmax(dim=1)
+            sel = torch.repeat_interleave(best, torch.as_tensor(pb.nl, dtype=torch.long)).to(dev)
+            idx = torch.arange(sel.numel(), device=dev)
+            pb.pos.copy_(P[sel, idx])
+            pb.norm.copy_(torch.stack(cand_norm, 0)[sel, idx])
+        if visualization_list is not None:
+            pos = pb.pos.cpu()
+            for idx_, vis in enumerate(visualization_list):
+                lo, hi = int(pb.lig_ptr[idx_]), int(pb.lig_ptr[idx_ + 1])
+                vis.add((pos[lo:hi] + data_list[idx_].original_center).detach().cpu(), part=1, order=t_idx + 2)
+    status = eng.ws.t["status"].cpu()
+    if bool((status != 0).any()):
+        raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status).flatten().tolist()}")
+    pos, norm = pb.pos.cpu(), pb.norm.cpu()
+    for i, g in enumerate(data_list):
+        lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
+        g["ligand"].pos = pos[lo:hi].clone()
+        g["ligand"].norm = norm[lo:hi].clone()
+    return data_list, None

@@ -1,0 +1,211 @@
+"""SURVEY.md 8f rows on the GPU: `sample_step`, the best-of-R branching sampler and the `fit` driver."""
+import copy
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffphore_amd import config, sdf_io, synthetic, weights  # noqa: E402
+from diffphore_amd.hetero import Batch  # noqa: E402
+
+
+def _args(**kw):
+    cfg = config.ModelConfig()
+    base = {k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")}
+    base.update(no_torsion=False)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def _model():
+    from diffphore_amd.score_model import TensorProductScoreModel
+    return TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+
+
+def _noise(S, R, gs, seed):
+    gen = torch.Generator().manual_seed(seed)
+    nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
+    return dict(tr=torch.randn(S, R, len(gs), 3, generator=gen), rot=torch.randn(S, R, len(gs), 3, generator=gen),
+                tor=torch.randn(S, R, nT, generator=gen))
+
+
+def test_sample_step_is_one_sampler_step_and_matches_oracle():
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sample_step, sampling_phore
+    from oracle import sampler as osampler
+    from oracle.model import OracleScoreModel
+    from oracle.tables import load_tables
+    gs = synthetic.synthetic_pairs(311, 5, (12, 20), (1, 5), (10, 18))
+    args = _args()
+    m = _model()
+    t = 0.4
+    nz = _noise(1, 1, gs, 5)
+    # (a) one-step sampling_phore with schedule [t]: dt = t on the last step
+    a, _ = sampling_phore(copy.deepcopy(gs), m, 1, [t], [t], [t], "cuda", t_to_sigma_fn(args), args,
+                          noise=dict(tr=nz["tr"][:, 0], rot=nz["rot"][:, 0], tor=nz["tor"][:, 0]))
+    # (b) sample_step on the collated batch
+    batch = Batch.from_data_list(copy.deepcopy(gs))
+    osampler.set_time_phore(batch, t, t, t, batch.num_graphs)
+    sig = t_to_sigma_fn(args)(t, t, t)
+    b, tor_p, tr_p, rot_p = sample_step(batch, m, args, *sig, delta_t=t, noise=(nz["tr"][0, 0], nz["rot"][0, 0], nz["tor"][0, 0]))
+    for x, y in zip(a, b):
+        assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
+    # (c) the returned perturbations are c1*score + c2*z with the oracle's scores
+    om = OracleScoreModel(weights.init_state_dict(), config.ModelConfig(), dtype=torch.float64, tables=load_tables())
+    ob = Batch.from_data_list(copy.deepcopy(gs))
+    osampler.set_time_phore(ob, t, t, t, ob.num_graphs)
+    tr_s, rot_s, tor_s = om(ob)
+    tr_g = float(sig[0]) * np.sqrt(2 * np.log(args.tr_sigma_max / args.tr_sigma_min))
+    rot_g = 2 * float(sig[1]) * np.sqrt(np.log(args.rot_sigma_max / args.rot_sigma_min))
+    tor_g = float(sig[2]) * np.sqrt(2 * np.log(args.tor_sigma_max / args.tor_sigma_min))
+    np.testing.assert_allclose(tr_p.numpy(), (tr_g ** 2 * t * tr_s + tr_g * np.sqrt(t) * nz["tr"][0, 0]).numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(rot_p.numpy(), (rot_g ** 2 * t * rot_s + rot_g * np.sqrt(t) * nz["rot"][0, 0]).numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(tor_p, (tor_g ** 2 * t * tor_s + tor_g * np.sqrt(t) * nz["tor"][0, 0]).numpy(), rtol=2e-4, atol=2e-4)
+    assert tr_p.shape == (5, 3) and tor_p.shape == tor_s.shape
+    # no_random: deterministic and different
+    b2 = Batch.from_data_list(copy.deepcopy(gs))
+    osampler.set_time_phore(b2, t, t, t, b2.num_graphs)
+    c, _, tr0, _ = sample_step(b2, m, args, *sig, delta_t=t, no_random=True)
+    np.testing.assert_allclose(tr0.numpy(), (tr_g ** 2 * t * tr_s).numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_branching_sampler_selects_best_candidate_per_pose():
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore, sampling_phore_with_fitscore
+    gs = synthetic.synthetic_pairs(312, 4, (12, 18), (1, 4), (10, 16))
+    for i, g in enumerate(gs):
+        g.original_center = torch.tensor([[1.0 * i, 0.0, -2.0]])
+    S, R = 3, 3
+    sched = get_t_schedule(S)
+    m = _model()
+    nz = _noise(S, R, gs, 11)
+    # R <= 1: identical to sampling_phore under the same noise
+    args1 = _args(random_samples=0)
+    a, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args1), args1,
+                          noise=dict(tr=nz["tr"][:, 0], rot=nz["rot"][:, 0], tor=nz["tor"][:, 0]))
+    b, _ = sampling_phore_with_fitscore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args1), args1,
+                                        noise={k: v[:, :1] for k, v in nz.items()})
+    for x, y in zip(a, b):
+        assert torch.equal(x["ligand"].pos, y["ligand"].pos)
+    # R = 3 with a geometric score (closer to the origin of the docked frame is better); record the choices
+    argsR = _args(random_samples=R)
+    choices = []
+
+    def score(dock, data_list):
+        assert len(dock) == len(data_list) * R and dock[0].shape == (int(data_list[0]["ligand"].pos.shape[0]), 3)
+        s = np.asarray([-np.linalg.norm(d.mean(0)) for d in dock])
+        choices.append(s.reshape(len(data_list), R).argmax(1))
+        return s
+
+    c, _ = sampling_phore_with_fitscore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(argsR), argsR,
+                                        fitscore_fn=score, noise=nz, no_final_step_noise=True)
+    assert len(choices) == S - 1                                   # the noise-free last step does not branch
+    # replay: the plain sampler fed with each pose's chosen candidate noise reproduces the branching run bit for bit
+    tor_ptr = np.concatenate([[0], np.cumsum([int(g["ligand"].edge_mask.sum()) for g in gs])])
+    sel = dict(tr=torch.zeros(S, len(gs), 3), rot=torch.zeros(S, len(gs), 3), tor=torch.zeros(S, int(tor_ptr[-1])))
+    for s_ in range(S - 1):
+        for i in range(len(gs)):
+            j = int(choices[s_][i])
+            sel["tr"][s_, i], sel["rot"][s_, i] = nz["tr"][s_, j, i], nz["rot"][s_, j, i]
+            sel["tor"][s_, tor_ptr[i]:tor_ptr[i + 1]] = nz["tor"][s_, j, tor_ptr[i]:tor_ptr[i + 1]]
+    d, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(argsR), argsR, noise=sel,
+                          no_final_step_noise=True)
+    for x, y in zip(c, d):
+        assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
+    assert any(len(set(ch.tolist())) > 1 for ch in choices)       # different poses picked different candidates
+    with pytest.raises(ValueError):
+        sampling_phore_with_fitscore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(argsR), argsR)
+    with pytest.raises(NotImplementedError):
+        sampling_phore_with_fitscore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args1), args1, ode=True)
+
+
+def _mol_for(g, name):
+    """A V2000 record with one carbon per heavy atom, the graph's bonds, plus two explicit hydrogens the driver must drop."""
+    pos = g["ligand"].pos.numpy().astype(np.float64)
+    n = pos.shape[0]
+    m = sdf_io.Mol(title=name, program="  synthetic", comment="")
+    m.coords = np.concatenate([pos, pos[:2] + 0.9])
+    m.symbols = ["C"] * n + ["H", "H"]
+    m.atom_tail = [" C   0  0  0  0  0  0  0  0  0  0  0  0"] * n + [" H   0  0  0  0  0  0  0  0  0  0  0  0"] * 2
+    ei = g["ligand", "ligand"].edge_index.numpy()
+    seen = set()
+    for a, b in ei.T:
+        if (min(a, b), max(a, b)) not in seen:
+            seen.add((min(a, b), max(a, b)))
+            m.bonds.append([int(a) + 1, int(b) + 1, 1])
+            m.bond_tail.append("  0")
+    m.bonds += [[1, n + 1, 1], [2, n + 2, 1]]
+    m.bond_tail += ["  0", "  0"]
+    return m
+
+
+def test_fit_driver_files_resume_and_retry(tmp_path, monkeypatch, capsys):
+    from diffphore_amd import fit as fitmod
+    from diffphore_amd.diffusion import t_to_sigma_fn
+    gs = synthetic.synthetic_pairs(313, 3, (12, 18), (1, 4), (10, 16))
+    for i, g in enumerate(gs):
+        g.name = f"tgt__lig{i}"
+        g.original_center = torch.tensor([[10.0 + i, -3.0, 2.0]])
+        g.mol = _mol_for(g, g.name)
+    N = 4
+    args = _args(run_dir=str(tmp_path), out_dir=str(tmp_path), sample_per_complex=N, inference_steps=3, overwrite=False, batch_size=20,
+                 no_random=False, ode=False, no_final_step_noise=True, complexes_per_launch=2, cutoff=None)
+    m = _model()
+
+    def scorer(a, dock_pose, name, g):
+        return [-float(np.linalg.norm(p.mean(0) - np.array([10.0, -3.0, 2.0]))) for p in dock_pose]
+
+    torch.manual_seed(1)
+    np.random.seed(1)
+    res = fitmod.fit(args, m, gs, "cuda", t_to_sigma_fn(args), scorer=scorer)
+    assert res["name"] == [g.name for g in gs] and all(len(s) == N for s in res["fitscore"])
+    for g, sc in zip(gs, res["fitscore"]):
+        recs = sdf_io.read_sdf(os.path.join(tmp_path, f"ranked_poses/{g.name}_ranked.sdf"))
+        assert [r.title for r in recs] == [f"{g.name}_rank_{i}" for i in range(N)]
+        fs = [float(r.data["fitscore"]) for r in recs]
+        assert fs == sorted(sc, reverse=True)                                         # best first
+        assert all(r.num_atoms == g["ligand"].pos.shape[0] and "H" not in r.symbols for r in recs)   # hydrogens dropped
+        # ranked coordinates are in the original frame: their score, recomputed from the file, matches
+        np.testing.assert_allclose([-np.linalg.norm(r.coords.mean(0) - np.array([10.0, -3.0, 2.0])) for r in recs], fs, atol=2e-4)
+        # bonded geometry of the template survives (torsion + rigid moves only)
+        d_ref = [np.linalg.norm(g.mol.coords[a - 1] - g.mol.coords[b - 1]) for a, b, _ in recs[0].bonds]
+        d_new = [np.linalg.norm(recs[0].coords[a - 1] - recs[0].coords[b - 1]) for a, b, _ in recs[0].bonds]
+        np.testing.assert_allclose(d_new, d_ref, atol=3e-4)
+        log = json.load(open(os.path.join(tmp_path, f"mapping_process/{g.name}/{g.name}_dock.log")))
+        assert log["name"] == g.name and log["fitscore"] == sc
+    df = fitmod.analyze_results(args, res)
+    assert os.path.exists(os.path.join(tmp_path, "ranked_results.csv")) and len(df) == 3
+
+    # resume: nothing is sampled again
+    def boom(*a, **k):
+        raise AssertionError("resumed complexes must not be re-sampled")
+    monkeypatch.setattr(fitmod, "sampling_phore", boom)
+    res2 = fitmod.fit(args, m, gs, "cuda", t_to_sigma_fn(args), scorer=scorer)
+    assert res2["fitscore"] == res["fitscore"] and res2["name"] == res["name"]
+
+    # SVD-retry convention: 'failed to converge' is retried up to 5 times per complex, then the complex is skipped; no scorer -> -2.0
+    calls = {"n": 0}
+    real = fitmod.__dict__["randomize_position"]
+
+    def flaky(**kw):
+        calls["n"] += 1
+        if calls["n"] <= 3:
+            raise RuntimeError("linalg.svd: Kabsch alignment failed to converge for poses [0]")
+        from diffphore_amd.sampling import sampling_phore as sp
+        return sp(**kw)
+    monkeypatch.setattr(fitmod, "sampling_phore", flaky)
+    args.overwrite = True
+    res3 = fitmod.fit(args, m, gs[:1], "cuda", t_to_sigma_fn(args))
+    assert calls["n"] == 4 and res3["fitscore"] == [[-2.0] * N]
+
+    def dead(**kw):
+        raise RuntimeError("failed to converge")
+    monkeypatch.setattr(fitmod, "sampling_phore", dead)
+    res4 = fitmod.fit(args, m, gs[:1], "cuda", t_to_sigma_fn(args))
+    assert res4["name"] == [] and "skipping the complex" in capsys.readouterr().out
+    assert real is fitmod.randomize_position
