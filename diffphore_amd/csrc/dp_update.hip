@@ -342,6 +342,64 @@ __global__ __launch_bounds__(256) void conformer_update_kernel(DpBatch b, DpStep
   if (tid == 0 && status && s_flag) status[p] |= s_flag;     // sticky across the steps of a run; the caller zeroes it
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Gaussian-volume pharmacophore-fit SURROGATE for ranking candidate poses on the device.
+// NOT AncPhore (closed binary, absent): same Gaussian overlap kernel and constants as the reference's own type/count similarity
+// (`get_perfect_similarity`, src/inference.py:273-295: vol = 7.999999999 (pi/(a1+a2))^1.5 exp(-a1 a2 r^2/(a1+a2))), evaluated
+// on the actual geometry.  Per pose:
+//     V    = sum over features m (non-EX) of w_m * max over ligand atoms n with phorefp[n, type_m] of G(a_m, a_m, |r_nm|^2)
+//     Vref = sum over features m of w_m * G(a_m, a_m, 0)
+//     X    = sum over exclusion spheres m, atoms n of exp(-a_m |r_nm|^2 / 2)
+//     score = V / Vref - ex_lambda * X / N_l          (-1 when the model has no weighted feature)
+// One workgroup per pose, one thread per pharmacophore node, fixed-order reduction: reruns are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fit_overlap_kernel(DpBatch b, const float* pos_in, float ex_lambda, float* score) {
+  __shared__ float s_pos[MAXN_L * 3];
+  __shared__ float s_v[MAXN_P], s_ref[MAXN_P], s_x[MAXN_P];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int l0 = b.lig_ptr[p], nl = b.lig_ptr[p + 1] - l0, p0 = b.ph_ptr[p], np_ = b.ph_ptr[p + 1] - p0;
+  const float* pos = pos_in ? pos_in : b.pos;
+  for (int i = tid; i < nl * 3; i += 256) s_pos[i] = pos[(size_t)l0 * 3 + i];
+  __syncthreads();
+  float v = 0.f, ref = 0.f, x = 0.f;
+  if (tid < np_) {
+    const int m = p0 + tid, type = b.ph_type[m];
+    const float alpha = b.ph_scalar[m * 2], w = b.ph_scalar[m * 2 + 1];
+    const float px = b.ph_pos[m * 3], py = b.ph_pos[m * 3 + 1], pz = b.ph_pos[m * 3 + 2];
+    if (type != 10) {
+      const float g0 = 7.999999999f * powf(3.14159265358979323846f / (2.f * alpha), 1.5f);
+      float best = 0.f;
+      for (int n = 0; n < nl; ++n) {
+        if (b.phorefp[(size_t)(l0 + n) * 11 + type] != 0.f) {
+          const float dx = s_pos[n * 3] - px, dy = s_pos[n * 3 + 1] - py, dz = s_pos[n * 3 + 2] - pz;
+          best = fmaxf(best, expf(-0.5f * alpha * (dx * dx + dy * dy + dz * dz)));
+        }
+      }
+      v = w * g0 * best;
+      ref = w * g0;
+    } else {
+      for (int n = 0; n < nl; ++n) {
+        const float dx = s_pos[n * 3] - px, dy = s_pos[n * 3 + 1] - py, dz = s_pos[n * 3 + 2] - pz;
+        x += expf(-0.5f * alpha * (dx * dx + dy * dy + dz * dz));
+      }
+    }
+  }
+  s_v[tid] = v;
+  s_ref[tid] = ref;
+  s_x[tid] = x;
+  __syncthreads();
+  if (tid == 0) {
+    float V = 0.f, R = 0.f, X = 0.f;
+    for (int m = 0; m < np_; ++m) {
+      V += s_v[m];
+      R += s_ref[m];
+      X += s_x[m];
+    }
+    score[p] = (R > 0.f ? V / R : -1.f) - ex_lambda * X / (float)(nl > 0 ? nl : 1);
+  }
+}
+
 }  // namespace dp
 
 extern "C" {
@@ -369,6 +427,14 @@ int dp_sample_step(const DpBatch* b, const DpWeights* w, DpWork* k, const DpStep
   int rc = dp_forward(b, w, k, tr, rot, tor, stream);
   if (rc) return rc;
   return dp_conformer_update(b, sp, tr, rot, tor, z_tr, z_rot, z_tor, k ? k->status : nullptr, stream);
+}
+
+
+int dp_fit_overlap(const DpBatch* b, const float* pos, float ex_lambda, float* score, void* stream) {
+  if (!b || b->B <= 0 || !score) return DP_E_BADARG;
+  if (b->max_nl > dp::MAXN_L || b->max_np > dp::MAXN_P) return DP_E_TOOLARGE;
+  hipLaunchKernelGGL(dp::fit_overlap_kernel, dim3(b->B), dim3(256), 0, (hipStream_t)stream, *b, pos, ex_lambda, score);
+  return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -84,6 +84,15 @@ def fit(args, model, complex_graphs, device, t_to_sigma, tmp_log: str = "", n_re
     todo = []
     for i, g in enumerate(complex_graphs):
         name = _name(g)
+        if getattr(args, "min_similarity", 0) > 0:          # inference.py:170-178
+            try:
+                from .fitness import get_perfect_similarity
+                max_sim = get_perfect_similarity(g)
+                if max_sim < args.min_similarity:
+                    print(f"[I] `{name}` is excluded due to pharmacophore fingerprint similarity constraints ({max_sim:.2f} < {args.min_similarity:.2f}).")
+                    continue
+            except Exception as e:
+                print(f"[W] Failed to calculate the pharmacophore fingerprint similarity of `{name}`, skipped. {e}")
         docked_file, log_file = _paths(args, name)
         if os.path.exists(docked_file) and os.path.exists(log_file) and not getattr(args, "overwrite", False):
             log = json.load(open(log_file))

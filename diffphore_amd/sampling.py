@@ -257,6 +257,7 @@ def sampling_phore_with_fitscore(data_list, model, inference_steps, tr_schedule,
     use `tor_z` that the ODE branch never defines) and raises NotImplementedError here; (3) the ODE translation update of the
     reference is `0.5*g*sqrt(dt)*score` (:344, not squared) - reproduced.
     With `random_samples <= 1`, `no_random` or on the noise-free last step this is `sampling_phore`'s update.
+    `fitscore_fn="overlap"` selects the built-in on-device surrogate (`diffphore_amd.fitness`, not AncPhore).
     `noise` = {'tr': [S,R,N,3], 'rot': [S,R,N,3], 'tor': [S,R,sum T]} overrides the generator (R = 1 when not branching)."""
     if confidence_model is not None:
         raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
@@ -305,7 +306,18 @@ def sampling_phore_with_fitscore(data_list, model, inference_steps, tr_schedule,
             if branching:
                 cand_pos.append(pb.pos.clone())
                 cand_norm.append(pb.norm.clone())
-        if branching:
+        if branching and isinstance(fitscore_fn, str):
+            if fitscore_fn != "overlap":
+                raise ValueError(f"unknown built-in fit score {fitscore_fn!r}")
+            from .fitness import overlap_scores                            # on-device surrogate: no host round trip in the loop
+            P = torch.stack(cand_pos, 0)
+            ex_l = float(getattr(model_args, "ex_lambda", 1.0))
+            best = torch.stack([overlap_scores(pb, P[j], ex_l) for j in range(R)], 1).argmax(dim=1)
+            sel = torch.repeat_interleave(best, torch.as_tensor(pb.nl, dtype=torch.long, device=dev))
+            idx = torch.arange(sel.numel(), device=dev)
+            pb.pos.copy_(P[sel, idx])
+            pb.norm.copy_(torch.stack(cand_norm, 0)[sel, idx])
+        elif branching:
             P = torch.stack(cand_pos, 0)                                   # [R, sum N_l, 3]
             dock = []
             Pn = P.cpu().numpy()

@@ -224,6 +224,12 @@ int dp_conformer_update(const DpBatch* b, const DpStepParams* sp, const float* t
 /* randomize_position (sampling.py:16-63): theta [n_tor] random torsion angles, rot_mats [B,3,3] random rotations, tr [B,3]
  * translation (NULL = no_random).  The random numbers are drawn by the caller, exactly as the reference draws them. */
 int dp_randomize_position(const DpBatch* b, const float* theta, const float* rot_mats, const float* tr, int32_t no_torsion, void* stream);
+
+/* Pharmacophore-fit SURROGATE for ranking poses on the device.  Stands where the reference shells out to the
+ * closed AncPhore binary (`calculate_fitscore`, src/utils/sampling.py:447-498) and is NOT that program: a Gaussian-volume overlap
+ * with the constants of `get_perfect_similarity` (src/inference.py:273-295); formula in dp_update.hip.  `pos` = candidate ligand
+ * coordinates [n_lig,3] or NULL for the batch's current state; `score` [B]. */
+int dp_fit_overlap(const DpBatch* b, const float* pos, float ex_lambda, float* score, void* stream);
 /* dp_forward + dp_conformer_update */
 int dp_sample_step(const DpBatch* b, const DpWeights* w, DpWork* k, const DpStepParams* sp, float* tr, float* rot, float* tor,
                    const float* z_tr, const float* z_rot, const float* z_tor, void* stream);

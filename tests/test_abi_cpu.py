@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "diffphore_amd.h")).read()
     names = set(re.findall(r"^\s*int\s+(dp_\w+)\s*\(", hdr, flags=re.M))
-    assert {"dp_tp_conv", "dp_forward", "dp_sample_step", "dp_conformer_update", "dp_prepare", "dp_randomize_position",
+    assert {"dp_tp_conv", "dp_forward", "dp_sample_step", "dp_conformer_update", "dp_prepare", "dp_randomize_position", "dp_fit_overlap",
             "dp_pack_conv_weights", "dp_abi_version", "dp_struct_sizes"} <= names
     L = _lib.lib()
     for n in names:

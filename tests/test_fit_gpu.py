@@ -209,3 +209,60 @@ def test_fit_driver_files_resume_and_retry(tmp_path, monkeypatch, capsys):
     res4 = fitmod.fit(args, m, gs[:1], "cuda", t_to_sigma_fn(args))
     assert res4["name"] == [] and "skipping the complex" in capsys.readouterr().out
     assert real is fitmod.randomize_position
+
+
+def test_fit_overlap_surrogate_matches_its_oracle_and_ranks_on_device():
+    """dp_fit_overlap (8f-3) vs the numpy restatement; then the branching sampler scoring candidates on the device."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.engine import PackedBatch
+    from diffphore_amd.fitness import overlap_scorer, overlap_scores
+    from diffphore_amd.sampling import sampling_phore_with_fitscore
+    from oracle import fitness as ofit
+    gs = synthetic.synthetic_pairs(314, 6, (10, 40), (0, 6), (8, 79))
+    pb = PackedBatch(gs, "cuda")
+    got = overlap_scores(pb, ex_lambda=0.7).cpu().numpy()
+    want = np.asarray([ofit.overlap_score_graph(g, ex_lambda=0.7) for g in gs])
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    # candidate coordinates instead of the batch state; moving the ligand far away kills the overlap and the clash term
+    far = pb.pos + 100.0
+    np.testing.assert_allclose(overlap_scores(pb, far).cpu().numpy(), 0.0, atol=1e-12)
+    np.testing.assert_allclose(overlap_scores(pb, pb.pos.clone(), 0.7).cpu().numpy(), got, rtol=0, atol=0)
+    # an atom sitting exactly on every feature it matches scores the full volume (no exclusion spheres counted: lambda = 0)
+    g = copy.deepcopy(gs[0])
+    types_ = np.asarray(g["phore"].phoretype).argmax(1)
+    feat = np.where(types_ != 10)[0]
+    n = g["ligand"].pos.shape[0]
+    assert len(feat) <= n
+    g["ligand"].pos[:len(feat)] = g["phore"].pos[feat]
+    fp = torch.zeros_like(g["ligand"].phorefp)
+    fp[torch.arange(len(feat)), torch.as_tensor(types_[feat])] = 1.0
+    g["ligand"].phorefp = fp
+    np.testing.assert_allclose(overlap_scores(PackedBatch([g], "cuda"), ex_lambda=0.0).cpu().numpy(), [1.0], rtol=1e-6)
+    # scorer hook of fit(): docked frame in, same numbers out
+    g0 = gs[1]
+    g0.original_center = torch.tensor([[3.0, -1.0, 2.0]])
+    dock = np.stack([g0["ligand"].pos.numpy() + g0.original_center.numpy(), g0["ligand"].pos.numpy() + 1.5 + g0.original_center.numpy()])
+    sc = overlap_scorer(types.SimpleNamespace(), dock, "x", g0)
+    np.testing.assert_allclose(sc, [ofit.overlap_score_graph(g0), ofit.overlap_score_graph(g0, pos=g0["ligand"].pos.numpy() + 1.5)], rtol=2e-5, atol=2e-6)
+
+    # branching sampler with the built-in score == branching sampler with the same score computed on the host
+    S, R = 3, 3
+    sched = get_t_schedule(S)
+    argsR = _args(random_samples=R)
+    m = _model()
+    gs2 = synthetic.synthetic_pairs(315, 4, (12, 18), (1, 4), (10, 16))
+    nz = _noise(S, R, gs2, 21)
+
+    def host_score(dock, data_list):
+        out = []
+        for i, g_ in enumerate(data_list):
+            for j in range(R):
+                c = g_.original_center.reshape(1, 3).numpy() if "original_center" in g_ else 0.0   # candidates arrive in the docked frame
+                out.append(ofit.overlap_score_graph(g_, pos=dock[i * R + j] - c))
+        return out
+    a, _ = sampling_phore_with_fitscore(copy.deepcopy(gs2), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(argsR), argsR,
+                                        fitscore_fn="overlap", noise=nz, no_final_step_noise=True)
+    b, _ = sampling_phore_with_fitscore(copy.deepcopy(gs2), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(argsR), argsR,
+                                        fitscore_fn=host_score, noise=nz, no_final_step_noise=True)
+    same = sum(bool(torch.equal(x["ligand"].pos, y["ligand"].pos)) for x, y in zip(a, b))
+    assert same == len(gs2), same

@@ -91,3 +91,26 @@ def test_analyze_results_layout(tmp_path):
     assert lines[0].split("\t")[:3] == ["target", "ligand", "name"] and lines[1].split("\t")[:3] == ["t1", "b", "t1__b"]
     assert len(open(tmp_path / "ranked_results_gt0.6.csv").read().splitlines()) == 3
     assert fitmod.my_max([]) == -2.0
+
+
+def test_perfect_similarity_and_surrogate_formula():
+    import torch
+    from diffphore_amd import synthetic
+    from diffphore_amd.fitness import get_perfect_similarity
+    from oracle import fitness as ofit
+    (g,) = synthetic.synthetic_pairs(5, 1, 14, 2, 12)
+    vol = g["phore"].phoretype.sum(0)
+    g["ligand"].ph = vol.clone()                       # the ligand offers every feature the model asks for
+    assert abs(get_perfect_similarity(g) - 1.0) < 1e-6
+    g["ligand"].ph = torch.zeros(11)
+    assert get_perfect_similarity(g) == 0.0
+    half = vol.clone()
+    k = int(torch.nonzero(vol[:10])[0])
+    half[k] = 0
+    g["ligand"].ph = half
+    coeff = torch.tensor([1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0.]) * 7.999999999 * (torch.tensor([1.0, 1.0, 0.7, 1.0, 1.0, 0.7, 1.0, 1.0, 0.7, 1.0, 0.837]) * torch.pi / 2) ** 1.5
+    want = 1.0 - float(vol[k] * coeff[k] / (vol * coeff).sum())
+    assert abs(get_perfect_similarity(g) - want) < 1e-6
+    # Gaussian volume: the self-overlap constant and the 1/e distance
+    assert abs(ofit.gaussian_volume(1.0, 1.0, 0.0) - 7.999999999 * (np.pi / 2) ** 1.5) < 1e-12
+    assert abs(ofit.gaussian_volume(0.7, 0.7, 2 / 0.7) / ofit.gaussian_volume(0.7, 0.7, 0.0) - np.exp(-1)) < 1e-12
