@@ -30,7 +30,7 @@ from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn  # noqa: E402
 ALG_BYTES_PER_EDGE = {0: 2516, 1: 4636, 2: 6756, 3: 9236}      # 4*(numel + D_in + 9) per edge-conv, fp32
 ALG_FLOPS_PER_EDGE = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400}   # radial-MLP GEMM + TP
 MFMA_F32_PEAK_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
-MEASURED_TRAFFIC_BYTES = int((2 * 37665.2 + 6000.0) * 1024)       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, cfg2, this kernel+slot
+MEASURED_TRAFFIC_BYTES = int((2 * 37757.6 + 6000.0) * 1024)   # profiles/r1_conv_hbm_traffic.csv, layer-2 phore->lig launch
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 PROF_LAYER, PROF_CONV = 2, 1                                     # layer-2 phore->ligand conv: dense cross edge set
 

@@ -812,7 +812,7 @@ struct StageB {
       {
         // A-operand fetches as raw ds_read_b128 + hand-counted lgkmcnt.  With ordinary LDS loads the compiler cannot prove that
         // they do not alias the LDS-DMA destinations and puts an s_waitcnt vmcnt(0) in front of the first read of every tile,
-        // i.e. a full L2 round trip for the tile that was JUST requested (measured: 0.88 -> see profiles/r1_bf16_ablation.md).
+        // i.e. a full L2 round trip for the tile that was JUST requested (measured: 0.88 -> see profiles/r1_conv_ablation.md).
         bf16x8 W[NS];
         const unsigned la = lds_w + (TILE % R) * NQ * 16;
         OperandPipe<KIND, NS, 0>::run(la, W, hb, D);
