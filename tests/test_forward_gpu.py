@@ -283,3 +283,41 @@ def test_fit_complexes_driver_single_rank():
             ds = np.linalg.norm(p[s][ei[0]] - p[s][ei[1]], axis=1)
             np.testing.assert_allclose(ds, d0, atol=2e-4)
         assert np.abs(p[0] - p[1]).max() > 1e-2
+
+
+def test_hip_path_matches_reference_model_and_sampler_golden(golden_dir):
+    """The HIP path held DIRECTLY to outputs of the reference's own model / sampler code (tests/golden/make_model_golden.py;
+    third-party packages adapted onto the oracle's restatements there - see that file's header for what this does and does not pin)."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import randomize_position, sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import sampler as osampler
+    G = np.load(os.path.join(golden_dir, "ref_model_glue.npz"))
+    m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+    for ci in range(5):
+        seed, n, nl, nt, npn = (int(v) for v in G[f"case{ci}_spec"])
+        t = float(G[f"case{ci}_t"])
+        batch = Batch.from_data_list(synthetic.synthetic_pairs(seed, n, nl, nt, npn))
+        osampler.set_time_phore(batch, t, t, t, batch.num_graphs)
+        tr, rot, tor = m(batch)
+        assert _rel(tr, torch.from_numpy(G[f"case{ci}_tr"])) < 2e-4 and _rel(rot, torch.from_numpy(G[f"case{ci}_rot"])) < 2e-4
+        if tor.numel():
+            assert _rel(tor, torch.from_numpy(G[f"case{ci}_tor"])) < 2e-4
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    S = 4
+    sched = get_t_schedule(S)
+    for name, kw in (("sde", dict(ode=False)), ("ode", dict(ode=True)), ("sde_nofinal", dict(ode=False, no_final_step_noise=True))):
+        gs = synthetic.synthetic_pairs(97, 6, 18, 4, 20)
+        np.random.seed(7)
+        torch.manual_seed(7)
+        randomize_position(gs, False, False, args.tr_sigma_max)           # same global generators, same order as the reference
+        np.testing.assert_allclose(np.stack([g["ligand"].pos.numpy() for g in gs]), G[f"samp_{name}_start"], atol=5e-6)
+        res, _ = sampling_phore(gs, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, batch_size=3, **kw)
+        pos = np.stack([g["ligand"].pos.numpy() for g in res])
+        r = np.sqrt(((pos - G[f"samp_{name}_pos"]) ** 2).sum(-1).mean(-1))
+        print(name, "RMSD vs reference sampler (A):", r)
+        assert np.median(r) < 1e-4 and r.max() < 1e-3, r
+        nrm = np.stack([g["ligand"].norm.numpy().reshape(18, 33) for g in res])
+        assert np.abs(nrm - G[f"samp_{name}_norm"]).max() < 1e-3
