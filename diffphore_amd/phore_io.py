@@ -6,8 +6,9 @@ Restates /root/reference/src/datasets/process_pharmacophore.py:
                                                           exclusion sphere -> every node within `neighbor_cutoff`, nearest-neighbour fallback
     phore_featurizer                 :717-748             x = [type idx, is-EX idx, has-norm idx, alpha, weight]
 and the one-hot `phoretype` / centring of pdbbind_phore.py:1172-1184.  Pure text + numpy (no RDKit); the ligand half of
-the graph still needs the reference's RDKit featuriser.  Parity: unpinned (the reference module imports rdkit and cannot be
-imported here); checked against the node/edge counts SURVEY.md measured on the shipped example.
+the graph still needs the reference's RDKit featuriser.  Parity: pinned - `tests/golden/make_phore_golden.py` runs the reference's
+own three functions on the shipped example and two generated records; `tests/test_phore_io_cpu.py` compares features, coordinates,
+normals and the ordered edge list.
 """
 from __future__ import annotations
 

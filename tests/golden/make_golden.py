@@ -12,9 +12,9 @@ Outputs (data only: inputs and expected outputs; never reference source text):
     diffphore_amd/data/torus_score_norm.npy    reference `utils/torus.py:score_norm_`     (5001 f64, ONE Monte-Carlo draw,
                                                np.random.seed(20250321) set before the import; canonical for oracle+GPU)
 
-The score model (`models/score_model_phore.py`) and `utils/sampling.py` cannot be imported here: e3nn,
-torch_scatter, torch_cluster, torch_geometric and rdkit are absent.  Only the conformer-update half of
-the hot path is pinned by these fixtures; the e3nn-defined half stays "parity unpinned".
+The score model (`models/score_model_phore.py`) and `utils/sampling.py` need e3nn, torch_scatter, torch_cluster, torch_geometric
+and rdkit, which are absent: their golden vectors come from `make_model_golden.py`, which runs the reference's
+model / sampler code with those packages adapted onto the oracle's restatements (and says what that does and does not pin).
 
 `torch_geometric` is stubbed in sys.modules purely so `utils/torsion.py` and `utils/diffusion_utils.py` import; none
 of the stubbed symbols is called by the functions exercised here.

@@ -52,3 +52,20 @@ def test_shipped_example_counts():
     # 5 features + 74 exclusion spheres = 79 nodes, 811 phore-phore edges
     assert len(ph.features) == 5 and len(ph.exclusion_volumes) == 74
     assert g["pos"].shape == (79, 3) and g["edge_index"].shape == (2, 811)
+
+
+def test_parser_and_graph_match_reference_code(golden_dir):
+    """`phore_io` against the reference's own `parse_phore` + `get_phore_graph` + `phore_featurizer`
+    (tests/golden/make_phore_golden.py): node features, coordinates, unit normals and the directed edge list, in order."""
+    G = np.load(os.path.join(golden_dir, "ref_phore_graph.npz"))
+    phs = phore_io.parse_phore(os.path.join(golden_dir, "sQC_QFA_complex.phore")) + phore_io.parse_phore_text(str(G["generated_text"]))
+    assert len(phs) == int(G["n_graphs"]) == 3
+    for k, ph in enumerate(phs):
+        assert ph.id == str(G[f"g{k}_id"])
+        g = phore_io.phore_graph(ph)
+        np.testing.assert_allclose(np.asarray(g["x"], dtype=np.float64), G[f"g{k}_x"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(g["pos"], G[f"g{k}_pos"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(g["norm"], G[f"g{k}_norm"], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(np.asarray(g["edge_index"]), G[f"g{k}_edge_index"])
+        # phoretype (set by the dataset class in the reference, pdbbind_phore.py) is the one-hot of x[:, 0]
+        assert (np.asarray(g["phoretype"]).argmax(1) == G[f"g{k}_x"][:, 0].astype(int)).all()
