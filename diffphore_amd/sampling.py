@@ -289,14 +289,26 @@ def sampling_phore_with_fitscore(data_list, model, inference_steps, tr_schedule,
         noisy = not (ode or no_random or last)
         cand_pos, cand_norm = [], []
         pos0, norm0 = pb.pos.clone(), pb.norm.clone()
+        drawn = None
+        if noisy and noise is None:
+            # the reference's draw order (:352-381): per `batch_size` chunk  tr_z [R,b,3], rot_z [R,b,3], tor_z [R, sum T of the chunk]
+            ztr, zrot, ztor = [], [], []
+            for lo in range(0, N, batch_size):
+                b_ = min(batch_size, N - lo)
+                shp = (reps, b_, 3) if reps > 1 else (b_, 3)
+                ztr.append(torch.normal(mean=0, std=1, size=shp).reshape(reps, b_, 3))
+                zrot.append(torch.normal(mean=0, std=1, size=shp).reshape(reps, b_, 3))
+                tc = int(pb.nt[lo:lo + b_].sum())
+                if not no_torsion:
+                    ztor.append(torch.normal(mean=0, std=1, size=(reps, tc) if reps > 1 else (tc,)).reshape(reps, tc))
+            drawn = (torch.cat(ztr, 1), torch.cat(zrot, 1), torch.cat(ztor, 1) if ztor else torch.zeros(reps, 0))
         for j in range(reps):
             z_tr = z_rot = z_tor = None
             if noisy:
                 if noise is not None:
                     z_tr, z_rot, z_tor = noise["tr"][t_idx][j], noise["rot"][t_idx][j], noise["tor"][t_idx][j]
                 else:
-                    z_tr, z_rot = torch.normal(mean=0, std=1, size=(N, 3)), torch.normal(mean=0, std=1, size=(N, 3))
-                    z_tor = torch.normal(mean=0, std=1, size=(nT,))
+                    z_tr, z_rot, z_tor = drawn[0][j], drawn[1][j], drawn[2][j]
                 z_tr, z_rot = z_tr.to(dev, torch.float32).contiguous(), z_rot.to(dev, torch.float32).contiguous()
                 z_tor = z_tor.to(dev, torch.float32).contiguous() if (not no_torsion and nT) else None
             if j:

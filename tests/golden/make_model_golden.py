@@ -273,6 +273,32 @@ def main():
         out[f"samp_{name}_pos"] = np.stack([g["ligand"].pos.numpy() for g in res])
         out[f"samp_{name}_norm"] = np.stack([np.asarray(g["ligand"].norm).reshape(18, 33) for g in res])
         print(f"sampler {name}: moved {np.abs(out[f'samp_{name}_pos'] - out[f'samp_{name}_start']).max():.3f} A")
+    # ---- the reference's `sample_step` and `sampling_phore_with_fitscore` (non-branching paths) -------------------
+    import copy
+    gs = synthetic.synthetic_pairs(311, 5, 16, 3, 14)
+    batch = Batch.from_data_list(gs)
+    t = 0.4
+    set_time_phore(batch, t, t, t, batch.num_graphs, "cpu")
+    torch.manual_seed(11)
+    with torch.no_grad():
+        dl, tor_p, tr_p, rot_p = ref_sampling.sample_step(batch, model, args, *t_to_sigma(t, t, t), delta_t=0.07)
+    out["step_pos"] = np.stack([g["ligand"].pos.numpy() for g in dl])
+    out["step_tr"], out["step_rot"], out["step_tor"] = tr_p.numpy(), rot_p.numpy(), np.asarray(tor_p)
+    for name, a2, kw in (("fs_sde", args, dict(ode=False)), ("fs_ode_notor", Namespace(**{**vars(args), "no_torsion": True}), dict(ode=True))):
+        gs = synthetic.synthetic_pairs(97, 6, 18, 4, 20)
+        for g in gs:
+            g["ligand"].mask_rotate = [np.asarray(g["ligand"].mask_rotate)]
+        np.random.seed(9)
+        torch.manual_seed(9)
+        ref_sampling.randomize_position(gs, False, False, args.tr_sigma_max)
+        for g in gs:
+            g["ligand"].mask_rotate = g["ligand"].mask_rotate[0]
+        out[f"{name}_start"] = np.stack([g["ligand"].pos.numpy() for g in gs])
+        with torch.no_grad():
+            res, _ = ref_sampling.sampling_phore_with_fitscore(gs, model, S, sched, sched, sched, torch.device("cpu"), t_to_sigma, a2,
+                                                               batch_size=3, **kw)
+        out[f"{name}_pos"] = np.stack([g["ligand"].pos.numpy() for g in res])
+        print(f"with_fitscore {name}: moved {np.abs(out[f'{name}_pos'] - out[f'{name}_start']).max():.3f} A")
     np.savez_compressed(os.path.join(HERE, "ref_model_glue.npz"), **out)
     print("wrote", os.path.join(HERE, "ref_model_glue.npz"))
 

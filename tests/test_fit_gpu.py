@@ -266,3 +266,37 @@ def test_fit_overlap_surrogate_matches_its_oracle_and_ranks_on_device():
                                         fitscore_fn=host_score, noise=nz, no_final_step_noise=True)
     same = sum(bool(torch.equal(x["ligand"].pos, y["ligand"].pos)) for x, y in zip(a, b))
     assert same == len(gs2), same
+
+
+def test_sample_step_and_fitscore_sampler_match_reference_code(golden_dir):
+    """8f-4 against the reference's OWN `sample_step` / `sampling_phore_with_fitscore` (tests/golden/make_model_golden.py):
+    same global RNG seeding, same draw order; the ODE case pins the reference's un-squared translation coefficient (:344)."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import randomize_position, sample_step, sampling_phore_with_fitscore
+    from oracle import sampler as osampler
+    G = np.load(os.path.join(golden_dir, "ref_model_glue.npz"))
+    m = _model()
+    args = _args()
+    gs = synthetic.synthetic_pairs(311, 5, 16, 3, 14)
+    batch = Batch.from_data_list(gs)
+    t = 0.4
+    osampler.set_time_phore(batch, t, t, t, batch.num_graphs)
+    torch.manual_seed(11)
+    dl, tor_p, tr_p, rot_p = sample_step(batch, m, args, *t_to_sigma_fn(args)(t, t, t), delta_t=0.07)
+    np.testing.assert_allclose(tr_p.numpy(), G["step_tr"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(rot_p.numpy(), G["step_rot"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(tor_p, G["step_tor"], rtol=2e-4, atol=2e-5)
+    pos = np.stack([g["ligand"].pos.numpy() for g in dl])
+    assert np.sqrt(((pos - G["step_pos"]) ** 2).sum(-1).mean(-1)).max() < 2e-5
+    S = 4
+    sched = get_t_schedule(S)
+    for name, a2, kw in (("fs_sde", args, dict(ode=False)), ("fs_ode_notor", _args(no_torsion=True), dict(ode=True))):
+        gs = synthetic.synthetic_pairs(97, 6, 18, 4, 20)
+        np.random.seed(9)
+        torch.manual_seed(9)
+        randomize_position(gs, False, False, args.tr_sigma_max)
+        np.testing.assert_allclose(np.stack([g["ligand"].pos.numpy() for g in gs]), G[f"{name}_start"], atol=5e-6)
+        res, _ = sampling_phore_with_fitscore(gs, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(a2), a2, batch_size=3, **kw)
+        pos = np.stack([g["ligand"].pos.numpy() for g in res])
+        r = np.sqrt(((pos - G[f"{name}_pos"]) ** 2).sum(-1).mean(-1))
+        assert np.median(r) < 1e-4 and r.max() < 1e-3, (name, r)
