@@ -120,3 +120,21 @@ def test_pose_limits_are_enforced_before_any_launch():
     big["ligand"].pos = torch.zeros(n, 3)
     with pytest.raises(ValueError):
         PackedBatch([big], "cpu")
+
+
+def test_transformation_mask_matches_reference_code(golden_dir):
+    """`synthetic.transformation_mask` (which bonds rotate, which side moves) against the reference's own
+    `get_transformation_mask` run on the same bond lists (tests/golden/make_mask_golden.py)."""
+    import os
+    G = np.load(os.path.join(golden_dir, "ref_transformation_mask.npz"))
+    for k in range(int(G["n"])):
+        seed, n, t = (int(v) for v in G[f"m{k}_spec"])
+        lig = synthetic.make_ligand(np.random.default_rng(seed), n, t)
+        me, mr = synthetic.transformation_mask(n, np.asarray(lig["edge_index"]))
+        np.testing.assert_array_equal(me, G[f"m{k}_edges"])
+        np.testing.assert_array_equal(mr, G[f"m{k}_rotate"])
+        # the generator keeps a subset of those bonds as torsions, with the reference's rows for them
+        sel = np.asarray(lig["edge_mask"], dtype=bool)
+        assert (me[sel]).all() and sel.sum() == np.asarray(lig["mask_rotate"]).shape[0]
+        rows = np.cumsum(me) - 1
+        np.testing.assert_array_equal(np.asarray(lig["mask_rotate"]), mr[rows[sel]])
