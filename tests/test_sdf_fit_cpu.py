@@ -114,3 +114,22 @@ def test_perfect_similarity_and_surrogate_formula():
     # Gaussian volume: the self-overlap constant and the 1/e distance
     assert abs(ofit.gaussian_volume(1.0, 1.0, 0.0) - 7.999999999 * (np.pi / 2) ** 1.5) < 1e-12
     assert abs(ofit.gaussian_volume(0.7, 0.7, 2 / 0.7) / ofit.gaussian_volume(0.7, 0.7, 0.0) - np.exp(-1)) < 1e-12
+
+
+def test_fit_helpers_match_reference_code(golden_dir, tmp_path):
+    """`get_perfect_similarity` and `analyze_results` against the reference's own functions (tests/golden/make_fit_golden.py):
+    similarities to 1e-6, the csv files byte for byte."""
+    import torch
+    from diffphore_amd import synthetic
+    from diffphore_amd.fitness import get_perfect_similarity
+    G = np.load(os.path.join(golden_dir, "ref_fit_helpers.npz"))
+    for k in range(6):
+        (g,) = synthetic.synthetic_pairs(40 + k, 1, 14, 2, 10 + k)
+        g["ligand"].ph = torch.as_tensor(G[f"sim{k}_ph"])
+        assert abs(get_perfect_similarity(g) - float(G["sims"][k])) < 1e-6
+    res = {"name": ["t1__a", "t1__b", "t2__c", "t3__d"], "run_time": [1.0, 2.5, 3.0, 0.5],
+           "fitscore": [[0.1, 0.7, 0.3], [0.9, 0.2, 0.8, 0.1, 0.5, 0.6], [-2.0, -2.0], [0.7, 0.7, 0.1, 0.0, 0.2, 0.3]]}
+    args = types.SimpleNamespace(out_dir=str(tmp_path), cutoff=0.6)
+    fitmod.analyze_results(args, res)
+    assert open(tmp_path / "ranked_results.csv").read() == str(G["csv"])
+    assert open(tmp_path / "ranked_results_gt0.6.csv").read() == str(G["csv_cut"])
