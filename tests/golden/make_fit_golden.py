@@ -61,20 +61,66 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         pass
 
 
-def main():
-    from oracle import tables
+def _import_reference_inference():
+    """`import inference` with (a) the FUNCTIONAL adapters of make_model_golden.py for what the model / sampler path executes and
+    (b) permissive placeholders for every other absent package."""
+    sys.path.insert(0, HERE)
+    import make_model_golden as mm
+    so3, torus = mm.install_adapters()
+    dims = {k: getattr(sys.modules[k], a) for k, a in (("datasets.process_mols", "lig_feature_dims"), ("datasets.process_pharmacophore", "phore_feature_dims"))}
+    for k in [k for k in list(sys.modules) if k.split(".")[0] in ("rdkit", "spyrmsd", "datasets") or k in ("torch_geometric.nn", "torch_geometric.nn.data_parallel", "torch_geometric.data")]:
+        del sys.modules[k]
+    tg = sys.modules["torch_geometric"]
+    tg.__path__ = []
+    for a in ("nn", "data"):
+        if hasattr(tg, a):
+            delattr(tg, a)
     sys.meta_path.insert(0, _Finder())
     pkg = types.ModuleType("datasets")                       # the reference's package, not the installed HF one
     pkg.__path__ = [os.path.join(REF, "datasets")]
     sys.modules["datasets"] = pkg
+    for k, a in (("datasets.process_mols", "lig_feature_dims"), ("datasets.process_pharmacophore", "phore_feature_dims")):
+        m = _Module(k)          # everything else these two modules export is chemistry the driver path never executes
+        setattr(m, a, dims[k])
+        sys.modules[k] = m
+
+    from diffphore_amd.hetero import Batch
+
+    class DataLoader:            # torch_geometric.loader.DataLoader on the duck-typed graphs: in-order chunks, PyG-style collation
+        def __init__(self, dataset=None, batch_size=1, shuffle=False, **kw):
+            self.d, self.bs = dataset, batch_size
+
+        def __len__(self):
+            n = self.d.len() if hasattr(self.d, "len") else len(self.d)
+            return (n + self.bs - 1) // self.bs
+
+        def __iter__(self):
+            n = self.d.len() if hasattr(self.d, "len") else len(self.d)
+            get = self.d.get if hasattr(self.d, "get") else self.d.__getitem__
+            for lo in range(0, n, self.bs):
+                items = [get(i) for i in range(lo, min(lo + self.bs, n))]
+                for g in items:   # a batch-of-1 carries `mask_rotate` as [array]; modify_conformer un-nests exactly one level
+                    mr = g["ligand"].mask_rotate
+                    if isinstance(mr, list):
+                        g["ligand"].mask_rotate = mr[0]
+                b = Batch.from_data_list(items)
+                for a in ("name", "mol", "phore_file"):      # PyG collates python attributes into lists
+                    if all(a in g for g in items):
+                        setattr(b, a, [getattr(g, a) for g in items])
+                if all("original_center" in g for g in items):
+                    b.original_center = torch.cat([torch.as_tensor(g.original_center).reshape(-1, 3) for g in items])
+                yield b
+
+    mm._module("torch_geometric.loader", DataLoader=DataLoader, DataListLoader=_Inert)
     sys.path.insert(0, REF)
     import utils as up
-    for nm, fn in (("so3", lambda eps: torch.from_numpy(tables.so3_score_norm(eps.numpy()))), ("torus", lambda s: tables.torus_score_norm(s))):
-        m = types.ModuleType("utils." + nm)
-        m.score_norm = fn
-        sys.modules["utils." + nm] = m
-        setattr(up, nm, m)
+    up.so3, up.torus = so3, torus
     import inference as ref
+    return ref, mm
+
+
+def main():
+    ref, mm = _import_reference_inference()
 
     from diffphore_amd import synthetic
     out = {}
@@ -98,8 +144,43 @@ def main():
         ref.analyze_results(args, {k: list(v) for k, v in res.items()})
         out["csv"] = np.asarray(open(os.path.join(td, "ranked_results.csv")).read())
         out["csv_cut"] = np.asarray(open(os.path.join(td, "ranked_results_gt0.6.csv")).read())
-    np.savez_compressed(os.path.join(HERE, "ref_fit_helpers.npz"), **out)
     print(str(out["csv"]))
+
+    # ---- the driver itself: inference.py::fit around the reference model and sampler, AncPhore replaced by a geometric score ----
+    import json
+    import yaml
+    from argparse import Namespace
+    from functools import partial
+    margs = Namespace(**yaml.full_load(open("/root/reference/weights/diffphore_calibrated_warmuped_ft/model_parameters.yml")))
+    t_to_sigma = partial(ref.t_to_sigma_compl, args=margs)
+    model = ref.get_model(margs, torch.device("cpu"), t_to_sigma=t_to_sigma, no_parallel=True)
+    model.eval()
+    from diffphore_amd import weights
+    model.load_state_dict(weights.init_state_dict(), strict=True)
+
+    def fake_fitscore(args, ligand_pos, name, mol, phore_file=None, store_ranked_pose=True):
+        os.makedirs(os.path.join(args.run_dir, f"mapping_process/{name}"), exist_ok=True)     # calculate_fitscore does (sampling.py:462-463)
+        return [float(-np.linalg.norm(p.mean(0) - np.array([10.0, -3.0, 2.0]))) for p in ligand_pos]
+    ref.calculate_fitscore = fake_fitscore
+    gs = synthetic.synthetic_pairs(313, 3, 14, 3, 12)
+    for i, g in enumerate(gs):
+        g.name = f"tgt__lig{i}"
+        g.original_center = torch.tensor([[10.0 + i, -3.0, 2.0]])
+        g.mol = "placeholder-mol"
+        g.phore_file = "none.phore"
+    with tempfile.TemporaryDirectory() as td:
+        args = Namespace(**{**vars(margs), "run_dir": td, "sample_per_complex": 3, "inference_steps": 3, "overwrite": True, "save_single": False,
+                            "min_similarity": 0.0, "no_random": False, "ode": False, "batch_size": 20, "no_final_step_noise": True})
+        np.random.seed(13)
+        torch.manual_seed(13)
+        with torch.no_grad():
+            metrics = ref.fit(args, model, gs, torch.device("cpu"), t_to_sigma)
+        logs = [json.load(open(os.path.join(td, f"mapping_process/{n}/{n}_dock.log"))) for n in metrics["name"]]
+    out["fit_names"] = np.asarray(metrics["name"])
+    out["fit_scores"] = np.asarray(metrics["fitscore"], dtype=np.float64)
+    out["fit_log_scores"] = np.asarray([l["fitscore"] for l in logs], dtype=np.float64)
+    print("fit:", metrics["name"], out["fit_scores"])
+    np.savez_compressed(os.path.join(HERE, "ref_fit_helpers.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -300,3 +300,30 @@ def test_sample_step_and_fitscore_sampler_match_reference_code(golden_dir):
         pos = np.stack([g["ligand"].pos.numpy() for g in res])
         r = np.sqrt(((pos - G[f"{name}_pos"]) ** 2).sum(-1).mean(-1))
         assert np.median(r) < 1e-4 and r.max() < 1e-3, (name, r)
+
+
+def test_fit_driver_matches_reference_fit(golden_dir, tmp_path):
+    """8f-1 against the reference's OWN `inference.py::fit` run end to end in the build container (reference model + sampler,
+    AncPhore replaced by a geometric score; tests/golden/make_fit_golden.py).  One complex per launch so the global RNG is
+    consumed in the reference's order; the scores are centroid distances in A, so 1e-3 bounds the docked poses themselves."""
+    from diffphore_amd import fit as fitmod
+    from diffphore_amd.diffusion import t_to_sigma_fn
+    G = np.load(os.path.join(golden_dir, "ref_fit_helpers.npz"))
+    gs = synthetic.synthetic_pairs(313, 3, 14, 3, 12)
+    for i, g in enumerate(gs):
+        g.name = f"tgt__lig{i}"
+        g.original_center = torch.tensor([[10.0 + i, -3.0, 2.0]])
+    args = _args(run_dir=str(tmp_path), sample_per_complex=3, inference_steps=3, overwrite=True, batch_size=20, no_random=False, ode=False,
+                 no_final_step_noise=True, complexes_per_launch=1)
+
+    def scorer(a, dock_pose, name, g):
+        return [float(-np.linalg.norm(p.mean(0) - np.array([10.0, -3.0, 2.0]))) for p in dock_pose]
+    np.random.seed(13)
+    torch.manual_seed(13)
+    res = fitmod.fit(args, _model(), gs, "cuda", t_to_sigma_fn(args), scorer=scorer)
+    assert res["name"] == [str(n) for n in G["fit_names"]]
+    np.testing.assert_allclose(np.asarray(res["fitscore"]), G["fit_scores"], atol=1e-3)
+    for n, want in zip(res["name"], G["fit_log_scores"]):
+        log = json.load(open(os.path.join(tmp_path, f"mapping_process/{n}/{n}_dock.log")))
+        np.testing.assert_allclose(log["fitscore"], want, atol=1e-3)
+        assert set(log) == {"name", "fitscore", "run_time"}
