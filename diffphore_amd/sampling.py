@@ -57,7 +57,9 @@ def _draw_reference_order(N, T_per_pose: np.ndarray, batch_size: int):
 def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
                    no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
                    confidence_model_args=None, batch_size=20, no_final_step_noise=False, noise=None, engine: Optional[Engine] = None,
-                   write_back=True, max_poses: int = 8192):
+                   write_back=True, max_poses: int = 8192, timing: Optional[dict] = None):
+    import time as _time
+    _t0 = _time.time()
     if confidence_model is not None:
         raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
     N = len(data_list)
@@ -84,20 +86,36 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
         pb.set_state(torch.cat([g["ligand"].pos for g in data_list]), torch.cat([g["ligand"].norm.reshape(-1, 33) for g in data_list]))
     no_torsion = bool(getattr(model_args, "no_torsion", False))
     keep_update = bool(getattr(model_args, "keep_update", False))
+    # All normals of the run are drawn up front, in the reference's order (step-major, then per `batch_size` chunk: tr, rot, tor -
+    # nothing else consumes the generator inside the reference's loop), and uploaded once: the step loop then never touches the host.
+    noisy_steps = [t for t in range(inference_steps) if not (ode or no_random or (no_final_step_noise and t == inference_steps - 1))]
+    Z = None
+    if noisy_steps:
+        if noise is not None:
+            Z = {k: noise[k].to(dev, torch.float32) for k in ("tr", "rot", "tor")}
+        else:
+            d = [_draw_reference_order(N, pb.nt, batch_size) for _ in noisy_steps]
+            Z = {k: torch.zeros((inference_steps,) + tuple(d[0][i].shape)) for i, k in enumerate(("tr", "rot", "tor"))}
+            for t, dd in zip(noisy_steps, d):
+                for i, k in enumerate(("tr", "rot", "tor")):
+                    Z[k][t] = dd[i]
+            Z = {k: v.to(dev, torch.float32) for k, v in Z.items()}
+    # diffusion times of every step, uploaded once: inside the loop the host only enqueues launches
+    T_all = torch.stack([torch.tensor([float(tr_schedule[t]), float(rot_schedule[t]), float(tor_schedule[t])], dtype=torch.float32)
+                         for t in range(inference_steps)]).to(dev)
+    if timing is not None:
+        torch.cuda.synchronize()
+        timing["pack_and_noise_s"] = _time.time() - _t0
+        _t0 = _time.time()
     for t_idx in range(inference_steps):
         last = t_idx == inference_steps - 1
         zero = no_random or (no_final_step_noise and last)
         sp = _step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero)
-        pb.set_time(float(tr_schedule[t_idx]), float(rot_schedule[t_idx]), float(tor_schedule[t_idx]))
+        pb.t.copy_(T_all[t_idx].expand(pb.B, 3))
         z_tr = z_rot = z_tor = None
         if not (ode or zero):
-            if noise is not None:
-                z_tr, z_rot, z_tor = noise["tr"][t_idx], noise["rot"][t_idx], noise["tor"][t_idx]
-            else:
-                z_tr, z_rot, z_tor = _draw_reference_order(N, pb.nt, batch_size)
-            z_tr = z_tr.to(dev, torch.float32).contiguous()
-            z_rot = z_rot.to(dev, torch.float32).contiguous()
-            z_tor = z_tor.to(dev, torch.float32).contiguous() if (not no_torsion and z_tor.numel()) else None
+            z_tr, z_rot, z_tor = Z["tr"][t_idx].contiguous(), Z["rot"][t_idx].contiguous(), Z["tor"][t_idx].contiguous()
+            z_tor = z_tor if (not no_torsion and z_tor.numel()) else None
         eng.sample_step(sp, z_tr, z_rot, z_tor)
         if keep_update:
             _record_updates(data_list, eng, sp, z_tr, z_rot, z_tor, no_torsion)
@@ -106,6 +124,10 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             for idx, vis in enumerate(visualization_list):
                 lo, hi = int(pb.lig_ptr[idx]), int(pb.lig_ptr[idx + 1])
                 vis.add((pos[lo:hi] + data_list[idx].original_center).detach().cpu(), part=1, order=t_idx + 2)
+    if timing is not None:
+        torch.cuda.synchronize()
+        timing["loop_s"] = _time.time() - _t0
+        _t0 = _time.time()
     if write_back:
         status = eng.ws.t["status"].cpu()
         if bool((status != 0).any()):
@@ -116,6 +138,8 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
             g["ligand"].pos = pos[lo:hi].clone()
             g["ligand"].norm = norm[lo:hi].clone()
+    if timing is not None:
+        timing["write_back_s"] = _time.time() - _t0
     return data_list, None
 
 
