@@ -54,59 +54,26 @@ def _draw_reference_order(N, T_per_pose: np.ndarray, batch_size: int):
     return torch.cat(ztr), torch.cat(zrot), torch.cat(ztor)
 
 
-def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
-                   no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
-                   confidence_model_args=None, batch_size=20, no_final_step_noise=False, noise=None, engine: Optional[Engine] = None,
-                   write_back=True, max_poses: int = 8192, timing: Optional[dict] = None):
-    import time as _time
-    _t0 = _time.time()
-    if confidence_model is not None:
-        raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
-    N = len(data_list)
-    if N > max_poses and engine is None:
-        # Device-batch the pose list.  Poses are independent, so results are unchanged; with noise=None the global RNG stream
-        # is consumed chunk-major instead of step-major (the reference never runs more than `--sample_per_complex` poses at once).
-        if visualization_list is not None:
-            raise NotImplementedError("visualization_list with more than max_poses poses")
-        t_off = 0
-        for lo in range(0, N, max_poses):
-            part = data_list[lo:lo + max_poses]
-            nt_part = sum(int(torch.as_tensor(g["ligand"].edge_mask).sum()) for g in part)
-            sub = None if noise is None else {"tr": noise["tr"][:, lo:lo + max_poses], "rot": noise["rot"][:, lo:lo + max_poses],
-                                              "tor": noise["tor"][:, t_off:t_off + nt_part]}
-            sampling_phore(part, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
-                           no_random=no_random, ode=ode, batch_size=batch_size, no_final_step_noise=no_final_step_noise, noise=sub,
-                           write_back=write_back, max_poses=max_poses)
-            t_off += nt_part
-        return data_list, None
-    eng = engine if engine is not None else Engine(model.device_model, PackedBatch(data_list, device))
-    pb = eng.pb
-    dev = pb.device
-    if engine is not None:   # caller-managed engine: refresh the diffusion state from data_list
-        pb.set_state(torch.cat([g["ligand"].pos for g in data_list]), torch.cat([g["ligand"].norm.reshape(-1, 33) for g in data_list]))
+def _noisy_steps(inference_steps, ode, no_random, no_final_step_noise):
+    return [t for t in range(inference_steps) if not (ode or no_random or (no_final_step_noise and t == inference_steps - 1))]
+
+
+def _host_stage(part, device, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise):
+    """Everything that needs no device: pack the graphs, draw the run's normals (reference order), tabulate the times."""
+    pb = PackedBatch(part, device, upload=False)
+    return _host_stage_noise_only(pb, len(part), inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random,
+                                  no_final_step_noise, batch_size, noise)
+
+
+def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, no_random, ode,
+                 no_final_step_noise, visualization_list):
+    """Upload the run's noise / times and enqueue every step; no host synchronisation unless keep_update / visualisation ask for it."""
+    pb, dev = eng.pb, eng.pb.device
     no_torsion = bool(getattr(model_args, "no_torsion", False))
     keep_update = bool(getattr(model_args, "keep_update", False))
-    # All normals of the run are drawn up front, in the reference's order (step-major, then per `batch_size` chunk: tr, rot, tor -
-    # nothing else consumes the generator inside the reference's loop), and uploaded once: the step loop then never touches the host.
-    noisy_steps = [t for t in range(inference_steps) if not (ode or no_random or (no_final_step_noise and t == inference_steps - 1))]
-    Z = None
-    if noisy_steps:
-        if noise is not None:
-            Z = {k: noise[k].to(dev, torch.float32) for k in ("tr", "rot", "tor")}
-        else:
-            d = [_draw_reference_order(N, pb.nt, batch_size) for _ in noisy_steps]
-            Z = {k: torch.zeros((inference_steps,) + tuple(d[0][i].shape)) for i, k in enumerate(("tr", "rot", "tor"))}
-            for t, dd in zip(noisy_steps, d):
-                for i, k in enumerate(("tr", "rot", "tor")):
-                    Z[k][t] = dd[i]
-            Z = {k: v.to(dev, torch.float32) for k, v in Z.items()}
-    # diffusion times of every step, uploaded once: inside the loop the host only enqueues launches
-    T_all = torch.stack([torch.tensor([float(tr_schedule[t]), float(rot_schedule[t]), float(tor_schedule[t])], dtype=torch.float32)
-                         for t in range(inference_steps)]).to(dev)
-    if timing is not None:
-        torch.cuda.synchronize()
-        timing["pack_and_noise_s"] = _time.time() - _t0
-        _t0 = _time.time()
+    if Z is not None:
+        Z = {k: v.to(dev, torch.float32) for k, v in Z.items()}
+    T_all = T_all.to(dev)
     for t_idx in range(inference_steps):
         last = t_idx == inference_steps - 1
         zero = no_random or (no_final_step_noise and last)
@@ -118,29 +85,96 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             z_tor = z_tor if (not no_torsion and z_tor.numel()) else None
         eng.sample_step(sp, z_tr, z_rot, z_tor)
         if keep_update:
-            _record_updates(data_list, eng, sp, z_tr, z_rot, z_tor, no_torsion)
+            _record_updates(part, eng, sp, z_tr, z_rot, z_tor, no_torsion)
         if visualization_list is not None:
             pos = pb.pos.cpu()
             for idx, vis in enumerate(visualization_list):
                 lo, hi = int(pb.lig_ptr[idx]), int(pb.lig_ptr[idx + 1])
-                vis.add((pos[lo:hi] + data_list[idx].original_center).detach().cpu(), part=1, order=t_idx + 2)
-    if timing is not None:
-        torch.cuda.synchronize()
-        timing["loop_s"] = _time.time() - _t0
-        _t0 = _time.time()
-    if write_back:
-        status = eng.ws.t["status"].cpu()
-        if bool((status != 0).any()):
-            # the reference raises from torch.linalg.svd and the caller string-matches this text (inference.py:211)
-            raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status).flatten().tolist()}")
-        pos, norm = pb.pos.cpu(), pb.norm.cpu()
-        for i, g in enumerate(data_list):
-            lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
-            g["ligand"].pos = pos[lo:hi].clone()
-            g["ligand"].norm = norm[lo:hi].clone()
+                vis.add((pos[lo:hi] + part[idx].original_center).detach().cpu(), part=1, order=t_idx + 2)
+
+
+def _finish_run(eng, part):
+    pb = eng.pb
+    status = eng.ws.t["status"].cpu()
+    if bool((status != 0).any()):
+        # the reference raises from torch.linalg.svd and the caller string-matches this text (inference.py:211)
+        raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status).flatten().tolist()}")
+    pos, norm = pb.pos.cpu(), pb.norm.cpu()
+    for i, g in enumerate(part):
+        lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
+        g["ligand"].pos = pos[lo:hi].clone()
+        g["ligand"].norm = norm[lo:hi].clone()
+
+
+def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
+                   no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
+                   confidence_model_args=None, batch_size=20, no_final_step_noise=False, noise=None, engine: Optional[Engine] = None,
+                   write_back=True, max_poses: int = 8192, timing: Optional[dict] = None):
+    import time as _time
+    if confidence_model is not None:
+        raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
+    N = len(data_list)
+    common = (inference_steps, tr_schedule, rot_schedule, tor_schedule)
+    if engine is not None:   # caller-managed engine: refresh the diffusion state from data_list, one device batch
+        engine.pb.set_state(torch.cat([g["ligand"].pos for g in data_list]), torch.cat([g["ligand"].norm.reshape(-1, 33) for g in data_list]))
+        _, Z, T_all = _host_stage_noise_only(engine.pb, N, *common, ode, no_random, no_final_step_noise, batch_size, noise)
+        _enqueue_run(engine, Z, T_all, data_list, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list)
+        if write_back:
+            _finish_run(engine, data_list)
+        return data_list, None
+    if N > max_poses and visualization_list is not None:
+        raise NotImplementedError("visualization_list with more than max_poses poses")
+    # Device-batch the pose list (`max_poses` per batch).  Poses are independent, so results do not depend on the batching; with
+    # noise=None the global RNG stream is consumed batch-major instead of step-major when there is more than one batch (the
+    # reference never runs more than `--sample_per_complex` poses at once).  The host stage of batch k+1 (packing, noise) runs
+    # while the GPU works on batch k: the step loop is enqueued without any host synchronisation.
+    parts, subs, t_off = [], [], 0
+    for lo in range(0, N, max_poses):
+        part = data_list[lo:lo + max_poses]
+        nt_part = sum(int(torch.as_tensor(g["ligand"].edge_mask).sum()) for g in part) if (noise is not None and N > max_poses) else 0
+        subs.append(noise if (noise is None or N <= max_poses) else
+                    {"tr": noise["tr"][:, lo:lo + max_poses], "rot": noise["rot"][:, lo:lo + max_poses], "tor": noise["tor"][:, t_off:t_off + nt_part]})
+        parts.append(part)
+        t_off += nt_part
+    _t0 = _time.time()
+    stage = _host_stage(parts[0], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[0])
+    for k, part in enumerate(parts):
+        pb, Z, T_all = stage
+        eng = Engine(model.device_model, pb.upload())
+        if timing is not None and k == 0:
+            torch.cuda.synchronize()
+            timing["pack_and_noise_s"] = _time.time() - _t0
+            _t0 = _time.time()
+        _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list)
+        stage = _host_stage(parts[k + 1], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[k + 1]) if k + 1 < len(parts) else None
+        if timing is not None and k == len(parts) - 1:
+            torch.cuda.synchronize()
+            timing["loop_s"] = _time.time() - _t0
+            _t0 = _time.time()
+        if write_back:
+            _finish_run(eng, part)
     if timing is not None:
         timing["write_back_s"] = _time.time() - _t0
     return data_list, None
+
+
+def _host_stage_noise_only(pb, N, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise):
+    """`_host_stage` for an already packed batch."""
+    steps = _noisy_steps(inference_steps, ode, no_random, no_final_step_noise)
+    Z = None
+    if steps:
+        if noise is not None:
+            Z = {k: noise[k].to(torch.float32) for k in ("tr", "rot", "tor")}
+        else:
+            # step-major, then per `batch_size` chunk: tr, rot, tor - nothing else consumes the generator inside the reference's loop
+            d = [_draw_reference_order(N, pb.nt, batch_size) for _ in steps]
+            Z = {k: torch.zeros((inference_steps,) + tuple(d[0][i].shape)) for i, k in enumerate(("tr", "rot", "tor"))}
+            for t, dd in zip(steps, d):
+                for i, k in enumerate(("tr", "rot", "tor")):
+                    Z[k][t] = dd[i]
+    T_all = torch.stack([torch.tensor([float(tr_schedule[t]), float(rot_schedule[t]), float(tor_schedule[t])], dtype=torch.float32)
+                         for t in range(inference_steps)])
+    return pb, Z, T_all
 
 
 def _record_updates(data_list, eng, sp, z_tr, z_rot, z_tor, no_torsion):

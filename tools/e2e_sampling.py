@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--precision", default="f32")
+    ap.add_argument("--max-poses", type=int, default=8192, help="device batch size (several batches are pipelined)")
     a = ap.parse_args()
     c = synthetic.CONFIGS[a.config]
     gs = synthetic.synthetic_pairs(20250321 + a.config, a.poses, c["n_atoms"], c["n_tor"], c["n_phore"])
@@ -38,7 +39,7 @@ def main():
         randomize_position(dl, False, False, args.tr_sigma_max)
         t1 = time.time()
         tm = {}
-        sampling_phore(dl, m, a.steps, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, batch_size=20, timing=tm)
+        sampling_phore(dl, m, a.steps, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, batch_size=20, timing=tm, max_poses=a.max_poses)
         torch.cuda.synchronize()
         t2 = time.time()
         out = dict(poses=a.poses, steps=a.steps, config=a.config, precision=a.precision, randomize_s=t1 - t0, sampling_s=t2 - t1,
