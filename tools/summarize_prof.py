@@ -32,7 +32,7 @@ def main():
     cur = con.cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     out = [f"# rocprofv3 --kernel-trace --stats summary ({tag}); durations in microseconds",
-           "# command: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 20 --warmup 3",
+           "# command: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-alt --steps 20 --warmup 3",
            "kernel,calls,total_us,avg_us,percent"]
     for n, c, t, a, p in rows:
         if p < 0.001:
