@@ -355,3 +355,39 @@ def test_sampler_without_any_torsion_and_no_torsion_flag():
             d0 = torch.cdist(g0["ligand"].pos, g0["ligand"].pos)
             d1 = torch.cdist(g1["ligand"].pos, g1["ligand"].pos)
             assert (d0 - d1).abs().max() < 2e-4
+
+
+def test_full_schedule_20_steps_matches_oracle():
+    """SURVEY.md 8c's parity definition, literally: the full 20-step schedule (BASELINE's inference_steps), final coordinates within
+    1e-4 A RMSD of the CPU oracle (fp64 score model) on the same weights, tables and pre-drawn noise."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import conformer, sampler as osampler
+    from scipy.spatial.transform import Rotation
+    gs = synthetic.synthetic_pairs(501, 8, 30, 8, 32)
+    rng = np.random.default_rng(11)
+    draws = [dict(tor=rng.uniform(-np.pi, np.pi, size=int(g["ligand"].edge_mask.sum())),
+                  rot=Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix(),
+                  tr=torch.from_numpy(rng.normal(scale=2.0, size=(1, 3)).astype(np.float32))) for g in gs]
+    conformer.randomize_position(gs, False, False, 5.0, draws=draws)
+    for g in gs:
+        g["ligand"].norm = g["ligand"].norm.reshape(-1, 33)
+    S = 20
+    sched = get_t_schedule(S)
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    gen = torch.Generator().manual_seed(20)
+    nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
+    noise = dict(tr=torch.randn(S, len(gs), 3, generator=gen), rot=torch.randn(S, len(gs), 3, generator=gen), tor=torch.randn(S, nT, generator=gen))
+    sd, om = _model()
+    a, _ = osampler.sampling_phore(copy.deepcopy(gs), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=8, noise=noise,
+                                   no_final_step_noise=True)
+    for prec in ("f32", "bf16x6"):
+        m = TensorProductScoreModel(device="cuda", precision=prec).load_state_dict(sd)
+        b, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, batch_size=8, noise=noise,
+                              no_final_step_noise=True)
+        r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b)])
+        print(prec, "20-step per-pose RMSD (A):", r)
+        assert np.median(r) < 1e-4 and (r < 1e-3).sum() >= len(r) - 1, (prec, r)
