@@ -78,23 +78,22 @@ def fit_complexes(graphs: Sequence, model, args, samples_per_complex: int = 40, 
     import torch.distributed as dist
 
     from .diffusion import get_t_schedule, t_to_sigma_fn
-    from .sampling import randomize_position, sampling_phore
+    from .sampling import sampling_phore
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     idx, mine = shard_poses(graphs, rank, world)
     steps = int(getattr(args, "inference_steps", 20))
     sched = get_t_schedule(steps)
     out = []
-    # keep whole complexes together in a device batch
+    # One fused call: every device batch (whole complexes, <= max_poses poses) is packed once, randomised and sampled on the device,
+    # and the host stage of the next batch overlaps the device loop of the current one (sampling_phore's pipeline).
     per = max(1, max_poses // samples_per_complex)
-    for lo in range(0, len(mine), per):
-        block = mine[lo:lo + per]
-        data_list = [copy.deepcopy(g) for g in block for _ in range(samples_per_complex)]
-        randomize_position(data_list, getattr(args, "no_torsion", False), False, args.tr_sigma_max, device=device)
-        sampling_phore(data_list, model, steps, sched, sched, sched, device, t_to_sigma_fn(args), args,
-                       no_random=getattr(args, "no_random", False), ode=getattr(args, "ode", False), batch_size=batch_size,
-                       no_final_step_noise=getattr(args, "no_final_step_noise", False), max_poses=max(max_poses, len(data_list)))
-        for c in range(len(block)):
-            poses = data_list[c * samples_per_complex:(c + 1) * samples_per_complex]
-            out.append(torch.stack([p["ligand"].pos for p in poses]).numpy())
+    data_list = [g.sample_copy() if hasattr(g, "sample_copy") else copy.deepcopy(g) for g in mine for _ in range(samples_per_complex)]
+    sampling_phore(data_list, model, steps, sched, sched, sched, device, t_to_sigma_fn(args), args,
+                   no_random=getattr(args, "no_random", False), ode=getattr(args, "ode", False), batch_size=batch_size,
+                   no_final_step_noise=getattr(args, "no_final_step_noise", False), max_poses=per * samples_per_complex,
+                   randomize=dict(no_torsion=getattr(args, "no_torsion", False), no_random=False, tr_sigma_max=args.tr_sigma_max))
+    for c in range(len(mine)):
+        poses = data_list[c * samples_per_complex:(c + 1) * samples_per_complex]
+        out.append(torch.stack([p["ligand"].pos for p in poses]).numpy())
     return idx, out

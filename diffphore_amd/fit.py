@@ -59,16 +59,26 @@ def store_ranked_poses(args, dock_pose: np.ndarray, name: str, mol: Optional[sdf
                                        properties={"fitscore": np.array(scores)[perm]})
 
 
+def _pose_copy(g):
+    """One more sample of a complex (inference.py:183 deep-copies the graph; only the ligand state is ever written)."""
+    return g.sample_copy() if hasattr(g, "sample_copy") else copy.deepcopy(g)
+
+
 def _sample(args, model, graphs, N, device, t_to_sigma, sched):
-    data_list = [copy.deepcopy(g) for g in graphs for _ in range(N)]
-    randomize_position(data_list, args.no_torsion, False, args.tr_sigma_max, keep_update=getattr(args, "keep_traj", False),
-                       device=device)
-    initial = [g["ligand"].pos.cpu().numpy() for g in data_list] if getattr(args, "keep_update", False) else None
+    data_list = [_pose_copy(g) for g in graphs for _ in range(N)]
+    rz = dict(no_torsion=args.no_torsion, no_random=False, tr_sigma_max=args.tr_sigma_max, keep_update=getattr(args, "keep_traj", False))
+    initial = None
     t0 = time.time()
+    if getattr(args, "keep_update", False):        # the caller wants the randomised start poses back: two calls, like the reference
+        randomize_position(data_list, rz["no_torsion"], False, rz["tr_sigma_max"], keep_update=rz["keep_update"], device=device)
+        initial = [g["ligand"].pos.cpu().numpy() for g in data_list]
+        rz = None
+        t0 = time.time()
+    # otherwise randomisation is fused into the sampler call: packed once, randomised and sampled on the device (same RNG order)
     sampling_phore(data_list=data_list, model=model, inference_steps=args.inference_steps, tr_schedule=sched, rot_schedule=sched,
                    tor_schedule=sched, device=device, t_to_sigma=t_to_sigma, model_args=args, no_random=getattr(args, "no_random", False),
                    ode=getattr(args, "ode", False), batch_size=getattr(args, "batch_size", 20),
-                   no_final_step_noise=getattr(args, "no_final_step_noise", False), max_poses=max(8192, len(data_list)))
+                   no_final_step_noise=getattr(args, "no_final_step_noise", False), max_poses=max(8192, len(data_list)), randomize=rz)
     return data_list, initial, time.time() - t0
 
 

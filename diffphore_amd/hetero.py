@@ -94,6 +94,23 @@ class HeteroData:
             out._attrs[k] = copy.deepcopy(v, memo)
         return out
 
+    def sample_copy(self):
+        """A new pose of the same complex: shares every static tensor with `self`, owns only the ligand's diffusion state
+        (`pos`, `norm`).  What `copy.deepcopy(graph)` is used for in the reference's sampling drivers (inference.py:183), ~25x cheaper."""
+        out = type(self)()
+        for k, st in self._stores.items():
+            out._stores[k] = Store(st)
+        lig = out._stores.get("ligand")
+        if lig is not None:
+            for a in ("pos", "norm"):
+                if a in lig and torch.is_tensor(lig[a]):
+                    lig[a] = lig[a].clone()
+        out._attrs.update(self._attrs)
+        for a, v in vars(self).items():
+            if a not in ("_stores", "_attrs"):
+                object.__setattr__(out, a, v)
+        return out
+
     def to(self, device):
         for s in self._stores.values():
             for a, v in list(s.items()):

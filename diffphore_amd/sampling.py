@@ -58,11 +58,17 @@ def _noisy_steps(inference_steps, ode, no_random, no_final_step_noise):
     return [t for t in range(inference_steps) if not (ode or no_random or (no_final_step_noise and t == inference_steps - 1))]
 
 
-def _host_stage(part, device, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise):
-    """Everything that needs no device: pack the graphs, draw the run's normals (reference order), tabulate the times."""
+def _host_stage(part, device, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise,
+                randomize=None):
+    """Everything that needs no device: pack the graphs, draw the start randomisation (if asked) and then the run's normals - the
+    reference's order for one complex: randomize_position(...) first, sampling_phore(...) after - and tabulate the times."""
     pb = PackedBatch(part, device, upload=False)
+    rz = None
+    if randomize is not None:
+        rz = _randomize_draws(part, pb.nt, randomize["no_torsion"], randomize["no_random"], randomize["tr_sigma_max"],
+                              randomize.get("keep_update", False), randomize.get("draws"))
     return _host_stage_noise_only(pb, len(part), inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random,
-                                  no_final_step_noise, batch_size, noise)
+                                  no_final_step_noise, batch_size, noise) + (rz,)
 
 
 def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, no_random, ode,
@@ -109,7 +115,9 @@ def _finish_run(eng, part):
 def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
                    no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
                    confidence_model_args=None, batch_size=20, no_final_step_noise=False, noise=None, engine: Optional[Engine] = None,
-                   write_back=True, max_poses: int = 8192, timing: Optional[dict] = None):
+                   write_back=True, max_poses: int = 8192, timing: Optional[dict] = None, randomize: Optional[dict] = None):
+    """`randomize={'no_torsion','no_random','tr_sigma_max'[,'keep_update','draws']}` fuses `randomize_position` into the call: every
+    device batch is packed once, randomised on the device and sampled, without the pack / D2H / re-pack round trip of two calls."""
     import time as _time
     if confidence_model is not None:
         raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
@@ -117,6 +125,8 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
     common = (inference_steps, tr_schedule, rot_schedule, tor_schedule)
     if engine is not None:   # caller-managed engine: refresh the diffusion state from data_list, one device batch
         engine.pb.set_state(torch.cat([g["ligand"].pos for g in data_list]), torch.cat([g["ligand"].norm.reshape(-1, 33) for g in data_list]))
+        if randomize is not None:
+            raise ValueError("randomize= needs a batch packed by this call (engine=None)")
         _, Z, T_all = _host_stage_noise_only(engine.pb, N, *common, ode, no_random, no_final_step_noise, batch_size, noise)
         _enqueue_run(engine, Z, T_all, data_list, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list)
         if write_back:
@@ -137,16 +147,20 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
         parts.append(part)
         t_off += nt_part
     _t0 = _time.time()
-    stage = _host_stage(parts[0], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[0])
+    stage = _host_stage(parts[0], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[0], randomize)
     for k, part in enumerate(parts):
-        pb, Z, T_all = stage
-        eng = Engine(model.device_model, pb.upload())
+        pb, Z, T_all, rz = stage
+        pb.upload()
+        if rz is not None:
+            _randomize_launch(pb, *rz, randomize["no_torsion"])
+        eng = Engine(model.device_model, pb)
         if timing is not None and k == 0:
             torch.cuda.synchronize()
             timing["pack_and_noise_s"] = _time.time() - _t0
             _t0 = _time.time()
         _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list)
-        stage = _host_stage(parts[k + 1], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[k + 1]) if k + 1 < len(parts) else None
+        stage = (_host_stage(parts[k + 1], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[k + 1], randomize)
+                 if k + 1 < len(parts) else None)
         if timing is not None and k == len(parts) - 1:
             torch.cuda.synchronize()
             timing["loop_s"] = _time.time() - _t0
@@ -196,38 +210,53 @@ def _record_updates(data_list, eng, sp, z_tr, z_rot, z_tor, no_torsion):
             setattr(g, name, prev + [val])
 
 
-def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, keep_update=False, device="cuda", draws=None):
-    """sampling.py:16-63.  Random numbers come from the same global generators, in the same order, as the reference
-    (np.random.uniform per graph, then per graph scipy `R.random()` and `torch.normal`); the geometry runs in
-    `dp_randomize_position`.  `draws` (list of dicts 'tor','rot','tr') overrides the RNG for reproducible tests."""
-    L = _declare()
-    L.dp_randomize_position.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]
-    L.dp_randomize_position.restype = C.c_int
-    pb = PackedBatch(data_list, device)
+def _randomize_draws(data_list, nt, no_torsion, no_random, tr_sigma_max, keep_update=False, draws=None):
+    """Host half of `randomize_position`: the reference's global-generator calls in its order (np.random.uniform per graph, then
+    per graph scipy `R.random()` and `torch.normal`, sampling.py:32-57).  Returns CPU tensors (theta | None, rot [N,3,3], tr | None)."""
     thetas, rots, trs = [], [], []
     if not no_torsion:
         for i, g in enumerate(data_list):
-            T = int(pb.nt[i])
+            T = int(nt[i])
             th = draws[i]["tor"] if draws is not None else np.random.uniform(low=-np.pi, high=np.pi, size=T)
-            thetas.append(torch.as_tensor(np.asarray(th), dtype=torch.float64))
+            thetas.append(np.asarray(th, dtype=np.float64).reshape(-1))
             if keep_update:
                 g.fw_tor_update = np.asarray(th)
     for i, g in enumerate(data_list):
         rot = draws[i]["rot"] if draws is not None else R.random().as_matrix()
-        rots.append(torch.from_numpy(np.asarray(rot)).float())
+        rots.append(np.asarray(rot, dtype=np.float32))
         if not no_random:
             tr = draws[i]["tr"] if draws is not None else torch.normal(mean=0, std=tr_sigma_max, size=(1, 3))
             trs.append(torch.as_tensor(tr).float().reshape(1, 3))
             if keep_update:
                 g.fw_tr_update = trs[-1].numpy()
         if keep_update:
-            g.fw_rot_update = rots[-1].numpy()
+            g.fw_rot_update = rots[-1]
+    theta = torch.from_numpy(np.concatenate(thetas).astype(np.float32)) if thetas and sum(t.size for t in thetas) else None
+    rm = torch.from_numpy(np.ascontiguousarray(np.stack(rots)))
+    tr = torch.cat(trs).contiguous() if trs else None
+    return theta, rm, tr
+
+
+def _randomize_launch(pb, theta, rm, tr, no_torsion):
+    """Device half: `dp_randomize_position` on an uploaded batch (state stays on the device)."""
+    L = _declare()
+    L.dp_randomize_position.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]
+    L.dp_randomize_position.restype = C.c_int
     dev = pb.device
-    theta = torch.cat(thetas).float().to(dev) if thetas and sum(t.numel() for t in thetas) else None
-    rm = torch.stack(rots).contiguous().to(dev)
-    tr = torch.cat(trs).contiguous().to(dev) if trs else None
+    theta = theta.to(dev) if theta is not None else None
+    rm = rm.to(dev)
+    tr = tr.to(dev) if tr is not None else None
     _lib.check(L.dp_randomize_position(C.byref(pb.struct), _lib.ptr(theta), rm.data_ptr(), _lib.ptr(tr), 1 if no_torsion else 0,
                                        _stream()), "dp_randomize_position")
+
+
+def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, keep_update=False, device="cuda", draws=None):
+    """sampling.py:16-63.  Random numbers come from the same global generators, in the same order, as the reference
+    (np.random.uniform per graph, then per graph scipy `R.random()` and `torch.normal`); the geometry runs in
+    `dp_randomize_position`.  `draws` (list of dicts 'tor','rot','tr') overrides the RNG for reproducible tests."""
+    pb = PackedBatch(data_list, device)
+    theta, rm, tr = _randomize_draws(data_list, pb.nt, no_torsion, no_random, tr_sigma_max, keep_update, draws)
+    _randomize_launch(pb, theta, rm, tr, no_torsion)
     pos, norm = pb.pos.cpu(), pb.norm.cpu()
     for i, g in enumerate(data_list):
         lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
