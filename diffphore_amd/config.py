@@ -11,7 +11,7 @@ The HIP kernels are specialised for exactly this configuration (ns=20, nv=10, 4 
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Tuple
 
 NS, NV = 20, 10

@@ -22,7 +22,7 @@ import copy
 import json
 import os
 import time
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, Optional, Sequence
 
 import numpy as np
 import torch

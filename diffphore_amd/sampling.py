@@ -13,7 +13,7 @@ Extra, optional keywords:
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 import torch

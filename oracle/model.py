@@ -19,7 +19,6 @@ from __future__ import annotations
 import math
 from typing import Dict, Optional
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

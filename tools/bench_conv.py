@@ -4,7 +4,6 @@ import argparse
 import ctypes as C
 import json
 
-import numpy as np
 import torch
 
 from diffphore_amd import _lib, packing, weights
