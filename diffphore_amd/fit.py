@@ -205,3 +205,105 @@ def analyze_results(args, results):
     if cutoff is not None:
         df[df["max_fitscore"] >= cutoff].to_csv(os.path.join(args.out_dir, f"ranked_results_gt{cutoff}.csv"), sep="\t", index=False)
     return df
+
+
+def inference_epoch(model, complex_graphs, device, t_to_sigma, args, scorer: Optional[Scorer] = None):
+    """`src/utils/training.py::inference_epoch` (:370-552) - the validation-time caller of the hot path: N samples per complex,
+    randomised start, reverse diffusion, heavy-atom RMSD of every sample to the reference pose (`orig_pos - original_center`,
+    no symmetry correction), success rates.  Same metrics dict (`rmsds_lt2`, `rmsds_lt5`, `rmsd`, `fitscore`, `run_time`,
+    `failed_indices`, `fitscore_gt0.7/0.4`, and `dock_process` when `args.keep_update`).  Like the reference it calls the sampler
+    with its DEFAULT keywords (batch_size 20, noise on every step), and switches to `sampling_phore_with_fitscore` when
+    `args.random_samples > 1` (then `scorer`-independent `args.fitscore_fn` must be set: AncPhore is not available).
+    Complexes are sampled `args.complexes_per_launch` (default 64) at a time; 1 reproduces the reference's RNG order."""
+    from .sampling import sampling_phore_with_fitscore
+    sched = get_t_schedule(inference_steps=args.inference_steps)
+    N = getattr(args, "sample_per_complex", 1)
+    per_launch = max(1, int(getattr(args, "complexes_per_launch", 64)))
+    keep = bool(getattr(args, "keep_update", False))
+    branching = getattr(args, "random_samples", 0) and args.random_samples > 1
+    rmsds, fitscore, run_times, names, failed_indices = [], [], [], [], []
+    rec = {k: [] for k in ("fw_tr_update", "fw_tor_update", "fw_rot_update", "rvs_tr_update", "rvs_tor_update", "rvs_rot_update",
+                           "origin_pos", "initial_pos", "perturb_pos", "docked_poses", "original_centers")}
+
+    def sample(graphs):
+        data_list = [_pose_copy(g) for g in graphs for _ in range(N)]
+        if keep or branching:
+            randomize_position(data_list, args.no_torsion, False, args.tr_sigma_max, keep_update=keep, device=device)
+            pert = [g["ligand"].pos.cpu().numpy() for g in data_list] if keep else None
+            if branching:
+                sampling_phore_with_fitscore(data_list, model, args.inference_steps, sched, sched, sched, device, t_to_sigma, args,
+                                             fitscore_fn=getattr(args, "fitscore_fn", None))
+            else:
+                sampling_phore(data_list, model, args.inference_steps, sched, sched, sched, device, t_to_sigma, args,
+                               max_poses=max(8192, len(data_list)))
+            return data_list, pert
+        sampling_phore(data_list, model, args.inference_steps, sched, sched, sched, device, t_to_sigma, args, max_poses=max(8192, len(data_list)),
+                       randomize=dict(no_torsion=args.no_torsion, no_random=False, tr_sigma_max=args.tr_sigma_max))
+        return data_list, None
+
+    def finish(i, g, poses, pert, dt):
+        name = _name(g)
+        run_times.append(dt)
+        center = torch.as_tensor(g.original_center).reshape(1, 3).cpu().numpy()
+        if args.no_torsion and "orig_pos" not in g["ligand"]:
+            g["ligand"].orig_pos = g["ligand"].pos.cpu().numpy() + center
+        orig = g["ligand"].orig_pos
+        orig = np.asarray(orig[0] if isinstance(orig, list) else orig)
+        filter_hs = torch.not_equal(g["ligand"].x[:, 0], 0).cpu().numpy()
+        ligand_pos = np.asarray([p["ligand"].pos.cpu().numpy()[filter_hs] for p in poses])
+        rmsds.append(np.sqrt(((ligand_pos - np.expand_dims(orig[filter_hs] - center, 0)) ** 2).sum(axis=2).mean(axis=1)))
+        if keep:
+            for k in ("fw_tr_update", "fw_tor_update", "fw_rot_update", "rvs_tr_update", "rvs_tor_update", "rvs_rot_update", "docked_poses"):
+                rec[k].append([getattr(p, k) if k in p else None for p in poses])
+            rec["initial_pos"].append(g["ligand"].pos.cpu().numpy())
+            rec["origin_pos"].append(orig)
+            rec["perturb_pos"].append(pert)
+            rec["original_centers"].append([center for _ in poses])
+            names.append(name)
+        if getattr(args, "fitscore", False):
+            scores = scorer(args, ligand_pos + center, name, g) if scorer is not None else None
+            if scores is None or len(scores) == 0:
+                fitscore.append([-2.0] * N)
+                print(f"[W] Warning fitscore calculated with error and set as -2.0 for `{name}`")
+            else:
+                fitscore.append([float(s) for s in scores])
+
+    todo = [i for i, g in enumerate(complex_graphs) if g["ligand"].pos.shape[0] > 0]
+    for lo in range(0, len(todo), per_launch):
+        group = todo[lo:lo + per_launch]
+        t0 = time.time()
+        try:
+            poses, pert = sample([complex_graphs[i] for i in group])
+            dt = (time.time() - t0) / len(group)
+            for c, i in enumerate(group):
+                finish(i, complex_graphs[i], poses[c * N:(c + 1) * N], pert[c * N:(c + 1) * N] if pert else None, dt)
+        except Exception as e:
+            if "failed to converge" not in str(e):
+                raise
+            for i in group:                                 # per-complex retry bookkeeping (:445-467)
+                failed = 0
+                while True:
+                    t0 = time.time()
+                    try:
+                        poses, pert = sample([complex_graphs[i]])
+                        finish(i, complex_graphs[i], poses, pert, time.time() - t0)
+                        break
+                    except Exception as e2:
+                        if "failed to converge" not in str(e2):
+                            raise
+                        failed += 1
+                        if failed > 5:
+                            print("| WARNING: SVD failed to converge 5 times - skipping the complex")
+                            failed_indices.append(i)
+                            break
+                        print("| WARNING: SVD failed to converge - trying again with a new sample")
+    rm = np.array(rmsds).reshape(-1, N) if N != 1 else np.array(rmsds).reshape(-1)
+    fs = np.array(fitscore).reshape(-1, N) if N != 1 else np.array(fitscore).reshape(-1)
+    metrics = {"rmsds_lt2": (100 * (rm < 2).sum() / max(len(rm), 1) / N), "rmsds_lt5": (100 * (rm < 5).sum() / max(len(rm), 1) / N),
+               "rmsd": rm.tolist(), "fitscore": fs.tolist(), "run_time": run_times, "failed_indices": failed_indices}
+    if len(fs) > 0:
+        metrics["fitscore_gt0.7"] = 100 * (fs > 0.7).sum() / len(fs)
+        metrics["fitscore_gt0.4"] = 100 * (fs > 0.4).sum() / len(fs)
+    if keep:
+        metrics["dock_process"] = dict(name=names, rmsd=rm, **rec)
+    return metrics

@@ -180,6 +180,21 @@ def main():
     out["fit_scores"] = np.asarray(metrics["fitscore"], dtype=np.float64)
     out["fit_log_scores"] = np.asarray([l["fitscore"] for l in logs], dtype=np.float64)
     print("fit:", metrics["name"], out["fit_scores"])
+    # ---- the validation-time caller: utils/training.py::inference_epoch (RMSD metrics), same adapters -----------------------
+    gs = synthetic.synthetic_pairs(314, 3, 14, 3, 12)
+    for i, g in enumerate(gs):
+        g.name = f"val__lig{i}"
+        g.original_center = torch.tensor([[1.0 + i, 2.0, -3.0]])
+        g["ligand"].orig_pos = g["ligand"].pos.numpy() + g.original_center.numpy()
+    eargs = Namespace(**{**vars(margs), "dataset": "pdbbind", "sample_per_complex": 3, "inference_steps": 3, "keep_update": False,
+                         "fitscore": False})
+    np.random.seed(17)
+    torch.manual_seed(17)
+    with torch.no_grad():
+        em = ref.inference_epoch(model, gs, torch.device("cpu"), t_to_sigma, eargs)
+    out["epoch_rmsd"] = np.asarray(em["rmsd"], dtype=np.float64)
+    out["epoch_lt2"], out["epoch_lt5"] = np.float64(em["rmsds_lt2"]), np.float64(em["rmsds_lt5"])
+    print("inference_epoch rmsd:", out["epoch_rmsd"], em["rmsds_lt2"], em["rmsds_lt5"], sorted(em))
     np.savez_compressed(os.path.join(HERE, "ref_fit_helpers.npz"), **out)
 
 

@@ -327,3 +327,30 @@ def test_fit_driver_matches_reference_fit(golden_dir, tmp_path):
         log = json.load(open(os.path.join(tmp_path, f"mapping_process/{n}/{n}_dock.log")))
         np.testing.assert_allclose(log["fitscore"], want, atol=1e-3)
         assert set(log) == {"name", "fitscore", "run_time"}
+
+
+def test_inference_epoch_matches_reference(golden_dir):
+    """The validation-time caller (`utils/training.py::inference_epoch`) against the reference's own function run in the build
+    container (tests/golden/make_fit_golden.py): per-sample RMSDs to 1e-3 A with the same global-RNG seeding, same metric keys."""
+    from diffphore_amd import fit as fitmod
+    from diffphore_amd.diffusion import t_to_sigma_fn
+    G = np.load(os.path.join(golden_dir, "ref_fit_helpers.npz"))
+    gs = synthetic.synthetic_pairs(314, 3, 14, 3, 12)
+    for i, g in enumerate(gs):
+        g.name = f"val__lig{i}"
+        g.original_center = torch.tensor([[1.0 + i, 2.0, -3.0]])
+        g["ligand"].orig_pos = g["ligand"].pos.numpy() + g.original_center.numpy()
+    args = _args(dataset="pdbbind", sample_per_complex=3, inference_steps=3, keep_update=False, fitscore=False, complexes_per_launch=1)
+    np.random.seed(17)
+    torch.manual_seed(17)
+    em = fitmod.inference_epoch(_model(), gs, "cuda", t_to_sigma_fn(args), args)
+    np.testing.assert_allclose(np.asarray(em["rmsd"]), G["epoch_rmsd"], atol=1e-3)
+    assert em["rmsds_lt2"] == float(G["epoch_lt2"]) and em["rmsds_lt5"] == float(G["epoch_lt5"])
+    assert sorted(em) == ["failed_indices", "fitscore", "rmsd", "rmsds_lt2", "rmsds_lt5", "run_time"] and em["failed_indices"] == []
+    # batched launch + keep_update bookkeeping + a scorer: shapes and invariants
+    args2 = _args(dataset="pdbbind", sample_per_complex=3, inference_steps=3, keep_update=True, fitscore=True, complexes_per_launch=8)
+    em2 = fitmod.inference_epoch(_model(), gs, "cuda", t_to_sigma_fn(args2), args2, scorer=lambda a, d, n, g: [0.8, 0.5, 0.1])
+    assert np.asarray(em2["rmsd"]).shape == (3, 3) and em2["fitscore_gt0.7"] == 100 * 3 / 3 and em2["fitscore_gt0.4"] == 100 * 6 / 3
+    dp = em2["dock_process"]
+    assert dp["name"] == [g.name for g in gs] and len(dp["docked_poses"][0][0]) == 3 and len(dp["perturb_pos"][0]) == 3
+    np.testing.assert_allclose(dp["docked_poses"][1][2][-1], dp["docked_poses"][1][2][-1])
