@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Random-shape soak of the HIP forward against the fp64 oracle: ligands of 2..70 atoms, 0..14 torsions, pharmacophores of 2..110
+nodes, mixed in random batches (`python tools/fuzz_shapes.py --batches 20`).  Prints the worst relative error per output."""
+import argparse
+
+import numpy as np
+import torch
+
+from diffphore_amd import config, synthetic, weights
+from diffphore_amd.hetero import Batch
+from diffphore_amd.score_model import TensorProductScoreModel
+from oracle import sampler as osampler
+from oracle.model import OracleScoreModel
+from oracle.tables import load_tables
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--precision", default="f32")
+    ap.add_argument("--only", type=int, default=-1, help="evaluate only this batch index (same random sequence), with per-pose detail")
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    sd = weights.init_state_dict()
+    om = OracleScoreModel(sd, config.ModelConfig(), dtype=torch.float64, tables=load_tables())
+    m = TensorProductScoreModel(device="cuda", precision=a.precision).load_state_dict(sd)
+    worst = dict(tr=0.0, rot=0.0, tor=0.0)
+    for bi in range(a.batches):
+        gs = []
+        for _ in range(int(rng.integers(1, 6))):
+            nl = int(rng.integers(2, 71))
+            nt = int(rng.integers(0, min(15, max(1, nl // 4))))
+            npn = int(rng.integers(2, 111))
+            for attempt in range(20):
+                try:
+                    gs += synthetic.synthetic_pairs(int(rng.integers(1 << 30)), 1, nl, nt, npn)
+                    break
+                except RuntimeError:
+                    nt = max(0, nt - 1)
+        batch = Batch.from_data_list(gs)
+        t = float(rng.uniform(0.02, 1.0))
+        if a.only >= 0 and bi != a.only:
+            continue
+        osampler.set_time_phore(batch, t, t, t, batch.num_graphs)
+        tr_o, rot_o, tor_o = om(batch)
+        tr, rot, tor = m(batch)
+        e = dict(tr=rel(tr, tr_o), rot=rel(rot, rot_o), tor=rel(tor, tor_o) if tor_o.numel() else 0.0)
+        shapes = [(int(g["ligand"].pos.shape[0]), int(g["ligand"].edge_mask.sum()), int(g["phore"].pos.shape[0])) for g in gs]
+        flag = "" if max(e.values()) < 3e-4 and np.isfinite(list(e.values())).all() else "   <<<<<<"
+        print(f"batch {bi:3d} t={t:.2f} shapes={shapes} err tr {e['tr']:.1e} rot {e['rot']:.1e} tor {e['tor']:.1e}{flag}", flush=True)
+        for k in worst:
+            worst[k] = max(worst[k], e[k])
+        if a.only >= 0:
+            om32 = OracleScoreModel(sd, config.ModelConfig(), dtype=torch.float32, tables=load_tables())
+            b2 = Batch.from_data_list(gs)
+            osampler.set_time_phore(b2, t, t, t, b2.num_graphs)
+            tr32, rot32, tor32 = om32(b2)
+            print("per-pose |tr - tr_oracle64|:", (tr.cpu().double() - tr_o).abs().max(1).values.numpy(), " oracle32 vs 64:", (tr32.double() - tr_o).abs().max(1).values.numpy())
+            print("per-pose |rot - rot_oracle64|:", (rot.cpu().double() - rot_o).abs().max(1).values.numpy(), " oracle32 vs 64:", (rot32.double() - rot_o).abs().max(1).values.numpy())
+            print("tr_o:", tr_o.numpy(), "\nrot_o:", rot_o.numpy())
+            print("nan in oracle:", bool(torch.isnan(tr_o).any()), " nan in hip:", bool(torch.isnan(tr).any()))
+    print("worst:", worst)
+
+
+if __name__ == "__main__":
+    main()
