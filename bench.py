@@ -83,9 +83,9 @@ def main():
     ap.add_argument("--poses", type=int, default=512, help="poses per GPU")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x9", "bf16x3"],
                     help="arithmetic of the radial-MLP contraction; the headline value uses exact fp32 MFMA")
-    ap.add_argument("--no-alt", action="store_true", help="skip the informational bf16x6 pass")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational split-bf16 passes")
     ap.add_argument("--cpu-poses", type=int, default=40)
     ap.add_argument("--cpu-steps", type=int, default=4)
     a = ap.parse_args()
@@ -187,13 +187,17 @@ def main():
     pb = pb0
     alt = None
     if not a.no_alt and a.precision == "f32":
-        alt_model = DeviceModel(sd, cfg, dev, precision="bf16x6")
-        if world > 1:
-            dist.broadcast(alt_model.blob, src=0)
-        el2, k2, bad2, fin2 = timed_run(alt_model)
-        alt = {"precision": "bf16x6 (3-way bf16 operand split, 6 products, fp32 accumulate; passes the same parity tolerances)",
-               "value": B * world * a.steps / el2, "ms_per_step": el2 / a.steps * 1e3, "kernel_ms": k2, "finite": fin2,
-               "kabsch_flagged_poses": bad2}
+        # informational passes with the radial GEMM on the bf16 matrix pipe by operand splitting (never the headline `value`)
+        alt = []
+        for prec, what in (("bf16x9", "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
+                           ("bf16x6", "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances")):
+            alt_model = DeviceModel(sd, cfg, dev, precision=prec)
+            if world > 1:
+                dist.broadcast(alt_model.blob, src=0)
+            el2, k2, bad2, fin2 = timed_run(alt_model)
+            alt.append({"precision": f"{prec} ({what})", "value": B * world * a.steps / el2, "ms_per_step": el2 / a.steps * 1e3,
+                        "kernel_ms": k2, "finite": fin2, "kabsch_flagged_poses": bad2})
+            del alt_model
 
     n_x = int(pb.x_ptr[-1])
     alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
@@ -217,7 +221,7 @@ def main():
                        "poses_per_gpu": B, "poses_per_sec_at_20_steps": total_poses * a.steps / elapsed / 20.0,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
                        "kabsch_flagged_poses": bad, "finite": finite, "precision": a.precision,
-                       "alt_precision_run": alt},
+                       "alt_precision_runs": alt},
             # The dominant kernel generates the per-edge TP weights with fp32 MFMA in registers (they never reach HBM), so it is
             # bound by the fp32 matrix pipe; SURVEY.md 8d asks for both views when the radial MLP is fused into the TP kernel.
             "roofline": {"bound": "mfma", "achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,

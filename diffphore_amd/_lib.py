@@ -16,7 +16,8 @@ DP_ABI_VERSION = 1
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
-PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
+PREC_BF16X9 = 4
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16x9": PREC_BF16X9}
 EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER = range(4)
 
 

@@ -707,7 +707,7 @@ __device__ __forceinline__ void lds_read_q(bf16x8& dst, unsigned addr, int off) 
 }
 template <int N> __device__ __forceinline__ void lds_landed(bf16x8& w) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(N)); }
 
-template <int KIND, int NS, int B>
+template <int KIND, int NS, int B, bool FULL = false>      // FULL (NS == 3 only): all 9 cross products = exact fp32 products
 struct OperandPipe {
   static __device__ __forceinline__ void run(unsigned la, bf16x8 (&W)[NS], const HidB<KIND, NS>& hb, f32x16& D) {
     constexpr int NB = NKB<KIND>;
@@ -720,10 +720,15 @@ struct OperandPipe {
       // smallest cross terms first; a split's register is re-requested right after its last use
       if constexpr (NS == 3) {
         lds_landed<NS - 1>(W[2]);
+        if constexpr (FULL) {
+          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[B][2], D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[B][1], D, 0, 0, 0);
+        }
         D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[B][0], D, 0, 0, 0);
         bf16x8 n2;
         if constexpr (more) lds_read_q(n2, la, ((B + 1) * NS + 2) * 1024);
         lds_landed<more ? NS - 1 : 1>(W[1]);
+        if constexpr (FULL) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][2], D, 0, 0, 0);
         D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][1], D, 0, 0, 0);
         D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][0], D, 0, 0, 0);
         bf16x8 n1;
@@ -750,7 +755,7 @@ struct OperandPipe {
           W[1] = n1;
         }
       }
-      OperandPipe<KIND, NS, B + 1>::run(la, W, hb, D);
+      OperandPipe<KIND, NS, B + 1, FULL>::run(la, W, hb, D);
     }
   }
 };
@@ -758,7 +763,7 @@ struct OperandPipe {
 // Stage TILE of the split-bf16 pipeline.  The packed weights stream L2 -> LDS through a RING-deep ring filled by LDS-DMA
 // RING-1 tiles ahead (an L2 round trip under load is ~2k cycles, longer than one bf16 tile), so a tile costs:
 //   issue DMA(tile+RING-1) | ds_read operands | 12 or 24 bf16 MFMAs | VALU contraction | counted vmcnt | s_barrier.
-template <int KIND, int NS, int TILE>
+template <int KIND, int NS, int TILE, bool FULL = false>
 struct StageB {
   static __device__ __forceinline__ void run(gptrq w2p, int wave, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
                                              const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
@@ -815,7 +820,7 @@ struct StageB {
         // i.e. a full L2 round trip for the tile that was JUST requested (measured: 0.88 -> see profiles/r1_conv_ablation.md).
         bf16x8 W[NS];
         const unsigned la = lds_w + (TILE % R) * NQ * 16;
-        OperandPipe<KIND, NS, 0>::run(la, W, hb, D);
+        OperandPipe<KIND, NS, 0, FULL>::run(la, W, hb, D);
       }
 #endif
 #endif
@@ -832,7 +837,7 @@ struct StageB {
         __builtin_amdgcn_s_barrier();
       }
       __builtin_amdgcn_sched_barrier(0);
-      StageB<KIND, NS, TILE + 1>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local);
+      StageB<KIND, NS, TILE + 1, FULL>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local);
     } else {
       constexpr int PHL = n_tiles_phase<KIND>(1) > 0 ? 1 : 0;
       PROF_MARK(5);
@@ -848,7 +853,7 @@ struct StageB {
   }
 };
 
-template <int KIND, int NS>
+template <int KIND, int NS, bool FULL = false>
 __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArgs a) {
   using S = Spec<KIND>;
   using G = Geo<KIND>;
@@ -893,7 +898,7 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     PROF_MARK(2);
-    StageB<KIND, NS, 0>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local);
+    StageB<KIND, NS, 0, FULL>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local);
   }
   __syncthreads();
   conv_epilogue<KIND, WAVES_B * 64>(a, r, s_acc);
@@ -905,13 +910,14 @@ template <int KIND> int launch(const DpConvArgs& a, hipStream_t st) {
   if (a.precision == DP_PREC_F32) hipLaunchKernelGGL(tp_conv_kernel<KIND>, grid, dim3(WAVES * 64), 0, st, a);
   else if (a.precision == DP_PREC_BF16X6) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 3>), grid, dim3(WAVES_B * 64), 0, st, a);
   else if (a.precision == DP_PREC_BF16X3) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2>), grid, dim3(WAVES_B * 64), 0, st, a);
+  else if (a.precision == DP_PREC_BF16X9) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 3, true>), grid, dim3(WAVES_B * 64), 0, st, a);
   else return DP_E_BADARG;
   return (int)hipGetLastError();
 }
 
 template <int KIND> int w2p_floats(int prec) {
   if (prec == DP_PREC_F32) return Geo<KIND>::W2P_FLOATS;
-  if (prec == DP_PREC_BF16X6) return Geo<KIND>::NT * TILE_QUADS<KIND, 3> * 4;
+  if (prec == DP_PREC_BF16X6 || prec == DP_PREC_BF16X9) return Geo<KIND>::NT * TILE_QUADS<KIND, 3> * 4;
   if (prec == DP_PREC_BF16X3) return Geo<KIND>::NT * TILE_QUADS<KIND, 2> * 4;
   return DP_E_BADARG;
 }
@@ -960,13 +966,13 @@ int dp_conv_w2p_floats(int32_t kind, int32_t precision) {
 int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, const float* fc0_b, const float* fc3_w,
                          const float* fc3_b, float* w1p, float* w2p) {
   if (!fc0_w || !fc0_b || !fc3_w || !fc3_b || !w1p || !w2p) return DP_E_BADARG;
-  if (precision != DP_PREC_F32 && precision != DP_PREC_BF16X6 && precision != DP_PREC_BF16X3) return DP_E_BADARG;
+  if (precision != DP_PREC_F32 && precision != DP_PREC_BF16X6 && precision != DP_PREC_BF16X3 && precision != DP_PREC_BF16X9) return DP_E_BADARG;
   switch (kind) {
 #define DP_CASE(K)                                                                                            \
   case K:                                                                                                     \
     dp::pack_w1<K>(fc0_w, fc0_b, w1p);                                                                        \
     if (precision == DP_PREC_F32) dp::pack_w2<K>(fc3_w, fc3_b, w2p);                                          \
-    else if (precision == DP_PREC_BF16X6) dp::pack_w2_bf16<K, 3>(fc3_w, fc3_b, (unsigned short*)w2p);         \
+    else if (precision == DP_PREC_BF16X6 || precision == DP_PREC_BF16X9) dp::pack_w2_bf16<K, 3>(fc3_w, fc3_b, (unsigned short*)w2p);         \
     else dp::pack_w2_bf16<K, 2>(fc3_w, fc3_b, (unsigned short*)w2p);                                          \
     return DP_OK;
     DP_CASE(0) DP_CASE(1) DP_CASE(2) DP_CASE(3) DP_CASE(4) DP_CASE(5)

@@ -54,7 +54,8 @@ enum DpEdgeMode {
 enum DpPrecision {
   DP_PREC_F32 = 0,      /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
   DP_PREC_BF16X6 = 3,   /* 3-way bf16 operand split, 6 cross products, fp32 accumulate: ~2^-24 relative, fp32-grade */
-  DP_PREC_BF16X3 = 2    /* 2-way bf16 split, 3 cross products: ~2^-17 relative */
+  DP_PREC_BF16X3 = 2,   /* 2-way bf16 split, 3 cross products: ~2^-17 relative */
+  DP_PREC_BF16X9 = 4    /* 3-way split, all 9 cross products: every fp32 x fp32 product exact (3 x 8 significand bits), fp32 accumulate */
 };
 
 typedef struct DpConvArgs {

@@ -45,7 +45,7 @@ def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x9", "bf16x3"])
 def test_forward_matches_oracle(prec):
     from diffphore_amd.score_model import TensorProductScoreModel
     tol = 1.0 if prec != "bf16x3" else 20.0
