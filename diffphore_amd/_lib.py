@@ -12,7 +12,7 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 1
+DP_ABI_VERSION = 2
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
@@ -32,7 +32,7 @@ class DpConvArgs(C.Structure):
         ("edge_emb", VOIDP), ("edge_sh", VOIDP), ("sh_stride", c_i32),
         ("w1p", VOIDP), ("w2p", VOIDP), ("bn_scale", VOIDP), ("bn_shift", VOIDP),
         ("out", VOIDP), ("out_stride", c_i32), ("accumulate", c_i32),
-        ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32),
+        ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32), ("phase_split", c_i32),
     ]
 
 

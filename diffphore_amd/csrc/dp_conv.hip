@@ -278,10 +278,11 @@ struct WgRange {
   int pose, sc0, n_lo, n_hi, n_loc, l0, p0, NL, NP, x0, k_begin, k_end;
 };
 
-__device__ __forceinline__ WgRange wg_range(const DpConvArgs& a) {
+__device__ __forceinline__ WgRange wg_range(const DpConvArgs& a, int bid = -1) {
   WgRange r;
-  r.pose = blockIdx.x / a.slices;
-  const int slice = blockIdx.x % a.slices;
+  if (bid < 0) bid = blockIdx.x;
+  r.pose = bid / a.slices;
+  const int slice = bid % a.slices;
   r.sc0 = a.scat_ptr[r.pose];
   const int nsc = a.scat_ptr[r.pose + 1] - r.sc0;
   r.n_lo = r.sc0 + (int)(((long long)nsc * slice) / a.slices);
@@ -439,13 +440,14 @@ __device__ __forceinline__ void gemm1_hidden(const DpConvArgs& a, const EdgeRef&
 //   an earlier wave, so its sum is parked in the wave's own (now dead) row 0 and merged by wave 0 after a barrier, in wave
 //   order (merge_wave_partials).  The summation tree depends only on the pose's own edge list: reruns are bit-identical.
 template <int D_OUT, int NCOL, typename ChanFn>
-__device__ __forceinline__ void wave_segsum(float* rows, int ld, int lane, int scat_local, float* s_acc, int* s_pnode_w, ChanFn chan) {
+__device__ __forceinline__ void wave_segsum(float* rows, int ld, int lane, int scat_local, float* s_acc, int* s_pnode_w, ChanFn chan,
+                                            int col_lo = 0, int col_hi = NCOL) {
   const int first_node = __builtin_amdgcn_readlane(scat_local, 0);
   if (lane == 0) *s_pnode_w = first_node;
 #pragma unroll
   for (int p = 0; p < (NCOL + 63) / 64; ++p) {
     const int col = lane + 64 * p;
-    const bool active = col < NCOL;
+    const bool active = col >= col_lo && col < col_hi;
     const int ch = active ? chan(col) : 0;
     float v[32];
 #pragma unroll
@@ -476,11 +478,12 @@ __device__ __forceinline__ void wave_segsum(float* rows, int ld, int lane, int s
 
 // second half of the above: wave 0 folds the NW parked first-segment sums into s_acc in wave order (call after a barrier)
 template <int D_OUT, int NCOL, int NW, typename ChanFn>
-__device__ __forceinline__ void merge_wave_partials(const float* s_msg, int ld, int lane, const int* s_pnode, float* s_acc, ChanFn chan) {
+__device__ __forceinline__ void merge_wave_partials(const float* s_msg, int ld, int lane, const int* s_pnode, float* s_acc, ChanFn chan,
+                                                    int col_lo = 0, int col_hi = NCOL) {
 #pragma unroll
   for (int p = 0; p < (NCOL + 63) / 64; ++p) {
     const int col = lane + 64 * p;
-    if (col < NCOL) {
+    if (col >= col_lo && col < col_hi) {
       const int ch = chan(col);
 #pragma unroll
       for (int q = 0; q < NW; ++q) {
@@ -514,6 +517,30 @@ __device__ __forceinline__ void conv_epilogue(const DpConvArgs& a, const WgRange
   }
 }
 
+// the same for a window of message columns (phase-split launches: a workgroup owns one phase's output channels)
+template <int KIND, int NTHREADS, typename ChanFn>
+__device__ __forceinline__ void conv_epilogue_cols(const DpConvArgs& a, const WgRange& r, const float* s_acc, ChanFn chan, int col_lo, int col_hi) {
+  using S = Spec<KIND>;
+  const int nc = col_hi - col_lo;
+  for (int i = threadIdx.x; i < r.n_loc * nc; i += NTHREADS) {
+    const int n = i / nc, c = chan(col_lo + (i - n * nc));
+    const int node = r.n_lo + n;
+    int deg;
+    if (a.mode == DP_EDGES_CSR) deg = a.rowend[node] - a.rowptr[node];
+    else if (a.mode == DP_EDGES_P2L) deg = r.NP;
+    else deg = r.NL;
+    float v = s_acc[n * S::D_OUT + c] / (float)max(deg, 1);
+    v = v * a.bn_scale[c] + a.bn_shift[c];
+    float* o = a.out + (size_t)node * a.out_stride + c;
+    if (a.accumulate) {
+      *o += v;
+    } else {
+      if (a.resid != nullptr && c < a.resid_width) v += a.resid[(size_t)node * a.resid_stride + c];
+      *o = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // PREC 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 4 waves / workgroup, W2p streamed from L2 per lane
 // ---------------------------------------------------------------------------------------------------------------
@@ -526,10 +553,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
   __shared__ int s_pnode[WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
-  const WgRange r = wg_range(a);
+  // phase_split: two workgroups per (pose, slice), one per accumulation phase = disjoint output channels.  Small batches cannot
+  // fill the chip with one workgroup per pose slice and a conv's latency is its longest workgroup; the split halves it at the
+  // price of doing the gathers and GEMM1 twice.  Per-channel sums are unchanged, so results are bit-identical to the unsplit launch.
+  const int only_ph = a.phase_split ? (int)(blockIdx.x & 1u) : -1;
+  const WgRange r = wg_range(a, a.phase_split ? (int)(blockIdx.x >> 1) : (int)blockIdx.x);
   if (r.n_loc <= 0) return;
   for (int i = tid; i < r.n_loc * S::D_OUT; i += WAVES * 64) s_acc[i] = 0.f;
   constexpr int NA0_ = n_acc_phase<KIND>(0);
+  const int col_lo = only_ph == 1 ? NA0_ : 0, col_hi = only_ph == 0 ? NA0_ : S::D_OUT;
   const auto chan = [](int c) { return c < NA0_ ? kChanLut<KIND, 0>.v[c < NA0_ ? c : 0] : kChanLut<KIND, 1>.v[c < NA0_ ? 0 : c - NA0_]; };
 
   PROF_MARK(-1);
@@ -548,7 +580,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
       constexpr int NT0 = n_tiles_phase<KIND>(0), NT1 = n_tiles_phase<KIND>(1);
       constexpr int NA0 = n_acc_phase<KIND>(0), NA1 = n_acc_phase<KIND>(1);
       float acc[NACC<KIND>];
-      if constexpr (NT0 > 0) {
+      if constexpr (NT0 > 0) if (only_ph != 1) {
 #pragma unroll
         for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
         gptr4 wp = (gptr4)a.w2p;
@@ -561,7 +593,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
         PROF_MARK(4);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (NT1 > 0) {
+      if constexpr (NT1 > 0) if (only_ph != 0) {
 #pragma unroll
         for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
         gptr4 wp = (gptr4)a.w2p + (size_t)NT0 * (G::K2 / 4) * 64;
@@ -575,14 +607,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void tp_conv_kernel(DpConvArgs a) {
       }
     }
 #if DP_ABLATE != 16
-    wave_segsum<S::D_OUT, S::D_OUT>(s_msg + (size_t)wave * 32 * G::MSG_LD, G::MSG_LD, lane, e.scat_local, s_acc, &s_pnode[wave], chan);
+    wave_segsum<S::D_OUT, S::D_OUT>(s_msg + (size_t)wave * 32 * G::MSG_LD, G::MSG_LD, lane, e.scat_local, s_acc, &s_pnode[wave], chan,
+                                    col_lo, col_hi);
     __syncthreads();
-    if (wave == 0) merge_wave_partials<S::D_OUT, S::D_OUT, WAVES>(s_msg, G::MSG_LD, lane, s_pnode, s_acc, chan);
+    if (wave == 0) merge_wave_partials<S::D_OUT, S::D_OUT, WAVES>(s_msg, G::MSG_LD, lane, s_pnode, s_acc, chan, col_lo, col_hi);
 #endif
     PROF_MARK(6);
   }
   __syncthreads();
-  conv_epilogue<KIND, WAVES * 64>(a, r, s_acc);
+  if (only_ph < 0) conv_epilogue<KIND, WAVES * 64>(a, r, s_acc);
+  else conv_epilogue_cols<KIND, WAVES * 64>(a, r, s_acc, chan, col_lo, col_hi);
   PROF_MARK(7);
 }
 
@@ -905,8 +939,11 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
   PROF_MARK(7);
 }
 
-template <int KIND> int launch(const DpConvArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)(a.B * a.slices));
+template <int KIND> int launch(const DpConvArgs& a_in, hipStream_t st) {
+  DpConvArgs a = a_in;
+  // phase-split needs both phases to exist and is implemented by the fp32-MFMA kernel only
+  if (a.precision != DP_PREC_F32 || n_tiles_phase<KIND>(0) == 0 || n_tiles_phase<KIND>(1) == 0) a.phase_split = 0;
+  dim3 grid((unsigned)(a.B * a.slices * (a.phase_split ? 2 : 1)));
   if (a.precision == DP_PREC_F32) hipLaunchKernelGGL(tp_conv_kernel<KIND>, grid, dim3(WAVES * 64), 0, st, a);
   else if (a.precision == DP_PREC_BF16X6) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 3>), grid, dim3(WAVES_B * 64), 0, st, a);
   else if (a.precision == DP_PREC_BF16X3) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2>), grid, dim3(WAVES_B * 64), 0, st, a);

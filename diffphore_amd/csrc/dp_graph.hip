@@ -604,6 +604,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     // ligand side: lig_conv (+ residual stream), phore_to_lig, phore_to_lig_norm      (:678-689, :703-706)
     memset(&a, 0, sizeof(a));
     a.kind = l; a.B = B; a.slices = slices; a.precision = w->precision; a.lig_ptr = b->lig_ptr; a.ph_ptr = b->ph_ptr; a.x_ptr = b->x_ptr;
+    a.phase_split = (B * slices < 512) ? 1 : 0;      // under-filled chip: one workgroup per accumulation phase (see DpConvArgs)
     a.sh_stride = 9; a.out_stride = 100; a.resid_stride = 100;
     a.gather_stride = a.attr1_stride = a.attr2_stride = 100;
     {

@@ -30,7 +30,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 1
+#define DP_ABI_VERSION 2
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -100,6 +100,9 @@ typedef struct DpConvArgs {
   const float* resid;        /* optional [n_scatter, resid_stride], added on the first resid_width channels */
   int32_t resid_stride;
   int32_t resid_width;
+  int32_t phase_split;       /* 1: two workgroups per (pose, slice), one per accumulation phase (scalar / vector output channels) - halves a
+                                conv's latency when B*slices cannot fill the chip; results are bit-identical.  fp32-MFMA kernel only
+                                (ignored otherwise and for kinds with a single phase) */
 } DpConvArgs;
 
 /* Fused gather -> radial MLP (MFMA) -> Clebsch-Gordan tensor product -> per-node segmented mean -> e3nn BatchNorm(eval).

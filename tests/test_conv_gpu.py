@@ -122,6 +122,12 @@ def test_conv_csr_ragged(kind, slices, prec):
     got2 = out.cpu().double()
     err = (got2 - (want + ref)).abs().max().item() / want.abs().max().item()
     assert err < 2 * TOL[prec], (prec, err)
+    # phase-split launch (one workgroup per accumulation phase): per-channel sums are untouched -> bit-identical output
+    base["accumulate"] = 0
+    out.fill_(float("nan"))
+    base["phase_split"] = 1
+    _run(base, keep)
+    assert torch.equal(out.cpu().double(), got), "phase-split launch must reproduce the unsplit result bit for bit"
 
 
 @pytest.mark.parametrize("prec", PRECS)

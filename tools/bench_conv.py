@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mode", default="p2l")
     ap.add_argument("--prec", default="f32")
+    ap.add_argument("--phase-split", type=int, default=0)
     ap.add_argument("--prof", action="store_true", help="print the cycle-stamp breakdown (library built with -DDP_PROF)")
     ap.add_argument("--lib", default=None, help="alternative libdiffphore_hip.so (ablation builds)")
     a = ap.parse_args()
@@ -46,6 +47,7 @@ def main():
     keep.update(lig_ptr=lig_ptr.to(dev), ph_ptr=ph_ptr.to(dev), x_ptr=x_ptr.to(dev))
     args = _lib.DpConvArgs()
     args.kind, args.B, args.slices = a.kind, B, a.slices
+    args.phase_split = a.phase_split
     args.precision = _lib.PRECISIONS[a.prec]
     args.max_scatter = NL if a.mode == "p2l" else NP
     args.mode = _lib.EDGES_P2L if a.mode == "p2l" else _lib.EDGES_L2P
