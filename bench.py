@@ -81,7 +81,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--poses", type=int, default=512, help="poses per GPU")
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3],
+                    help="synthetic.CONFIGS key = BASELINE.json configs index + 1 (default 2 = configs[1], the 512-pair workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x9", "bf16x3"],
                     help="arithmetic of the radial-MLP contraction; the headline value uses exact fp32 MFMA")
@@ -215,7 +216,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "f32" else a.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{a.config}]: {B} synthetic lig-phore pairs per GPU "
+            "config": {"workload": f"BASELINE.json configs[{a.config - 1}]: {B} synthetic lig-phore pairs per GPU "
                                    f"({shape['n_atoms']} atoms, {shape['n_tor']} torsions, {shape['n_phore']} phore nodes), "
                                    f"one reverse-diffusion step per bench step, fp32, random-init weights",
                        "poses_per_gpu": B, "poses_per_sec_at_20_steps": total_poses * a.steps / elapsed / 20.0,
