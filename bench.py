@@ -88,7 +88,7 @@ def main():
                     help="arithmetic of the radial-MLP contraction; the headline value uses exact fp32 MFMA")
     ap.add_argument("--no-alt", action="store_true", help="skip the informational split-bf16 passes")
     ap.add_argument("--cpu-poses", type=int, default=40)
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
