@@ -2,37 +2,67 @@
 """bench.py - DiffPhore reverse-diffusion hot path on MI355X.
 
 One "step" = one reverse-diffusion step (score-model forward + SDE perturbation + conformer update) over the whole
-per-GPU batch of poses, inputs resident in HBM.  Workload at N=1: BASELINE.json configs[1] - 512 synthetic
-ligand-pharmacophore pairs (30 atoms, 8 torsions, 32 pharmacophore nodes), fp32.  With --gpus N each rank runs its own
-512 poses (independent samples: no data-path collective; one RCCL broadcast of the weight blob at start-up), weak scaling.
+per-GPU batch of poses, inputs and pre-drawn noise resident in HBM.  Workload at N=1: BASELINE.json configs[1] - 512
+synthetic ligand-pharmacophore pairs (30 atoms, 8 torsions, 32 pharmacophore nodes).  `--config 1..5` selects the other
+BASELINE configs (diffphore_amd/workloads.py).  Poses are independent: with --gpus N every rank runs its own shard
+(no data-path collective; one RCCL broadcast of the weight blob at start-up), weak scaling.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused TP conv, layer-2 instantiation): algorithmic
-bytes of SURVEY.md 8d per launch / mean launch duration measured with HIP events recorded inside dp_forward on the
-launch stream during the timed steps.  `cpu_baseline` = this repo's CPU oracle (reference-style torch-CPU restatement,
-fp32) timed on a bounded sample of the same workload on the host cores.
+`python bench.py --gpus N` without a torchrun environment launches N ranks itself (torch.distributed.run, 127.0.0.1).
+
+Timed region: W warm-up steps (untimed), state reset to the randomised start poses, then EXACTLY K steps walking the
+schedule 0..S-1 (state reset at every wrap), bracketed by barrier + synchronize; MAX over ranks.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused TP conv, layer-2 phore->ligand launch):
+algorithmic flops / bytes of SURVEY.md 8d per launch / mean launch duration measured with HIP events recorded inside
+dp_forward on the launch stream during the timed steps.  `cpu_baseline` = this repo's CPU oracle (reference-style
+torch-CPU restatement, fp32) on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
+import hashlib
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from diffphore_amd import config, synthetic, weights  # noqa: E402
-from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn  # noqa: E402
-
 ALG_BYTES_PER_EDGE = {0: 2516, 1: 4636, 2: 6756, 3: 9236}      # SURVEY.md 8d: 4*(numel + D_in + 9) per edge-conv, fp32
 ALG_FLOPS_PER_EDGE = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400}   # SURVEY.md 8d: radial-MLP GEMM + TP
 MFMA_F32_PEAK_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
-MEASURED_TRAFFIC_BYTES = int((2 * 37757.6 + 6000.0) * 1024)   # profiles/r1_conv_hbm_traffic.csv, layer-2 phore->lig launch
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 PROF_LAYER, PROF_CONV = 2, 1                                     # layer-2 phore->ligand conv: dense cross edge set
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: a PMC traffic figure is only quoted for the sources it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "diffphore_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "diffphore_amd", "csrc", "*.h"))
+                    + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(config, poses, precision, conv_algo):
+    """HBM bytes per launch of the roofline kernel from committed rocprofv3 PMC passes, or None if no profile matches."""
+    try:
+        recs = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, None
+    src = kernel_source_hash()
+    for r in recs:
+        if (r.get("source_hash") == src and r.get("config") == config and r.get("poses") == poses and r.get("precision") == precision
+                and r.get("conv_algo", "edge") == conv_algo):
+            return int(r["traffic_bytes"]), r.get("profile")
+    return None, None
 
 
 class HipEvents:
@@ -41,6 +71,7 @@ class HipEvents:
         self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
         self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [C.c_void_p]
         self.ev = []
         for _ in range(2 * n):
             e = C.c_void_p()
@@ -57,110 +88,176 @@ class HipEvents:
         rc = self.hip.hipEventElapsedTime(C.byref(out), a, b)
         return out.value if rc == 0 else float("nan")
 
+    def destroy(self):
+        for e in self.ev:
+            self.hip.hipEventDestroy(e)
+        self.ev = []
 
-def cpu_baseline(graphs, sd, cfg, args, n_poses, n_steps):
-    """Reference-style CPU path (oracle, fp32, torch threads = all host cores) on a bounded sample of the workload."""
+
+def cpu_baseline(graphs, sd, cfg, margs, n_poses, n_steps, S_total):
+    """Reference-style CPU path (oracle, fp32) on a bounded sample of the workload: warm-up discarded, median of 3."""
     import copy
+
+    import torch
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
     from oracle import sampler as osampler
     from oracle.model import OracleScoreModel
     from oracle.tables import load_tables
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads only add fork/join overhead on these small ops
     om = OracleScoreModel(sd, cfg, dtype=torch.float32, tables=load_tables())
-    sample = copy.deepcopy(graphs[:n_poses])
-    sched = get_t_schedule(20)[:n_steps + 1]
-    t0 = time.perf_counter()
-    osampler.sampling_phore(sample, om, n_steps, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=20)
-    dt = time.perf_counter() - t0
-    return dict(value=n_poses * n_steps / dt, unit="pose-steps/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n_poses} poses x {n_steps} steps of the same workload, oracle (torch-CPU fp32 restatement), {dt:.1f} s")
+    sched = get_t_schedule(S_total)[:n_steps + 1]
+    n_poses = min(n_poses, len(graphs))
+
+    def once():
+        sample = copy.deepcopy(graphs[:n_poses])
+        t0 = time.perf_counter()
+        osampler.sampling_phore(sample, om, n_steps, sched, sched, sched, t_to_sigma_fn(margs), margs, batch_size=20)
+        return time.perf_counter() - t0
+
+    # BASELINE.md 3 says os.cpu_count() threads; on the many-core GPU hosts these small ops run SLOWER with every core (fork/join
+    # per op), so the warm-up run is done at both settings and the faster one is used for the three timed runs.
+    ncpu = os.cpu_count() or 1
+    cands = sorted({ncpu, min(ncpu, 32)})
+    warm = {}
+    for n in cands:
+        torch.set_num_threads(n)
+        warm[n] = once()
+    best = min(warm, key=warm.get)
+    torch.set_num_threads(best)
+    runs = sorted(once() for _ in range(3))
+    dt = runs[1]
+    return dict(value=n_poses * n_steps / dt, unit="pose-steps/s", cores=best, kind="port",
+                sample=(f"{n_poses} poses x {n_steps} steps of the same workload, oracle (torch-CPU fp32 restatement), warm-up discarded, "
+                        f"median of 3 = {dt:.2f} s (runs {', '.join(f'{r:.2f}' for r in runs)}); threads: "
+                        + ", ".join(f"{n} -> {warm[n]:.2f} s warm-up" for n in cands) + f"; host has {ncpu} logical CPUs"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks on this node, one per GPU, and relay rank 0's JSON line."""
+    import torch
+    backend = os.environ.get("DIFFPHORE_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < n and backend == "nccl":
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible (set DIFFPHORE_DIST_BACKEND=gloo to smoke-test several ranks on one GPU)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--poses", type=int, default=512, help="poses per GPU")
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3],
-                    help="synthetic.CONFIGS key = BASELINE.json configs index + 1 (default 2 = configs[1], the 512-pair workload)")
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100 = 5 x the 20-step schedule)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5],
+                    help="BASELINE.json configs index + 1 (default 2 = configs[1], the 512-pair workload)")
+    ap.add_argument("--poses", type=int, default=None, help="configs 1-3: poses per GPU (default 512/512/256)")
+    ap.add_argument("--units", type=int, default=None, help="configs 4/5: ligands / pharmacophores per GPU (x40 samples each; default 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x9", "bf16x3"],
-                    help="arithmetic of the radial-MLP contraction; the headline value uses exact fp32 MFMA")
-    ap.add_argument("--no-alt", action="store_true", help="skip the informational split-bf16 passes")
-    ap.add_argument("--cpu-poses", type=int, default=40)
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x6", "bf16x9", "bf16x3"],
+                    help="arithmetic of the radial-MLP contraction (default: f32; bf16x3 for config 5, BASELINE's 'bf16 mixed precision')")
+    ap.add_argument("--conv-algo", default=None, choices=["edge", "node"], help="fused conv formulation (default: library default)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational passes at other precisions / formulations")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the drop-in sampling_phore() end-to-end pass")
+    ap.add_argument("--cpu-poses", type=int, default=20)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a.gpus))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    backend = os.environ.get("DIFFPHORE_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI on ROCm
     ndev = torch.cuda.device_count()
-    if local >= ndev and os.environ.get("DIFFPHORE_DIST_BACKEND", "nccl") == "nccl":
+    if ndev == 0:
+        raise SystemExit("bench.py needs an AMD GPU (no CPU path exists for the hot path)")
+    if local >= ndev and backend == "nccl":
         raise SystemExit(f"LOCAL_RANK {local} but only {ndev} GPU(s) visible")
-    local = local % max(ndev, 1)                            # (gloo smoke runs may put several ranks on one GPU)
+    local = local % ndev                                             # (gloo smoke runs may put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("DIFFPHORE_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
-    from diffphore_amd.engine import DeviceModel, Engine, PackedBatch
-    from diffphore_amd.sampling import _step_params
     import types
+
+    from diffphore_amd import config, weights, workloads
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.engine import DeviceModel, Engine, PackedBatch
+    from diffphore_amd.sampling import _step_params, randomize_position
 
     cfg = config.ModelConfig()
     margs = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
                                                                   "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
-    shape = synthetic.CONFIGS[a.config]
-    n_pairs = a.poses
-    graphs = synthetic.synthetic_pairs(a.config, n_pairs, shape["n_atoms"], shape["n_tor"], shape["n_phore"],
-                                       seed=synthetic.BASE_SEED + a.config + 1000 * rank)
+    units = (a.poses if a.config in (1, 2, 3) else a.units) or workloads.DEFAULT_UNITS[a.config]
+    precision = a.precision or ("bf16x3" if a.config == 5 else "f32")
+    graphs, _mine = workloads.build(a.config, units, rank, world)
+    S_total = workloads.steps_of(a.config)
     sd = weights.init_state_dict()
-    model = DeviceModel(sd, cfg, dev, precision=a.precision)
+    model = DeviceModel(sd, cfg, dev, precision=precision)
     if world > 1:
         # the only collective of the job: weights from rank 0 to every GPU over xGMI (SURVEY.md 8e)
         dist.broadcast(model.blob, src=0)
         torch.cuda.synchronize()
     # initial state: randomize_position on the device (same call the sampler's callers make, inference.py:185)
-    from diffphore_amd.sampling import randomize_position
     np.random.seed(607201 + rank)
     torch.manual_seed(607201 + rank)
     randomize_position(graphs, False, False, cfg.tr_sigma_max, device=dev)
     pb0 = PackedBatch(graphs, dev)
     pos0, norm0 = pb0.pos.clone(), pb0.norm.clone()
-    S_total = 20
     sched = get_t_schedule(S_total)
     t2s = t_to_sigma_fn(margs)
     gen = torch.Generator(device=dev).manual_seed(607201 + rank)
     B, nT = pb0.B, int(pb0.tor_ptr[-1])
-    # pre-drawn noise resident in HBM (the reference draws it on the host inside the loop, sampling.py:230-243)
+    # pre-drawn noise resident in HBM (the reference draws it on the host inside the loop, sampling.py:230-243); one set per schedule step
     zs = [(torch.randn(B, 3, device=dev, generator=gen), torch.randn(B, 3, device=dev, generator=gen),
-           torch.randn(max(nT, 1), device=dev, generator=gen)) for _ in range(a.warmup + a.steps)]
+           torch.randn(max(nT, 1), device=dev, generator=gen)) for _ in range(S_total)]
+    sps = [_step_params(t, S_total, sched, sched, sched, t2s, margs, False, False) for t in range(S_total)]
+    T_dev = torch.tensor([[float(sched[t])] * 3 for t in range(S_total)], dtype=torch.float32, device=dev)   # diffusion times, resident
 
-    def timed_run(mdl):
+    def timed_run(mdl, conv_algo=None):
         pb = pb0
-        pb.pos.copy_(pos0)
-        pb.norm.copy_(norm0)
-        eng = Engine(mdl, pb)
+        eng = Engine(mdl, pb, conv_algo=conv_algo)
         ev = HipEvents(a.steps)
+
+        def reset():
+            pb.pos.copy_(pos0)
+            pb.norm.copy_(norm0)
+            eng.ws.t["status"].zero_()
 
         def step(i, prof_idx=None):
             t_idx = i % S_total
-            sp = _step_params(t_idx, S_total, sched, sched, sched, t2s, margs, False, False)
-            pb.set_time(float(sched[t_idx]), float(sched[t_idx]), float(sched[t_idx]))
+            if t_idx == 0:
+                reset()
+            pb.t.copy_(T_dev[t_idx].expand(B, 3))
             w = eng.ws.struct
             if prof_idx is None:
                 w.prof_start, w.prof_stop = None, None
             else:
                 s0, s1 = ev.pair(prof_idx)
                 w.prof_start, w.prof_stop, w.prof_layer, w.prof_conv = s0, s1, PROF_LAYER, PROF_CONV
-            z = zs[i]
-            eng.sample_step(sp, z[0], z[1], z[2] if nT else None)
+            z = zs[t_idx]
+            eng.sample_step(sps[t_idx], z[0], z[1], z[2] if nT else None)
 
         for i in range(a.warmup):
             step(i)
@@ -170,7 +267,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
-            step(a.warmup + i, prof_idx=i)
+            step(i, prof_idx=i)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -182,32 +279,68 @@ def main():
             el = float(te.item())
         nbad = int((eng.ws.t["status"] != 0).sum().item())
         fin = bool(torch.isfinite(pb.pos).all().item())
-        return el, float(np.nanmean([ev.ms(i) for i in range(a.steps)])), nbad, fin
+        kms = float(np.nanmean([ev.ms(i) for i in range(a.steps)]))
+        ev.destroy()
+        return el, kms, nbad, fin, eng.conv_algo
 
-    elapsed, kern_ms, bad, finite = timed_run(model)
+    elapsed, kern_ms, bad, finite, algo_used = timed_run(model, a.conv_algo)
     pb = pb0
+    totals = torch.tensor([B, int(pb.x_ptr[-1])], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    total_poses = int(totals[0].item())
+
     alt = None
-    if not a.no_alt and a.precision == "f32":
-        # informational passes with the radial GEMM on the bf16 matrix pipe by operand splitting (never the headline `value`)
+    if not a.no_alt and a.config == 2 and a.precision is None and a.conv_algo is None:
+        # informational passes (never the headline `value`): other precisions / the other conv formulation, same workload
         alt = []
-        for prec, what in (("bf16x9", "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
-                           ("bf16x6", "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances")):
-            alt_model = DeviceModel(sd, cfg, dev, precision=prec)
-            if world > 1:
-                dist.broadcast(alt_model.blob, src=0)
-            el2, k2, bad2, fin2 = timed_run(alt_model)
-            alt.append({"precision": f"{prec} ({what})", "value": B * world * a.steps / el2, "ms_per_step": el2 / a.steps * 1e3,
-                        "kernel_ms": k2, "finite": fin2, "kabsch_flagged_poses": bad2})
-            del alt_model
+        for prec, algo, what in (
+                ("f32", "edge" if algo_used != "edge" else "node", "exact fp32 MFMA, the other conv formulation"),
+                ("bf16x9", None, "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
+                ("bf16x6", None, "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances")):
+            try:
+                alt_model = model if prec == precision else DeviceModel(sd, cfg, dev, precision=prec)
+                if world > 1 and alt_model is not model:
+                    dist.broadcast(alt_model.blob, src=0)
+                el2, k2, bad2, fin2, algo2 = timed_run(alt_model, algo)
+            except Exception as e:      # noqa: BLE001 - an informational pass must never sink the headline line
+                alt.append({"precision": prec, "conv_algo": algo, "error": str(e)[:200]})
+                continue
+            alt.append({"precision": f"{prec} ({what})", "conv_algo": algo2, "value": total_poses * a.steps / el2,
+                        "ms_per_step": el2 / a.steps * 1e3, "kernel_ms": k2, "finite": fin2, "kabsch_flagged_poses": bad2})
+
+    e2e = None
+    if not a.no_e2e and world == 1 and a.config in (1, 2, 3):
+        # secondary figure: the whole drop-in call sampling_phore(data_list, ...) - host packing of the HeteroData list, noise
+        # draw + upload, device loop, write-back over PCIe - on the same poses (never `value`: that is HBM-resident)
+        import copy
+
+        from diffphore_amd.sampling import sampling_phore
+        from diffphore_amd.score_model import TensorProductScoreModel
+        m = TensorProductScoreModel(device=dev, precision=precision)
+        m.load_state_dict(sd)
+        gl = [g.sample_copy() for g in graphs]
+        sampling_phore(gl[:8], m, 2, sched, sched, sched, dev, t2s, margs, batch_size=20)     # warm-up
+        torch.cuda.synchronize()
+        tm = {}
+        t0 = time.perf_counter()
+        sampling_phore(gl, m, S_total, sched, sched, sched, dev, t2s, margs, batch_size=20, timing=tm)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        e2e = {"what": "drop-in sampling_phore(data_list) incl. host packing, noise draw/upload and write-back", "poses": len(gl),
+               "steps": S_total, "seconds": dt, "value": len(gl) * S_total / dt, "unit": "pose-steps/s",
+               "breakdown_s": {k: round(v, 4) for k, v in tm.items()}}
+        del copy
 
     n_x = int(pb.x_ptr[-1])
     alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
     flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * n_x
-    traffic = MEASURED_TRAFFIC_BYTES if (a.config == 2 and a.poses == 512 and a.precision == "f32") else None
+    traffic, traffic_src = measured_traffic(a.config, B, precision, algo_used) if world == 1 else (None, None)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else float("nan")
 
     if rank == 0:
-        total_poses = B * world
+        dtype = {"f32": "f32", "bf16x9": "f32 (bf16x9 split, exact products, fp32 accumulate)",
+                 "bf16x6": "f32 (bf16x6 split, ~2^-24 products, fp32 accumulate)", "bf16x3": "bf16x3 split (~2^-17 products), fp32 accumulate"}[precision]
         out = {
             "metric": "poses/sec (samples x steps) on the reverse-diffusion hot path",
             "value": total_poses * a.steps / elapsed,
@@ -215,31 +348,34 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "f32" else a.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{a.config - 1}]: {B} synthetic lig-phore pairs per GPU "
-                                   f"({shape['n_atoms']} atoms, {shape['n_tor']} torsions, {shape['n_phore']} phore nodes), "
-                                   f"one reverse-diffusion step per bench step, fp32, random-init weights",
-                       "poses_per_gpu": B, "poses_per_sec_at_20_steps": total_poses * a.steps / elapsed / 20.0,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workloads.describe(a.config, units) + f", one reverse-diffusion step per bench step ({S_total}-step schedule, "
+                                   f"state reset at every wrap), random-init weights",
+                       "poses_per_gpu": B, "poses_total": total_poses, f"poses_per_sec_at_{S_total}_steps": total_poses * a.steps / elapsed / S_total,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
-                       "kabsch_flagged_poses": bad, "finite": finite, "precision": a.precision,
-                       "alt_precision_runs": alt},
-            # The dominant kernel generates the per-edge TP weights with fp32 MFMA in registers (they never reach HBM), so it is
+                       "kabsch_flagged_poses": bad, "finite": finite, "precision": precision, "conv_algo": algo_used,
+                       "alt_runs": alt, "e2e": e2e},
+            # The dominant kernel generates the per-edge TP weights on the matrix pipe in registers (they never reach HBM), so it is
             # bound by the fp32 matrix pipe; SURVEY.md 8d asks for both views when the radial MLP is fused into the TP kernel.
+            # alg_flops_per_edge is the EDGE-SIDE count of SURVEY.md 8d (radial GEMM per edge); the node-side formulation computes
+            # the same result with fewer flops, so its `frac` under this count can exceed what the pipe could
+            # deliver for the edge-side form - `executed_flops_per_edge` is what that launch really issues.
             "roofline": {"bound": "mfma", "achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None,
                          "traffic": traffic,
-                         "kernel": "dp::tp_conv_kernel<2> (layer-2 phore->ligand conv, dense cross edges)",
+                         "kernel": f"fused TP conv, layer-2 phore->ligand launch (dense cross edges), conv_algo={algo_used}, precision={precision}",
                          "kernel_ms": kern_ms, "edges_per_launch": n_x,
                          "alg_flops_per_edge": ALG_FLOPS_PER_EDGE[PROF_LAYER], "alg_bytes_per_edge": ALG_BYTES_PER_EDGE[PROF_LAYER],
                          "hbm_equivalent": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                                             "note": "algorithmic bytes of the e3nn operator boundary (per-edge weights counted as "
                                                     "HBM input, SURVEY.md 8d) / launch time; the metric's 'fused TP-scatter HBM GB/s'"},
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950 "
-                                         "correction), profiles/r1_conv_hbm_traffic.csv; null for non-default workloads"},
+                         "traffic_note": (f"HBM bytes per launch from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), {traffic_src}, "
+                                          f"kernel sources {kernel_source_hash()}") if traffic is not None else
+                                         "null: no committed PMC profile matches these kernel sources / workload (profiles/conv_hbm_traffic.json)"},
         }
-        if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(graphs, sd, cfg, margs, a.cpu_poses, a.cpu_steps)
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(graphs, sd, cfg, margs, a.cpu_poses, a.cpu_steps, S_total)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

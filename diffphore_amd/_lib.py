@@ -12,13 +12,14 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 2
+DP_ABI_VERSION = 3
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
 PREC_BF16X9 = 4
 PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16x9": PREC_BF16X9}
 EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER = range(4)
+ALGO_AUTO, ALGO_EDGE, ALGO_NODE = range(3)
 
 
 class DpConvArgs(C.Structure):
@@ -33,6 +34,7 @@ class DpConvArgs(C.Structure):
         ("w1p", VOIDP), ("w2p", VOIDP), ("bn_scale", VOIDP), ("bn_shift", VOIDP),
         ("out", VOIDP), ("out_stride", c_i32), ("accumulate", c_i32),
         ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32), ("phase_split", c_i32),
+        ("w1n", VOIDP), ("w2n", VOIDP), ("algo", c_i32),
     ]
 
 
@@ -71,6 +73,15 @@ def _declare(L):
     L.dp_conv_dims.restype = C.c_int
     L.dp_pack_conv_weights.argtypes = [c_i32, c_i32, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP]
     L.dp_pack_conv_weights.restype = C.c_int
+    L.dp_tp_conv_node.argtypes = [C.POINTER(DpConvArgs), VOIDP]
+    L.dp_tp_conv_node.restype = C.c_int
+    L.dp_conv_w1n_floats.argtypes = [c_i32]
+    L.dp_conv_w1n_floats.restype = C.c_int
+    L.dp_conv_w2n_floats.argtypes = [c_i32]
+    L.dp_conv_w2n_floats.restype = C.c_int
+    L.dp_pack_conv_weights_node.argtypes = [c_i32] + [VOIDP] * 6
+    L.dp_pack_conv_weights_node.restype = C.c_int
+    L.dp_conv_node_max_nodes.restype = C.c_int
 
 
 def check(rc: int, what: str):

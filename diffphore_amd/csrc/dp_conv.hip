@@ -28,6 +28,9 @@
 #ifndef DP_ABLATE
 #define DP_ABLATE 0
 #endif
+#ifndef DP_NODE_AUTO_MIN_POSES          // DP_ALGO_AUTO picks the node-side kernel from this batch size on (1 << 30: never)
+#define DP_NODE_AUTO_MIN_POSES (1 << 30)
+#endif
 #ifdef DP_PROF   // cycle-stamp breakdown of the bf16 kernel (ablation builds only; tools/bench_conv.py --prof)
 __device__ unsigned long long dp_prof[16];
 __shared__ unsigned long long s_prof_prev;
@@ -1018,7 +1021,16 @@ int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, co
   }
 }
 
+int dp_resolve_conv_algo(int32_t algo, int32_t precision, int32_t B) {
+  // node-side: fp32 only; it needs >= ~256 workgroups of 16 nodes to fill the chip (small batches keep the edge-side kernel with
+  // its per-pose slicing and phase split)
+  if (algo == DP_ALGO_NODE) return precision == DP_PREC_F32 ? DP_ALGO_NODE : DP_ALGO_EDGE;
+  if (algo == DP_ALGO_EDGE) return DP_ALGO_EDGE;
+  return (precision == DP_PREC_F32 && B >= DP_NODE_AUTO_MIN_POSES) ? DP_ALGO_NODE : DP_ALGO_EDGE;
+}
+
 int dp_tp_conv(const DpConvArgs* a, void* stream) {
+  if (a && a->algo == DP_ALGO_NODE) return dp_tp_conv_node(a, stream);
   if (!a || a->B <= 0 || a->slices <= 0 || !a->scat_ptr || !a->gather_tab || !a->attr1_tab || !a->edge_emb || !a->edge_sh ||
       !a->w1p || !a->w2p || !a->bn_scale || !a->bn_shift || !a->out)
     return DP_E_BADARG;

@@ -585,6 +585,10 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while ((mx + slices - 1) / slices > dp_conv_max_nodes(w->precision)) ++slices;
     while (B * slices < 512 && slices < 8) ++slices;
   }
+  // dense cross convs: node-side formulation when asked for (or chosen by AUTO) and the weights were packed for it
+  const bool node_side = dp_resolve_conv_algo(k->conv_algo, w->precision, B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
+  const int nb = dp_conv_node_max_nodes();
+  const int slices_pl = (b->max_nl + nb - 1) / nb, slices_lp = (b->max_np + nb - 1) / nb;
   int cur = 0;
   static const int D[5] = {20, 50, 80, 100, 100};
   auto timed = [&](const DpConvArgs& c, int layer, int which) -> int {
@@ -622,6 +626,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
+      if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; }
       if ((rc = timed(c, l, 1 + nv))) return rc;
     }
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
@@ -640,6 +645,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
+        if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; }
         if ((rc = timed(c, l, 4 + nv))) return rc;
       }
     }

@@ -31,8 +31,9 @@ def bn_affine(sd: Dict[str, torch.Tensor], prefix: str, irreps, eps: float = 1e-
     return torch.cat(scale).float().contiguous(), torch.cat(shift).float().contiguous()
 
 
-def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: int = 0) -> Dict[str, torch.Tensor]:
-    """fc.0 / fc.3 / batch_norm of one TensorProductConvLayer -> MFMA operand order (host tensors)."""
+def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: int = 0, node_side: bool = False) -> Dict[str, torch.Tensor]:
+    """fc.0 / fc.3 / batch_norm of one TensorProductConvLayer -> MFMA operand order (host tensors).  `node_side` adds the layout of
+    the node-side kernel (dp_conv_node.hip: layer convs over the dense cross edge sets, fp32)."""
     L = _lib.lib()
     dims = _lib.conv_dims(kind)
     fc0_w = sd[prefix + ".fc.0.weight"].float().contiguous()
@@ -46,4 +47,11 @@ def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: in
     _lib.check(L.dp_pack_conv_weights(kind, precision, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
                                       w1p.data_ptr(), w2p.data_ptr()), "dp_pack_conv_weights")
     scale, shift = bn_affine(sd, prefix + ".batch_norm", _OUT_IRREPS[kind])
-    return dict(w1p=w1p, w2p=w2p, bn_scale=scale, bn_shift=shift)
+    out = dict(w1p=w1p, w2p=w2p, bn_scale=scale, bn_shift=shift)
+    if node_side:
+        w1n = torch.empty(L.dp_conv_w1n_floats(kind), dtype=torch.float32)
+        w2n = torch.empty(L.dp_conv_w2n_floats(kind), dtype=torch.float32)
+        _lib.check(L.dp_pack_conv_weights_node(kind, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
+                                               w1n.data_ptr(), w2n.data_ptr()), "dp_pack_conv_weights_node")
+        out.update(w1n=w1n, w2n=w2n)
+    return out

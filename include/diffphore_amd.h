@@ -30,7 +30,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 2
+#define DP_ABI_VERSION 3
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -56,6 +56,13 @@ enum DpPrecision {
   DP_PREC_BF16X6 = 3,   /* 3-way bf16 operand split, 6 cross products, fp32 accumulate: ~2^-24 relative, fp32-grade */
   DP_PREC_BF16X3 = 2,   /* 2-way bf16 split, 3 cross products: ~2^-17 relative */
   DP_PREC_BF16X9 = 4    /* 3-way split, all 9 cross products: every fp32 x fp32 product exact (3 x 8 significand bits), fp32 accumulate */
+};
+
+/* formulation of the fused conv: per-edge radial GEMM, or node-side contraction (dense cross edge sets, fp32 only) */
+enum DpConvAlgo {
+  DP_ALGO_AUTO = 0,     /* library's choice by precision and batch size (dp_resolve_conv_algo) */
+  DP_ALGO_EDGE = 1,     /* dp_conv.hip: w[e] = W2 hid[e] on the matrix pipe per edge, CG contraction on the VALU, segmented mean */
+  DP_ALGO_NODE = 2      /* dp_conv_node.hip: T[n] = hid^T z over the node's edges, out[n] = W2 T[n] batched over 16 nodes */
 };
 
 typedef struct DpConvArgs {
@@ -103,11 +110,26 @@ typedef struct DpConvArgs {
   int32_t phase_split;       /* 1: two workgroups per (pose, slice), one per accumulation phase (scalar / vector output channels) - halves a
                                 conv's latency when B*slices cannot fill the chip; results are bit-identical.  fp32-MFMA kernel only
                                 (ignored otherwise and for kinds with a single phase) */
+  /* node-side formulation (DP_ALGO_NODE): weights in the layout of dp_pack_conv_weights_node; `slices` = node groups per pose with
+   * ceil(max_scatter / slices) <= dp_conv_node_max_nodes().  Kinds 0-3, modes P2L / L2P, DP_PREC_F32 only. */
+  const float* w1n;
+  const float* w2n;
+  int32_t algo;              /* DpConvAlgo; AUTO / EDGE -> the edge-side kernel */
 } DpConvArgs;
 
 /* Fused gather -> radial MLP (MFMA) -> Clebsch-Gordan tensor product -> per-node segmented mean -> e3nn BatchNorm(eval).
  * Replaces TensorProductConvLayer.forward, score_model_phore.py:134-149. */
 int dp_tp_conv(const DpConvArgs* args, void* stream);
+/* the node-side kernel directly (dp_tp_conv dispatches here when args->algo == DP_ALGO_NODE) */
+int dp_tp_conv_node(const DpConvArgs* args, void* stream);
+int dp_conv_node_max_nodes(void);
+int dp_conv_w1n_floats(int32_t kind);
+int dp_conv_w2n_floats(int32_t kind);
+/* HOST pointers: the same reference tensors as dp_pack_conv_weights, re-ordered for the node-side kernel */
+int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b, float* w1n,
+                              float* w2n);
+/* what DP_ALGO_AUTO resolves to for a batch of B poses at `precision` (returns DP_ALGO_EDGE or DP_ALGO_NODE) */
+int dp_resolve_conv_algo(int32_t algo, int32_t precision, int32_t B);
 
 /* scatter nodes one workgroup can own: callers of dp_tp_conv pick `slices` so that ceil(nodes per pose / slices) <= this */
 int dp_conv_max_nodes(int32_t precision);
@@ -153,7 +175,7 @@ typedef struct DpBatch {
 } DpBatch;
 
 typedef struct DpMlp { const float *w0, *b0, *w3, *b3; } DpMlp;   /* nn.Sequential(Linear, act, Dropout, Linear) */
-typedef struct DpConvW { const float *w1p, *w2p, *bn_scale, *bn_shift; } DpConvW;
+typedef struct DpConvW { const float *w1p, *w2p, *bn_scale, *bn_shift, *w1n, *w2n; } DpConvW;   /* w1n/w2n: node-side layout or NULL */
 
 /* Device pointers into the uploaded parameter blob.  Reference names: score_model_phore.py:248-291, 524-641. */
 typedef struct DpWeights {
@@ -208,6 +230,7 @@ typedef struct DpWork {
    * 2 phore->lig (normals), 3 phore-phore, 4 lig->phore, 5 lig->phore (normals). */
   void *prof_start, *prof_stop;
   int32_t prof_layer, prof_conv;
+  int32_t conv_algo;                /* DpConvAlgo for the dense cross convs of dp_forward */
 } DpWork;
 
 typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */

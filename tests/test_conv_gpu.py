@@ -175,6 +175,74 @@ def test_conv_dense_cross(kind, mode, prec):
     assert err < TOL[prec], (prec, err)
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", ["p2l", "l2p"])
+def test_conv_node_side_dense_cross(kind, mode):
+    """Node-side formulation (dp_conv_node.hip, DP_ALGO_NODE) of the dense cross convs vs the fp64 oracle AND vs the edge-side
+    kernel: ragged pose sizes (1 node, < 16, > 16 nodes; 5 / 32 / 79 edges per node = 1-3 edge passes), residual + accumulate."""
+    g = torch.Generator().manual_seed(700 + kind)
+    sd = weights.init_state_dict(11)
+    fam = "phore_to_lig_conv_layers" if mode == "p2l" else "lig_to_phore_norm_conv_layers"
+    if kind == 3 and mode == "l2p":
+        fam = "lig_to_phore_conv_layers"
+    prefix = f"encoder.{fam}.{kind}"
+    dims = _lib.conv_dims(kind)
+    NL, NP = [7, 30, 13, 1, 40], [32, 5, 79, 33, 17]
+    B = len(NL)
+    lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+    ph_ptr = np.concatenate([[0], np.cumsum(NP)])
+    x_ptr = np.concatenate([[0], np.cumsum(np.asarray(NL) * np.asarray(NP))])
+    hl = torch.randn(int(lig_ptr[-1]), dims["d_in"], generator=g)
+    hp = torch.randn(int(ph_ptr[-1]), dims["d_in"], generator=g)
+    E = int(x_ptr[-1])
+    emb = torch.randn(E, 20, generator=g)
+    sh = torch.randn(E, 9, generator=g)
+    sh[:, 0] = 1.0                                  # Y_0 = 1 for every edge ('component' normalisation): the node-side kernel relies on it
+    src = torch.cat([torch.arange(lig_ptr[b], lig_ptr[b + 1]).repeat_interleave(NP[b]) for b in range(B)])
+    dst = torch.cat([torch.arange(ph_ptr[b], ph_ptr[b + 1]).repeat(NL[b]) for b in range(B)])
+    attr = torch.cat([emb, hl[src, :20], hp[dst, :20]], 1)
+    if mode == "p2l":
+        ref = _oracle_conv(sd, prefix, kind, hp[dst], attr, sh, src, hl.shape[0])
+        n_out, gt, scat_ptr, m, mx = hl.shape[0], hp, lig_ptr, _lib.EDGES_P2L, max(NL)
+    else:
+        ref = _oracle_conv(sd, prefix, kind, hl[src], attr, sh, dst, hp.shape[0])
+        n_out, gt, scat_ptr, m, mx = hp.shape[0], hl, ph_ptr, _lib.EDGES_L2P, max(NP)
+    pk = packing.pack_conv(sd, prefix, kind, _lib.PREC_F32, node_side=True)
+    nb = _lib.lib().dp_conv_node_max_nodes()
+    resid = torch.randn(n_out, dims["d_in"], generator=g)
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    base = dict(kind=kind, mode=m, B=B, slices=(mx + nb - 1) // nb, precision=_lib.PREC_F32, max_scatter=mx, scat_ptr=_dev(_i32(scat_ptr)),
+                lig_ptr=_dev(_i32(lig_ptr)), ph_ptr=_dev(_i32(ph_ptr)), x_ptr=_dev(_i32(x_ptr)), gather_tab=_dev(gt), gather_stride=dims["d_in"],
+                attr1_tab=_dev(hl), attr1_stride=dims["d_in"], attr2_tab=_dev(hp), attr2_stride=dims["d_in"], attr_swap=0,
+                edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]), w1n=_dev(pk["w1n"]), w2n=_dev(pk["w2n"]),
+                bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]), out=out, out_stride=dims["d_out"],
+                accumulate=0, resid=_dev(resid), resid_stride=dims["d_in"], resid_width=dims["d_in"], algo=_lib.ALGO_NODE)
+    _run(base, keep)
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item() / scale
+    assert err < TOL["f32"], err
+    base["accumulate"] = 1
+    _run(base, keep)
+    err = (out.cpu().double() - (want + ref)).abs().max().item() / scale
+    assert err < 2 * TOL["f32"], err
+    # the edge-side kernel on the same inputs: same operator, different association -> equal to fp32 rounding
+    out2 = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    base.update(algo=_lib.ALGO_EDGE, accumulate=0, out=out2, slices=3)
+    _run(base, keep)
+    err = (out2.cpu().double() - got).abs().max().item() / scale
+    assert err < TOL["f32"], err
+    # reruns are bit-identical (fixed summation order, no atomics)
+    out3 = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    base.update(algo=_lib.ALGO_NODE, out=out3, slices=(mx + nb - 1) // nb)
+    _run(base, keep)
+    assert torch.equal(out3.cpu().double(), got)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_conv_center_and_torsion_kinds(prec):
     g = torch.Generator().manual_seed(500)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--mode", default="p2l")
     ap.add_argument("--prec", default="f32")
     ap.add_argument("--phase-split", type=int, default=0)
+    ap.add_argument("--algo", default="edge", choices=["edge", "node"])
     ap.add_argument("--prof", action="store_true", help="print the cycle-stamp breakdown (library built with -DDP_PROF)")
     ap.add_argument("--lib", default=None, help="alternative libdiffphore_hip.so (ablation builds)")
     a = ap.parse_args()
@@ -30,7 +31,7 @@ def main():
         _lib.LIB_PATH = a.lib
     dims = _lib.conv_dims(a.kind)
     sd = weights.init_state_dict(1)
-    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PRECISIONS[a.prec])
+    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PRECISIONS[a.prec], node_side=a.algo == "node")
     B, NL, NP = a.B, a.nl, a.np
     dev = "cuda"
     lig_ptr = torch.arange(B + 1, dtype=torch.int32) * NL
@@ -59,6 +60,10 @@ def main():
     args.attr2_tab, args.attr2_stride = hp.data_ptr(), dims["d_in"]
     args.edge_emb, args.edge_sh, args.sh_stride = emb.data_ptr(), sh.data_ptr(), 9
     args.w1p, args.w2p = keep["w1p"].data_ptr(), keep["w2p"].data_ptr()
+    if a.algo == "node":
+        nb = _lib.lib().dp_conv_node_max_nodes()
+        args.algo, args.w1n, args.w2n = _lib.ALGO_NODE, keep["w1n"].data_ptr(), keep["w2n"].data_ptr()
+        args.slices = (args.max_scatter + nb - 1) // nb
     args.bn_scale, args.bn_shift = keep["bn_scale"].data_ptr(), keep["bn_shift"].data_ptr()
     args.out, args.out_stride, args.accumulate = out.data_ptr(), dims["d_out"], 0
     L = _lib.lib()
@@ -83,7 +88,7 @@ def main():
         names = ["gemm1+split", "operands+sync", "ring prologue", "tiles ph0", "segsum ph0", "tiles ph1", "segsum ph1", "epilogue"]
         for n, v in zip(names, buf[:8]):
             print(f"  {n:14s} {v:14d} ticks  {100.0 * v / tot:5.1f} %")
-    print(json.dumps(dict(kind=a.kind, prec=a.prec, mode=a.mode, B=B, edges=E, ms=ms, ns_per_edge=ms * 1e6 / E,
+    print(json.dumps(dict(kind=a.kind, prec=a.prec, algo=a.algo, mode=a.mode, B=B, edges=E, ms=ms, ns_per_edge=ms * 1e6 / E,
                           alg_GBps=E * ALG_BYTES[a.kind] / ms / 1e6, TFLOPs=E * FLOPS[a.kind] / ms / 1e9)))
 
 
