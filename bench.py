@@ -107,28 +107,26 @@ def cpu_baseline(graphs, sd, cfg, margs, n_poses, n_steps, S_total):
     sched = get_t_schedule(S_total)[:n_steps + 1]
     n_poses = min(n_poses, len(graphs))
 
-    def once():
-        sample = copy.deepcopy(graphs[:n_poses])
+    def once(np_=None, ns_=None):
+        np_, ns_ = np_ or n_poses, ns_ or n_steps
+        sample = copy.deepcopy(graphs[:np_])
         t0 = time.perf_counter()
-        osampler.sampling_phore(sample, om, n_steps, sched, sched, sched, t_to_sigma_fn(margs), margs, batch_size=20)
+        osampler.sampling_phore(sample, om, ns_, sched[:ns_ + 1], sched[:ns_ + 1], sched[:ns_ + 1], t_to_sigma_fn(margs), margs, batch_size=20)
         return time.perf_counter() - t0
 
-    # BASELINE.md 3 says os.cpu_count() threads; on the many-core GPU hosts these small ops run SLOWER with every core (fork/join
-    # per op), so the warm-up run is done at both settings and the faster one is used for the three timed runs.
+    # BASELINE.md 3 planned os.cpu_count() threads.  Measured on the 256-thread GPU host (round 2, profiles/r2_cpu_threads.md): a
+    # 4-pose x 1-step probe takes 0.21 s with 32 torch threads and 175.9 s with 256 (fork/join per small op): the baseline
+    # uses min(cpu_count, 32) threads, which is the FASTER setting for the CPU side.
     ncpu = os.cpu_count() or 1
-    cands = sorted({ncpu, min(ncpu, 32)})
-    warm = {}
-    for n in cands:
-        torch.set_num_threads(n)
-        warm[n] = once()
-    best = min(warm, key=warm.get)
+    best = min(ncpu, 32)
     torch.set_num_threads(best)
+    once()                                           # warm-up, discarded
     runs = sorted(once() for _ in range(3))
     dt = runs[1]
     return dict(value=n_poses * n_steps / dt, unit="pose-steps/s", cores=best, kind="port",
                 sample=(f"{n_poses} poses x {n_steps} steps of the same workload, oracle (torch-CPU fp32 restatement), warm-up discarded, "
-                        f"median of 3 = {dt:.2f} s (runs {', '.join(f'{r:.2f}' for r in runs)}); threads: "
-                        + ", ".join(f"{n} -> {warm[n]:.2f} s warm-up" for n in cands) + f"; host has {ncpu} logical CPUs"))
+                        f"median of 3 = {dt:.2f} s (runs {', '.join(f'{r:.2f}' for r in runs)}); {best} torch threads of {ncpu} logical CPUs "
+                        f"(all {ncpu} is ~800x slower on these small ops: profiles/r2_cpu_threads.md)"))
 
 
 def _free_port():

@@ -589,13 +589,21 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   const bool node_side = dp_resolve_conv_algo(k->conv_algo, w->precision, B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
   const int nb = dp_conv_node_max_nodes();
   const int slices_pl = (b->max_nl + nb - 1) / nb, slices_lp = (b->max_np + nb - 1) / nb;
+  // optional second stream: phore-side convs of a layer (and the torsion head) run beside the ligand-side ones
+  hipStream_t aux = (k->aux_stream && k->ev_fork && k->ev_join) ? (hipStream_t)k->aux_stream : nullptr;
+  auto fork = [&]() {
+    if (aux) { hipEventRecord((hipEvent_t)k->ev_fork, st); hipStreamWaitEvent(aux, (hipEvent_t)k->ev_fork, 0); }
+  };
+  auto join = [&]() {
+    if (aux) { hipEventRecord((hipEvent_t)k->ev_join, aux); hipStreamWaitEvent(st, (hipEvent_t)k->ev_join, 0); }
+  };
   int cur = 0;
   static const int D[5] = {20, 50, 80, 100, 100};
-  auto timed = [&](const DpConvArgs& c, int layer, int which) -> int {
+  auto timed = [&](const DpConvArgs& c, int layer, int which, hipStream_t s_) -> int {
     const bool prof = k->prof_start && k->prof_stop && k->prof_layer == layer && k->prof_conv == which;
-    if (prof) hipEventRecord((hipEvent_t)k->prof_start, st);
-    const int r = dp_tp_conv(&c, st);
-    if (prof) hipEventRecord((hipEvent_t)k->prof_stop, st);
+    if (prof) hipEventRecord((hipEvent_t)k->prof_start, s_);
+    const int r = dp_tp_conv(&c, s_);
+    if (prof) hipEventRecord((hipEvent_t)k->prof_stop, s_);
     return r;
   };
   for (int l = 0; l < 4; ++l) {
@@ -611,13 +619,16 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     a.phase_split = (B * slices < 512) ? 1 : 0;      // under-filled chip: one workgroup per accumulation phase (see DpConvArgs)
     a.sh_stride = 9; a.out_stride = 100; a.resid_stride = 100;
     a.gather_stride = a.attr1_stride = a.attr2_stride = 100;
+    const bool two = aux != nullptr && l != 3;
+    hipStream_t sp_ = two ? aux : st;           // stream of the phore-side convs
+    if (two) fork();
     {
       DpConvArgs c = a;
       c.mode = DP_EDGES_CSR; c.scat_ptr = b->lig_ptr; c.max_scatter = b->max_nl; c.rowptr = k->ll_rowptr; c.rowend = k->ll_rowend; c.nbr = k->ll_nbr;
       c.edge_scat = k->ll_src; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hl; c.edge_emb = k->ll_emb; c.edge_sh = k->ll_sh;
       c.w1p = w->lig_conv[l].w1p; c.w2p = w->lig_conv[l].w2p; c.bn_scale = w->lig_conv[l].bn_scale; c.bn_shift = w->lig_conv[l].bn_shift;
       c.out = hl2; c.accumulate = 0; c.resid = hl; c.resid_width = din;
-      if ((rc = timed(c, l, 0))) return rc;
+      if ((rc = timed(c, l, 0, st))) return rc;
     }
     for (int nv = 0; nv < 2; ++nv) {
       DpConvArgs c = a;
@@ -627,7 +638,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
       if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; }
-      if ((rc = timed(c, l, 1 + nv))) return rc;
+      if ((rc = timed(c, l, 1 + nv, st))) return rc;
     }
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
       {
@@ -636,7 +647,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_scat = b->pp_src; c.gather_tab = hp; c.attr1_tab = hp; c.attr2_tab = hp; c.edge_emb = k->pp_emb; c.edge_sh = k->pp_sh;
         c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
-        if ((rc = timed(c, l, 3))) return rc;
+        if ((rc = timed(c, l, 3, sp_))) return rc;
       }
       for (int nv = 0; nv < 2; ++nv) {
         DpConvArgs c = a;
@@ -646,13 +657,16 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
         if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; }
-        if ((rc = timed(c, l, 4 + nv))) return rc;
+        if ((rc = timed(c, l, 4 + nv, sp_))) return rc;
       }
     }
+    if (two) join();
     cur ^= 1;
   }
   const float* hl = k->h_l[cur];
-  // translation / rotation head
+  // translation / rotation head on the launch stream, torsion head beside it when a second stream was given
+  const bool tor_aux = aux != nullptr && b->n_tor > 0;
+  if (tor_aux) fork();
   hipLaunchKernelGGL(dp::center_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
   {
     DpConvArgs c;
@@ -667,7 +681,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   hipLaunchKernelGGL(dp::trrot_head_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, *w, *k, tr, rot);
   // torsion head
   if (b->n_tor > 0) {
-    hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k, hl);
+    hipStream_t s2 = tor_aux ? aux : st;
+    hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, s2, *b, *w, *k, hl);
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
     c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr; c.precision = w->precision; c.max_scatter = b->max_t > 0 ? b->max_t : 1;
@@ -678,8 +693,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.attr_swap = 1; c.edge_emb = k->t_emb; c.edge_sh = k->t_sh; c.sh_stride = 7;
     c.w1p = w->tor_conv.w1p; c.w2p = w->tor_conv.w2p; c.bn_scale = w->tor_conv.bn_scale; c.bn_shift = w->tor_conv.bn_shift;
     c.out = k->t_q; c.out_stride = 40;
-    if ((rc = dp_tp_conv(&c, st))) return rc;
-    hipLaunchKernelGGL(dp::tor_head_kernel, dim3((b->n_tor + 63) / 64), dim3(64), 0, st, *b, *w, *k, tor);
+    if ((rc = dp_tp_conv(&c, s2))) return rc;
+    hipLaunchKernelGGL(dp::tor_head_kernel, dim3((b->n_tor + 63) / 64), dim3(64), 0, s2, *b, *w, *k, tor);
+    if (tor_aux) join();
   }
   return (int)hipGetLastError();
 }

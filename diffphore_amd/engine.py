@@ -64,11 +64,25 @@ class DpWork(C.Structure):
                 + [("h_l", VOIDP * 2), ("h_p", VOIDP * 2)]
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
-                + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)])
+                + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")])
 
 
 class DpStepParams(C.Structure):
     _fields_ = [(n, c_f32) for n in ("tr_c1", "tr_c2", "rot_c1", "rot_c2", "tor_c1", "tor_c2")] + [("no_torsion", c_i32)]
+
+
+class DpSegment(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("offset", C.c_int64), ("numel", C.c_int64)]
+
+
+class DpModelScalars(C.Structure):
+    _fields_ = [(n, c_f32) for n in ("lig_gauss_coeff", "ph_gauss_coeff", "x_gauss_coeff", "center_gauss_coeff", "scaler", "tr_smin",
+                                     "tr_smax", "rot_smin", "rot_smax", "tor_smin", "tor_smax", "emb_scale")]
+
+
+class DpSchedule(C.Structure):
+    _fields_ = [("steps", c_i32), ("sp", C.POINTER(DpStepParams)), ("t", VOIDP), ("z_tr", VOIDP), ("z_rot", VOIDP), ("z_tor", VOIDP)]
 
 
 def _declare():
@@ -83,6 +97,29 @@ def _declare():
     L.dp_conformer_update.restype = C.c_int
     L.dp_sample_step.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWeights), C.POINTER(DpWork), C.POINTER(DpStepParams)] + [VOIDP] * 7
     L.dp_sample_step.restype = C.c_int
+    L.dp_work_bytes.argtypes = [C.POINTER(DpBatch)]
+    L.dp_work_bytes.restype = C.c_size_t
+    L.dp_work_bind.argtypes = [C.POINTER(DpBatch), VOIDP, C.c_size_t, C.POINTER(DpWork)] + [C.POINTER(VOIDP)] * 3
+    L.dp_work_bind.restype = C.c_int
+    L.dp_work_init.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWork), VOIDP]
+    L.dp_work_init.restype = C.c_int
+    L.dp_weights_segments.argtypes = [c_i32, C.POINTER(DpSegment), c_i32]
+    L.dp_weights_segments.restype = C.c_int
+    L.dp_weights_blob_floats.argtypes = [c_i32]
+    L.dp_weights_blob_floats.restype = C.c_int64
+    L.dp_weights_bind.argtypes = [VOIDP, c_i32, C.POINTER(DpModelScalars), C.POINTER(DpWeights)]
+    L.dp_weights_bind.restype = C.c_int
+    L.dp_sample.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWeights), C.POINTER(DpWork), C.POINTER(DpSchedule), VOIDP, VOIDP, VOIDP, VOIDP]
+    L.dp_sample.restype = C.c_int
+    L.dp_sample_graph_create.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWeights), C.POINTER(DpWork), C.POINTER(DpSchedule), VOIDP, VOIDP,
+                                         VOIDP, C.POINTER(VOIDP)]
+    L.dp_sample_graph_create.restype = C.c_int
+    L.dp_sample_graph_launch.argtypes = [VOIDP, VOIDP]
+    L.dp_sample_graph_launch.restype = C.c_int
+    L.dp_sample_graph_destroy.argtypes = [VOIDP]
+    L.dp_sample_graph_destroy.restype = C.c_int
+    L.dp_resolve_conv_algo.argtypes = [c_i32, c_i32, c_i32]
+    L.dp_resolve_conv_algo.restype = C.c_int
     L._dp_engine_declared = True
     return L
 
@@ -155,57 +192,56 @@ class DeviceModel:
         H["emb_freq"] = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
         self._upload()
 
-    # one flat blob so multi-GPU start-up is a single RCCL broadcast
+    # one flat blob so multi-GPU start-up is a single RCCL broadcast; its layout is defined by the C library
+    # (dp_weights_segments), so that a host without this module can build and bind the same blob
+    def segments(self):
+        L = _declare()
+        prec = _lib.PRECISIONS[self.precision]
+        n = L.dp_weights_segments(prec, None, 0)
+        segs = (DpSegment * n)()
+        assert L.dp_weights_segments(prec, segs, n) == n
+        return [(sg.name.decode(), int(sg.offset), int(sg.numel)) for sg in segs]
+
     def _upload(self, blob: Optional[torch.Tensor] = None):
-        names = list(self.host.keys())
-        sizes = [int(self.host[n].numel()) for n in names]
-        offs, o = [], 0
-        for s in sizes:
-            offs.append(o)
-            o += (s + 3) // 4 * 4                  # 16-byte aligned segments
+        L = _declare()
+        segs = self.segments()
+        missing = [n for n, _, _ in segs if n not in self.host]
+        extra = [n for n in self.host if n not in {x[0] for x in segs}]
+        if missing or extra:
+            raise _lib.DiffPhoreLibraryError(f"parameter blob layout mismatch: missing {missing[:5]}, unexpected {extra[:5]}")
+        total = int(L.dp_weights_blob_floats(_lib.PRECISIONS[self.precision]))
         if blob is None:
-            flat = torch.zeros(o, dtype=torch.float32)
-            for n, off, s in zip(names, offs, sizes):
-                flat[off:off + s] = self.host[n].reshape(-1).float()
+            flat = torch.zeros(total, dtype=torch.float32)
+            for n, off, numel in segs:
+                t = self.host[n].reshape(-1).float()
+                if t.numel() != numel:
+                    raise _lib.DiffPhoreLibraryError(f"parameter segment {n}: {t.numel()} floats, the library expects {numel}")
+                flat[off:off + numel] = t
             blob = flat.to(self.device)
+        assert blob.numel() == total
         self.blob = blob
-        self.dev = {n: blob[off:off + s] for n, off, s in zip(names, offs, sizes)}
+        self.dev = {n: blob[off:off + numel] for n, off, numel in segs}
         self._fill_struct()
 
     def blob_numel(self) -> int:
         return int(self.blob.numel())
 
     def _fill_struct(self):
-        D, w, cfg = self.dev, DpWeights(), self.cfg
-        for n in ("lig_emb", "lig_lin_w", "lig_lin_b", "boarder_emb", "boarder_lin_w", "boarder_lin_b", "ph_emb", "ph_lin_w",
-                  "ph_lin_b", "tor_w0", "tor_w3", "so3_table", "torus_table", "lig_gauss_mu", "ph_gauss_mu", "x_gauss_mu",
-                  "center_gauss_mu", "emb_freq"):
-            setattr(w, n, D[n].data_ptr())
-        for name in ("lig_edge", "ph_edge", "x_edge", "cdt", "pdt", "pmt", "center_edge", "final_edge", "tr_final", "rot_final"):
-            m = getattr(w, name)
-            for part in ("w0", "b0", "w3", "b3"):
-                setattr(m, part, D[f"{name}.{part}"].data_ptr())
-        for name in ("lig_conv", "ph_conv", "l2p_conv", "p2l_conv", "l2p_norm_conv", "p2l_norm_conv"):
-            arr = getattr(w, name)
-            for l in range(4):
-                for part in ("w1p", "w2p", "bn_scale", "bn_shift", "w1n", "w2n"):
-                    if f"{name}.{l}.{part}" in D:
-                        setattr(arr[l], part, D[f"{name}.{l}.{part}"].data_ptr())
-        for name in ("final_conv", "tor_conv"):
-            cw = getattr(w, name)
-            for part in ("w1p", "w2p", "bn_scale", "bn_shift"):
-                setattr(cw, part, D[f"{name}.{part}"].data_ptr())
+        L, cfg = _declare(), self.cfg
 
         def coeff(mu):                             # GaussianSmearing.__init__ (:1009-1010)
             return -0.5 / (mu[1] - mu[0]).item() ** 2
-        w.lig_gauss_coeff, w.ph_gauss_coeff = coeff(self.host["lig_gauss_mu"]), coeff(self.host["ph_gauss_mu"])
-        w.x_gauss_coeff, w.center_gauss_coeff = coeff(self.host["x_gauss_mu"]), coeff(self.host["center_gauss_mu"])
-        w.scaler = cfg.scaler
-        w.tr_smin, w.tr_smax = cfg.tr_sigma_min, cfg.tr_sigma_max
-        w.rot_smin, w.rot_smax = cfg.rot_sigma_min, cfg.rot_sigma_max
-        w.tor_smin, w.tor_smax = cfg.tor_sigma_min, cfg.tor_sigma_max
-        w.emb_scale = cfg.embedding_scale
-        w.precision = _lib.PRECISIONS[self.precision]
+        sc = DpModelScalars()
+        sc.lig_gauss_coeff, sc.ph_gauss_coeff = coeff(self.host["lig_gauss_mu"]), coeff(self.host["ph_gauss_mu"])
+        sc.x_gauss_coeff, sc.center_gauss_coeff = coeff(self.host["x_gauss_mu"]), coeff(self.host["center_gauss_mu"])
+        sc.scaler = cfg.scaler
+        sc.tr_smin, sc.tr_smax = cfg.tr_sigma_min, cfg.tr_sigma_max
+        sc.rot_smin, sc.rot_smax = cfg.rot_sigma_min, cfg.rot_sigma_max
+        sc.tor_smin, sc.tor_smax = cfg.tor_sigma_min, cfg.tor_sigma_max
+        sc.emb_scale = cfg.embedding_scale
+        w = DpWeights()
+        _lib.check(L.dp_weights_bind(self.blob.data_ptr(), _lib.PRECISIONS[self.precision], C.byref(sc), C.byref(w)), "dp_weights_bind")
+        self.scalars = sc
         self.struct = w
 
 
@@ -341,37 +377,73 @@ class PackedBatch:
 
 
 class Workspace:
+    """One device block sized and carved by the C library (dp_work_bytes / dp_work_bind); `t[...]` are typed views of its arrays."""
+    _SHAPES = dict(lig_x_emb=("f", "n_lig", 20), ph_x_emb=("f", "n_ph", 20), pair_pre=("f", "n_lig", 220), pair_fm=("f", "n_lig", 11),
+                   pp_pre=("f", "n_pp", 20), pp_sh=("f", "n_pp", 9), tparams=("f", "B", 32), ll_rowptr=("i", "n_lig", 1),
+                   ll_rowend=("i", "n_lig", 1), ll_nbr=("i", "ll_cap", 1), ll_src=("i", "ll_cap", 1), ll_emb=("f", "ll_cap", 20),
+                   ll_sh=("f", "ll_cap", 9), pp_emb=("f", "n_pp", 20), x_emb=("f", "n_x", 20), x_sh=("f", "n_x", 9), x_nsh=("f", "n_x", 9),
+                   x_ew=("f", "n_x", 1), c_emb=("f", "n_lig", 20), c_sh=("f", "n_lig", 9), gpred=("f", "B", 12), t_rowptr=("i", "nT", 1),
+                   t_rowend=("i", "nT", 1), t_nbr=("i", "nT", 32), t_src=("i", "nT", 32), t_emb=("f", "nT", 640), t_sh=("f", "nT", 224),
+                   t_hb=("f", "nT", 20), t_q=("f", "nT", 40), status=("i", "B", 1))
+
     def __init__(self, pb: PackedBatch):
+        L = _declare()
         dev, s = pb.device, pb.struct
-        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)      # noqa: E731
-        i = lambda *shape: torch.empty(*shape, dtype=torch.int32, device=dev)        # noqa: E731
-        nT = max(s.n_tor, 1)
-        T = dict(lig_x_emb=f(s.n_lig, 20), ph_x_emb=f(s.n_ph, 20), pair_pre=f(s.n_lig, 11, 20), pair_fm=f(s.n_lig, 11),
-                 pp_pre=f(max(s.n_pp, 1), 20), pp_sh=f(max(s.n_pp, 1), 9), tparams=torch.zeros(s.B, 32, device=dev),
-                 ll_rowptr=i(s.n_lig), ll_rowend=i(s.n_lig), ll_nbr=i(max(s.ll_cap, 1)), ll_src=i(max(s.ll_cap, 1)),
-                 ll_emb=f(max(s.ll_cap, 1), 20), ll_sh=f(max(s.ll_cap, 1), 9), pp_emb=f(max(s.n_pp, 1), 20),
-                 x_emb=f(s.n_x, 20), x_sh=f(s.n_x, 9), x_nsh=f(s.n_x, 9), x_ew=f(s.n_x),
-                 h_l0=torch.zeros(s.n_lig, 100, device=dev), h_l1=torch.zeros(s.n_lig, 100, device=dev),
-                 h_p0=torch.zeros(s.n_ph, 100, device=dev), h_p1=torch.zeros(s.n_ph, 100, device=dev),
-                 c_emb=f(s.n_lig, 20), c_sh=f(s.n_lig, 9), gpred=f(s.B, 12),
-                 t_rowptr=i(nT), t_rowend=i(nT), t_nbr=i(nT * 32), t_src=i(nT * 32), t_emb=f(nT * 32, 20), t_sh=f(nT * 32, 7),
-                 t_hb=f(nT, 20), t_q=f(nT, 40), status=torch.zeros(s.B, dtype=torch.int32, device=dev))
-        self.t = T
+        nbytes = int(L.dp_work_bytes(C.byref(s)))
+        if nbytes <= 0:
+            raise _lib.DiffPhoreLibraryError("dp_work_bytes rejected the batch")
+        self.block = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        base = (self.block.data_ptr() + 255) // 256 * 256
         w = DpWork()
-        for k, v in T.items():
-            if k in ("h_l0", "h_l1", "h_p0", "h_p1"):
-                continue
-            setattr(w, k, v.data_ptr())
-        w.h_l[0], w.h_l[1] = T["h_l0"].data_ptr(), T["h_l1"].data_ptr()
-        w.h_p[0], w.h_p[1] = T["h_p0"].data_ptr(), T["h_p1"].data_ptr()
+        ptrs = [VOIDP(), VOIDP(), VOIDP()]
+        _lib.check(L.dp_work_bind(C.byref(s), base, nbytes, C.byref(w), *[C.byref(p) for p in ptrs]), "dp_work_bind")
+        _lib.check(L.dp_work_init(C.byref(s), C.byref(w), _stream()), "dp_work_init")
         self.struct = w
-        self.tr = f(s.B, 3)
-        self.rot = f(s.B, 3)
-        self.tor = f(nT)
+        lead = base - self.block.data_ptr()
+        f32 = self.block[lead:lead + nbytes].view(torch.float32)
+        i32 = self.block[lead:lead + nbytes].view(torch.int32)
+        dims = dict(n_lig=s.n_lig, n_ph=s.n_ph, n_pp=max(s.n_pp, 1), n_x=s.n_x, ll_cap=max(s.ll_cap, 1), B=s.B, nT=max(s.n_tor, 1))
+
+        def view(ptr, kind, rows, cols):
+            off = (int(ptr) - base) // 4
+            v = (f32 if kind == "f" else i32)[off:off + rows * cols]
+            return v if cols == 1 else v.view(rows, cols)
+        T = {k: view(getattr(w, k), kind, dims[rk], cols) for k, (kind, rk, cols) in self._SHAPES.items()}
+        T["h_l0"], T["h_l1"] = view(w.h_l[0], "f", s.n_lig, 100), view(w.h_l[1], "f", s.n_lig, 100)
+        T["h_p0"], T["h_p1"] = view(w.h_p[0], "f", s.n_ph, 100), view(w.h_p[1], "f", s.n_ph, 100)
+        self.t = T
+        nT = dims["nT"]
+        self.tr, self.rot = view(ptrs[0].value, "f", s.B, 3), view(ptrs[1].value, "f", s.B, 3)
+        self.tor = view(ptrs[2].value, "f", nT, 1)
         self.n_tor = s.n_tor
 
 
+class _HipHandles:
+    """A second stream + two events for dp_forward's optional fork/join (HIP runtime through ctypes; torch owns no handle here)."""
+
+    def __init__(self):
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(VOIDP), C.c_uint]
+        hip.hipEventCreateWithFlags.argtypes = [C.POINTER(VOIDP), C.c_uint]
+        hip.hipStreamDestroy.argtypes = [VOIDP]
+        hip.hipEventDestroy.argtypes = [VOIDP]
+        self.hip = hip
+        self.stream, self.ev_fork, self.ev_join = VOIDP(), VOIDP(), VOIDP()
+        assert hip.hipStreamCreateWithFlags(C.byref(self.stream), 1) == 0          # hipStreamNonBlocking
+        assert hip.hipEventCreateWithFlags(C.byref(self.ev_fork), 2) == 0          # hipEventDisableTiming
+        assert hip.hipEventCreateWithFlags(C.byref(self.ev_join), 2) == 0
+
+    def __del__(self):
+        try:
+            self.hip.hipEventDestroy(self.ev_fork)
+            self.hip.hipEventDestroy(self.ev_join)
+            self.hip.hipStreamDestroy(self.stream)
+        except Exception:      # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 CONV_ALGOS = {"auto": 0, "edge": 1, "node": 2}
+TWO_STREAM_MAX_POSES = 256        # below this a single conv launch leaves CUs idle (DESIGN.md 6)
 
 
 class Engine:
@@ -390,7 +462,27 @@ class Engine:
         self.L.dp_resolve_conv_algo.argtypes = [c_i32, c_i32, c_i32]
         self.L.dp_resolve_conv_algo.restype = C.c_int
         self.conv_algo = {1: "edge", 2: "node"}[self.L.dp_resolve_conv_algo(CONV_ALGOS[conv_algo], model.struct.precision, pb.B)]
+        self._handles = None
+        self._graph = None
+        two = os.environ.get("DIFFPHORE_TWO_STREAMS", "auto")
+        if two == "1" or (two == "auto" and pb.B < TWO_STREAM_MAX_POSES):
+            self.enable_two_streams()
         _lib.check(self.L.dp_prepare(C.byref(pb.struct), C.byref(model.struct), C.byref(self.ws.struct), _stream()), "dp_prepare")
+
+    def enable_two_streams(self):
+        """dp_forward then runs the phore-side convs of a layer and the torsion head on a second stream (bit-identical results;
+        pays when the batch is too small to fill the chip with one conv at a time)."""
+        if self._handles is None:
+            self._handles = _HipHandles()
+            w = self.ws.struct
+            w.aux_stream, w.ev_fork, w.ev_join = self._handles.stream, self._handles.ev_fork, self._handles.ev_join
+
+    def __del__(self):
+        if getattr(self, "_graph", None):
+            try:
+                self.L.dp_sample_graph_destroy(self._graph)
+            except Exception:      # noqa: BLE001
+                pass
 
     def forward(self):
         ws = self.ws
@@ -409,3 +501,34 @@ class Engine:
         _lib.check(self.L.dp_sample_step(C.byref(self.pb.struct), C.byref(self.model.struct), C.byref(ws.struct), C.byref(sp),
                                          ws.tr.data_ptr(), ws.rot.data_ptr(), ws.tor.data_ptr(), _lib.ptr(z_tr), _lib.ptr(z_rot),
                                          _lib.ptr(z_tor), _stream()), "dp_sample_step")
+
+    def sample(self, sps: Sequence[DpStepParams], times: torch.Tensor, z_tr=None, z_rot=None, z_tor=None, graph: bool = False):
+        """The whole reverse-diffusion loop in ONE library call (dp_sample): `sps` per-step scalars, `times` [S,3] device tensor,
+        `z_*` device noise tables [S,B,3] / [S,B,3] / [S,n_tor] or None.  `graph=True` captures the loop into a hipGraph (kept for
+        replays with the same tables) and launches it."""
+        ws, S = self.ws, len(sps)
+        arr = (DpStepParams * S)(*sps)
+        assert times.is_contiguous() and tuple(times.shape) == (S, 3) and times.dtype == torch.float32 and times.is_cuda
+        sch = DpSchedule()
+        sch.steps, sch.sp, sch.t = S, arr, times.data_ptr()
+        sch.z_tr, sch.z_rot, sch.z_tor = _lib.ptr(z_tr), _lib.ptr(z_rot), _lib.ptr(z_tor)
+        self._keep = (arr, times, z_tr, z_rot, z_tor)            # the graph bakes these pointers in
+        args = (C.byref(self.pb.struct), C.byref(self.model.struct), C.byref(ws.struct), C.byref(sch), ws.tr.data_ptr(), ws.rot.data_ptr(),
+                ws.tor.data_ptr())
+        if not graph:
+            _lib.check(self.L.dp_sample(*args, _stream()), "dp_sample")
+            return
+        if self._graph:
+            self.L.dp_sample_graph_destroy(self._graph)
+            self._graph = None
+        torch.cuda.current_stream().synchronize()               # capture happens on the library's own stream: order it after pending work
+        g = VOIDP()
+        _lib.check(self.L.dp_sample_graph_create(*args, C.byref(g)), "dp_sample_graph_create")
+        self._graph = g
+        self.replay()
+
+    def replay(self):
+        """Launch the captured loop again (same tables; the caller resets pos / norm / status first)."""
+        if not self._graph:
+            raise RuntimeError("no captured loop: call sample(..., graph=True) first")
+        _lib.check(self.L.dp_sample_graph_launch(self._graph, _stream()), "dp_sample_graph_launch")

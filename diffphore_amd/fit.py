@@ -106,7 +106,7 @@ def fit(args, model, complex_graphs, device, t_to_sigma, tmp_log: str = "", n_re
         docked_file, log_file = _paths(args, name)
         if os.path.exists(docked_file) and os.path.exists(log_file) and not getattr(args, "overwrite", False):
             log = json.load(open(log_file))
-            results[i] = (log["name"], log["fitscore"], log["run_time"], None, None)
+            results[i] = (log["name"], log["fitscore"] if log["fitscore"] is not None else [-2.0] * N, log["run_time"], None, None)
         elif g["ligand"].pos.shape[0] == 0:
             print(f"[W] Graph {[name]} with 0 atoms, skipped")
         else:
@@ -125,34 +125,48 @@ def fit(args, model, complex_graphs, device, t_to_sigma, tmp_log: str = "", n_re
         scores = None
         if scorer is not None:
             scores = scorer(args, dock_pose, name, g)
-        if scores is None or len(scores) == 0:
-            scores = [-2.0] * N
+        scored = scores is not None and len(scores) > 0
+        if scored:
+            scores = [float(s) for s in scores]
+            # the reference writes the ranked SDF inside calculate_fitscore, i.e. only when scoring succeeded (sampling.py:447-498):
+            # without it a later run finds no `*_ranked.sdf`, does not resume from the log and scores the complex again
+            store_ranked_poses(args, dock_pose, name, mol, scores)
+        else:
             print(f"[W] fitscore calculated with error and set as -2.0 for `{name}`")
-        scores = [float(s) for s in scores]
-        store_ranked_poses(args, dock_pose, name, mol, scores)
         _, log_file = _paths(args, name)
         os.makedirs(os.path.dirname(log_file), exist_ok=True)
-        json.dump({"name": name, "fitscore": scores, "run_time": run_time}, open(log_file, "w"), indent=4)
-        results[i] = (name, scores, run_time, initial, [p.docked_poses for p in poses] if keep else None)
+        json.dump({"name": name, "fitscore": scores if scored else None, "run_time": run_time}, open(log_file, "w"), indent=4)   # inference.py:241-245
+        results[i] = (name, scores if scored else [-2.0] * N, run_time, initial, [p.docked_poses for p in poses] if keep else None)
+
+    def finish_safe(i, poses, initial, run_time):
+        """Scoring / writing problems concern one complex only: never a reason to sample anything again."""
+        try:
+            finish(i, poses, initial, run_time)
+        except Exception as e:      # noqa: BLE001
+            print(f"[W] Error occured when fitting {_name(complex_graphs[i])} to the reference pharamcophore, skipped. {e}")
 
     done = 0
     for lo in range(0, len(todo), per_launch):
         group = todo[lo:lo + per_launch]
+        sampled = None
         try:
-            poses, initial, dt = _sample(args, model, [complex_graphs[i] for i in group], N, device, t_to_sigma, sched)
-            for c, i in enumerate(group):
-                finish(i, poses[c * N:(c + 1) * N], initial[c * N:(c + 1) * N] if initial else None, dt / len(group))
-        except Exception as e:                                   # per-complex retry bookkeeping of inference.py:196-218
+            sampled = _sample(args, model, [complex_graphs[i] for i in group], N, device, t_to_sigma, sched)
+        except Exception as e:                                   # only SAMPLER errors lead to re-sampling (inference.py:196-218)
             if "failed to converge" not in str(e):
                 print(f"[W] Error occured when fitting a batch of {len(group)} complexes, retrying one by one. {e}")
-            for i in group:
+        if sampled is not None:
+            poses, initial, dt = sampled
+            for c, i in enumerate(group):
+                finish_safe(i, poses[c * N:(c + 1) * N], initial[c * N:(c + 1) * N] if initial else None, dt / len(group))
+        else:
+            for i in group:                                      # per-complex retry bookkeeping of the reference
+                if i in results:
+                    continue
                 name = _name(complex_graphs[i])
                 failed = 0
                 while True:
                     try:
                         poses, initial, dt = _sample(args, model, [complex_graphs[i]], N, device, t_to_sigma, sched)
-                        finish(i, poses, initial, dt)
-                        break
                     except Exception as e2:
                         if "failed to converge" in str(e2):
                             failed += 1
@@ -160,9 +174,11 @@ def fit(args, model, complex_graphs, device, t_to_sigma, tmp_log: str = "", n_re
                                 print("[W] SVD failed to converge 5 times - skipping the complex")
                                 break
                             print("[W] SVD failed to converge - trying again with a new sample")
-                        else:
-                            print(f"[W] Error occured when fitting {name} to the reference pharamcophore, skipped. {e2}")
-                            break
+                            continue
+                        print(f"[W] Error occured when fitting {name} to the reference pharamcophore, skipped. {e2}")
+                        break
+                    finish_safe(i, poses, initial, dt)
+                    break
         done += len(group)
         if tmp_log != "" and (done // n_report) > ((done - len(group)) // n_report):
             print(f"[I] {done}/{len(todo)} processed...")

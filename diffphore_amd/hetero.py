@@ -216,5 +216,7 @@ class Batch(HeteroData):
                     continue
                 if isinstance(v, list) and len(v) == B:
                     g._attrs[a] = v[i]
+                elif torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B:
+                    g._attrs[a] = v[i:i + 1]          # graph-level tensors (e.g. original_center [B,3]) come back as [1,...], like PyG
             out.append(g)
         return out

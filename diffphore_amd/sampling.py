@@ -13,6 +13,7 @@ Extra, optional keywords:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -21,6 +22,9 @@ from scipy.spatial.transform import Rotation as R
 
 from . import _lib
 from .engine import DpStepParams, Engine, PackedBatch, _declare, _stream
+
+
+GRAPH_MAX_POSES = 128      # batches up to this size replay the captured loop
 
 
 def _step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero_noise) -> DpStepParams:
@@ -77,13 +81,27 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
     pb, dev = eng.pb, eng.pb.device
     no_torsion = bool(getattr(model_args, "no_torsion", False))
     keep_update = bool(getattr(model_args, "keep_update", False))
+    eng.ws.t["status"].zero_()     # dp_conformer_update ORs its flag in: a run on a reused engine must not inherit an old failure
     if Z is not None:
-        Z = {k: v.to(dev, torch.float32) for k, v in Z.items()}
-    T_all = T_all.to(dev)
+        Z = {k: v.to(dev, torch.float32).contiguous() for k, v in Z.items()}
+    T_all = T_all.to(dev).contiguous()
+    sps = []
     for t_idx in range(inference_steps):
         last = t_idx == inference_steps - 1
         zero = no_random or (no_final_step_noise and last)
-        sp = _step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero)
+        sps.append(_step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero))
+    if not keep_update and visualization_list is None and os.environ.get("DIFFPHORE_WHOLE_LOOP", "1") != "0":
+        # the whole loop in one library call (dp_sample): times and noise are device tables indexed by the step; small batches replay
+        # it from a hipGraph (launch-gap bound), large ones enqueue it eagerly (GPU bound either way)
+        g = os.environ.get("DIFFPHORE_GRAPH", "auto")
+        use_graph = g == "1" or (g == "auto" and pb.B <= GRAPH_MAX_POSES)
+        z_tor = Z["tor"] if (Z is not None and not no_torsion and Z["tor"].numel()) else None
+        eng.sample(sps, T_all, Z["tr"] if Z is not None else None, Z["rot"] if Z is not None else None, z_tor, graph=use_graph)
+        return
+    for t_idx in range(inference_steps):
+        last = t_idx == inference_steps - 1
+        zero = no_random or (no_final_step_noise and last)
+        sp = sps[t_idx]
         pb.t.copy_(T_all[t_idx].expand(pb.B, 3))
         z_tr = z_rot = z_tor = None
         if not (ode or zero):
@@ -356,6 +374,7 @@ def sampling_phore_with_fitscore(data_list, model, inference_steps, tr_schedule,
     if R > 1 and not no_random and fitscore_fn is None:
         raise ValueError("random_samples > 1 needs fitscore_fn (the reference calls the AncPhore binary here)")
     eng = Engine(model.device_model, PackedBatch(data_list, device))
+    eng.ws.t["status"].zero_()
     pb = eng.pb
     dev = pb.device
     nT = int(pb.tor_ptr[-1])

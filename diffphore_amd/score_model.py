@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import config as cfgmod
@@ -84,13 +85,41 @@ class TensorProductScoreModel:
         return self._dev
 
     # ---- forward ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _fingerprint(data):
+        """Cheap content key of the STATIC part of a collated batch (topology, categorical features, masks): packed engines are only
+        reused for a batch with the same fingerprint.  (`id(data)` is not a key: CPython reuses addresses of freed objects.)"""
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+
+        def add(t):
+            a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+            h.update(str(a.shape).encode())
+            h.update(np.ascontiguousarray(a).tobytes())
+
+        L, P = data["ligand"], data["phore"]
+        for t in (L.x, L.edge_mask, L.phorefp, L.norm_angle1, L.norm_angle2, data["ligand", "ligand"].edge_index,
+                  data["ligand", "ligand"].edge_attr, P.x, P.pos, P.norm, P.phoretype, data["phore", "phore"].edge_index):
+            add(t)
+        for name in ("batch",):
+            if name in L:
+                add(L[name])
+            if name in P:
+                add(P[name])
+        mr = L.mask_rotate
+        for m in (mr if isinstance(mr, (list, tuple)) else [mr]):
+            add(np.asarray(m))
+        return h.hexdigest()
+
     def engine_for(self, data) -> Engine:
-        """Pack `data` (a collated batch) - reusing the packed topology when the same batch object comes back."""
-        key = (id(data), int(data["ligand"].pos.shape[0]), int(data["phore"].pos.shape[0]))
+        """Pack `data` (a collated batch), reusing the packed topology when a batch with the same static content comes back (the
+        calibrated training sampler calls `sample_step` on the same batch once per step)."""
+        key = self._fingerprint(data)
         if self._engine is None or self._cache_key != key:
             graphs = data.to_data_list() if hasattr(data, "to_data_list") else [data]
             self._engine = Engine(self.device_model, PackedBatch(graphs, self.device))
             self._cache_key = key
+        self._engine.ws.t["status"].zero_()       # the Kabsch flag is sticky on the device: a reused engine starts clean
         return self._engine
 
     def forward(self, data):

@@ -19,6 +19,7 @@
 #ifndef DIFFPHORE_AMD_H
 #define DIFFPHORE_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -202,7 +203,8 @@ typedef struct DpWeights {
   int32_t precision;           /* DpPrecision the conv weights were packed for */
 } DpWeights;
 
-/* Caller-owned scratch; sizes in floats/ints are given by dp_work_sizes(). */
+/* Caller-owned scratch.  Size it with dp_work_bytes(batch), allocate ONE device block (256-byte aligned), carve it with
+ * dp_work_bind() and zero the few arrays that need it with dp_work_init(); the array shapes below are what those functions assume. */
 typedef struct DpWork {
   /* one-time static tables (dp_prepare) */
   float* lig_x_emb;    /* [n_lig,20] */
@@ -231,6 +233,10 @@ typedef struct DpWork {
   void *prof_start, *prof_stop;
   int32_t prof_layer, prof_conv;
   int32_t conv_algo;                /* DpConvAlgo for the dense cross convs of dp_forward */
+  /* optional second stream + two hipEvent_t handles (all three or none): dp_forward then runs the pharmacophore-side convs of a
+   * layer (and the torsion head) on `aux_stream`, forked from / joined back to the launch stream with the events.  Results are
+   * bit-identical; it only helps batches too small to fill the chip with one conv at a time.  Capturable into a hipGraph. */
+  void *aux_stream, *ev_fork, *ev_join;
 } DpWork;
 
 typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */
@@ -260,6 +266,53 @@ int dp_fit_overlap(const DpBatch* b, const float* pos, float ex_lambda, float* s
 /* dp_forward + dp_conformer_update */
 int dp_sample_step(const DpBatch* b, const DpWeights* w, DpWork* k, const DpStepParams* sp, float* tr, float* rot, float* tor,
                    const float* z_tr, const float* z_rot, const float* z_tor, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * What a host without diffphore_amd/engine.py needs (tests/c_host/dp_host_forward.c uses nothing else):
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* bytes of the single device block that holds every DpWork array plus the tr / rot / tor outputs of `b` (0 on bad input) */
+size_t dp_work_bytes(const DpBatch* b);
+/* carve `base` (device pointer, 256-byte aligned, >= dp_work_bytes) into *out and the three output arrays; touches no memory */
+int dp_work_bind(const DpBatch* b, void* base, size_t bytes, DpWork* out, float** tr, float** rot, float** tor);
+/* stream-ordered zeroing of the arrays that must start at zero (feature ping-pong buffers, tparams, status) */
+int dp_work_init(const DpBatch* b, DpWork* k, void* stream);
+
+/* The parameter blob: every tensor DpWeights points to lives in ONE flat float array (one RCCL broadcast at start-up).  Its layout
+ * is defined here: segment names ("lig_conv.2.w2p", "x_edge.w0", "so3_table", ...), offsets and sizes in floats.  Conv segments
+ * hold the output of dp_pack_conv_weights / dp_pack_conv_weights_node / dp_pack_bn; the others are the reference tensors
+ * flattened row-major (embedding tables concatenated in feature order; src/models/score_model_phore.py:248-291,524-641). */
+typedef struct DpSegment { char name[48]; int64_t offset; int64_t numel; } DpSegment;
+int dp_weights_segments(int32_t precision, DpSegment* out, int32_t cap);   /* returns the number of segments (also when out == NULL) */
+int64_t dp_weights_blob_floats(int32_t precision);
+typedef struct DpModelScalars {
+  float lig_gauss_coeff, ph_gauss_coeff, x_gauss_coeff, center_gauss_coeff;  /* GaussianSmearing.coeff = -0.5 / (offset[1]-offset[0])^2 */
+  float scaler;                                                                /* 100.0 */
+  float tr_smin, tr_smax, rot_smin, rot_smax, tor_smin, tor_smax;              /* model_parameters.yml sigma ranges */
+  float emb_scale;                                                             /* 10000 */
+} DpModelScalars;
+/* fill *w with pointers into the DEVICE blob (layout above) and the scalars */
+int dp_weights_bind(const float* blob, int32_t precision, const DpModelScalars* sc, DpWeights* w);
+/* HOST pointers: e3nn BatchNorm(eval) of conv kind `kind` as out = x*scale + shift per output channel (running_mean / bias cover
+ * the 0e channels only; e3nn/nn/_batchnorm.py semantics) */
+int dp_pack_bn(int32_t kind, const float* running_mean, const float* running_var, const float* weight, const float* bias, float eps,
+               float* scale, float* shift);
+
+/* The whole reverse-diffusion loop of sampling_phore (src/utils/sampling.py:204-255) as one call: for step i, set every pose's
+ * diffusion times to t[i], run the score model, perturb and update the conformers.  Nothing synchronises with the host. */
+typedef struct DpSchedule {
+  int32_t steps;
+  const DpStepParams* sp;        /* HOST array [steps]: the per-step scalars the reference computes on the host (:205-244) */
+  const float* t;                /* DEVICE [steps,3]: t_tr, t_rot, t_tor of every step (set_time_phore broadcasts them to all poses) */
+  const float *z_tr, *z_rot;     /* DEVICE pre-drawn normals [steps,B,3] or NULL */
+  const float* z_tor;            /* DEVICE [steps,n_tor] or NULL */
+} DpSchedule;
+int dp_sample(const DpBatch* b, const DpWeights* w, DpWork* k, const DpSchedule* s, float* tr, float* rot, float* tor, void* stream);
+/* the same loop captured into a hipGraph (all pointers are baked in): create once per (batch, workspace, schedule), replay with
+ * dp_sample_graph_launch; bit-identical to dp_sample */
+int dp_sample_graph_create(const DpBatch* b, const DpWeights* w, DpWork* k, const DpSchedule* s, float* tr, float* rot, float* tor,
+                           void** graph_exec);
+int dp_sample_graph_launch(void* graph_exec, void* stream);
+int dp_sample_graph_destroy(void* graph_exec);
 
 /* sizeof() of DpConvArgs, DpBatch, DpWeights, DpWork, DpStepParams, DpMlp (binding self-check) */
 int dp_struct_sizes(int32_t* out, int32_t n);

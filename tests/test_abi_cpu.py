@@ -13,9 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "diffphore_amd.h")).read()
-    names = set(re.findall(r"^\s*int\s+(dp_\w+)\s*\(", hdr, flags=re.M))
-    assert {"dp_tp_conv", "dp_forward", "dp_sample_step", "dp_conformer_update", "dp_prepare", "dp_randomize_position", "dp_fit_overlap",
-            "dp_pack_conv_weights", "dp_abi_version", "dp_struct_sizes"} <= names
+    names = set(re.findall(r"^\s*(?:int|size_t|int64_t)\s+(dp_\w+)\s*\(", hdr, flags=re.M))
+    assert {"dp_tp_conv", "dp_tp_conv_node", "dp_forward", "dp_sample_step", "dp_sample", "dp_sample_graph_create", "dp_sample_graph_launch",
+            "dp_sample_graph_destroy", "dp_conformer_update", "dp_prepare", "dp_randomize_position", "dp_fit_overlap",
+            "dp_pack_conv_weights", "dp_pack_conv_weights_node", "dp_pack_bn", "dp_work_bytes", "dp_work_bind", "dp_work_init",
+            "dp_weights_segments", "dp_weights_blob_floats", "dp_weights_bind", "dp_resolve_conv_algo", "dp_abi_version",
+            "dp_struct_sizes"} <= names
     L = _lib.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in the header but not exported"
@@ -29,6 +32,58 @@ def test_struct_layouts_match_the_compiler():
     want = [C.sizeof(_lib.DpConvArgs), C.sizeof(engine.DpBatch), C.sizeof(engine.DpWeights), C.sizeof(engine.DpWork),
             C.sizeof(engine.DpStepParams), C.sizeof(engine.DpMlp)]
     assert list(out) == want
+
+
+def test_workspace_and_blob_layout_queries_need_no_gpu():
+    """dp_work_bytes / dp_work_bind / dp_weights_segments are pure host arithmetic: callable here, consistent with each other"""
+    L = engine._declare()
+    b = engine.DpBatch()
+    assert L.dp_work_bytes(C.byref(b)) == 0                                   # B == 0 -> rejected
+    b.B, b.n_lig, b.n_ph, b.n_bond, b.n_tor, b.n_pp, b.n_x, b.ll_cap = 4, 120, 128, 250, 32, 900, 3840, 4200
+    n1 = L.dp_work_bytes(C.byref(b))
+    assert n1 > 4 * (3840 * (20 + 9 + 9 + 1) + 4200 * 29 + 2 * 120 * 100)     # at least the big per-edge / per-node arrays
+    w = engine.DpWork()
+    ptrs = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+    base = 1 << 20                                                            # a fake (aligned) device address: bind touches no memory
+    assert L.dp_work_bind(C.byref(b), base, n1, C.byref(w), *[C.byref(p) for p in ptrs]) == 0
+    fields = [getattr(w, n) for n, _ in engine.DpWork._fields_ if n not in ("h_l", "h_p", "prof_start", "prof_stop", "prof_layer",
+                                                                            "prof_conv", "conv_algo", "aux_stream", "ev_fork", "ev_join")]
+    fields += list(w.h_l) + list(w.h_p) + [p.value for p in ptrs]
+    assert all(f is not None and base <= f < base + n1 and f % 256 == 0 for f in fields) and len(set(fields)) == len(fields)
+    assert L.dp_work_bind(C.byref(b), base, n1 - 1, C.byref(w), *[C.byref(p) for p in ptrs]) == -3
+    assert L.dp_work_bind(C.byref(b), base + 8, n1, C.byref(w), *[C.byref(p) for p in ptrs]) == -1
+    b.n_x *= 2
+    assert L.dp_work_bytes(C.byref(b)) > n1
+    for prec in _lib.PRECISIONS.values():
+        n = L.dp_weights_segments(prec, None, 0)
+        segs = (engine.DpSegment * n)()
+        assert L.dp_weights_segments(prec, segs, n) == n
+        end = 0
+        for sg in segs:
+            assert sg.offset >= end and sg.offset % 4 == 0 and sg.numel > 0
+            end = sg.offset + sg.numel
+        assert L.dp_weights_blob_floats(prec) >= end
+        names = [sg.name.decode() for sg in segs]
+        assert len(set(names)) == n and "p2l_conv.3.w2p" in names and ("p2l_conv.3.w2n" in names) == (prec == _lib.PREC_F32)
+
+
+def test_pack_bn_matches_the_python_packer():
+    import numpy as np
+    from diffphore_amd import config, packing, weights
+    L = engine._declare()
+    sd = weights.init_state_dict(3)
+    irs = {2: config.SEQ[3], 4: config.FINAL_OUT, 5: config.TOR_OUT}
+    for kind, prefix in ((2, "encoder.lig_conv_layers.2"), (4, "final_conv"), (5, "tor_bond_conv")):
+        want_s, want_b = packing.bn_affine(sd, prefix + ".batch_norm", irs[kind])
+        t = {k: sd[f"{prefix}.batch_norm.{k}"].float().contiguous() for k in ("running_mean", "running_var", "weight", "bias")}
+        got_s, got_b = np.zeros(want_s.numel(), dtype=np.float32), np.zeros(want_s.numel(), dtype=np.float32)
+        L.dp_pack_bn.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 2
+        rc = L.dp_pack_bn(kind, t["running_mean"].data_ptr() if t["running_mean"].numel() else None, t["running_var"].data_ptr(),
+                          t["weight"].data_ptr(), t["bias"].data_ptr() if t["bias"].numel() else None, 1e-5, got_s.ctypes.data,
+                          got_b.ctypes.data)
+        assert rc == 0
+        np.testing.assert_allclose(got_s, want_s.numpy(), rtol=2e-7)
+        np.testing.assert_allclose(got_b, want_b.numpy(), rtol=2e-6, atol=1e-7)
 
 
 def test_bad_arguments_are_rejected_not_crashed():

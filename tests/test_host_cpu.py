@@ -138,3 +138,28 @@ def test_transformation_mask_matches_reference_code(golden_dir):
         assert (me[sel]).all() and sel.sum() == np.asarray(lig["mask_rotate"]).shape[0]
         rows = np.cumsum(me) - 1
         np.testing.assert_array_equal(np.asarray(lig["mask_rotate"]), mr[rows[sel]])
+
+
+def test_batch_keeps_graph_level_tensors_and_fingerprint_tracks_static_content():
+    """`to_data_list` must hand graph-level tensors (original_center) back; the packed-engine cache of the score model is
+    keyed on the batch's static CONTENT, never on `id(data)`."""
+    from diffphore_amd.score_model import TensorProductScoreModel
+    gs = synthetic.synthetic_pairs(3, 3, (8, 12), (1, 3), (6, 9))
+    b = Batch.from_data_list(gs)
+    for g, c in zip(gs, b.to_data_list()):
+        assert torch.equal(torch.as_tensor(g.original_center).reshape(1, 3), c.original_center.reshape(1, 3))
+    fp = TensorProductScoreModel._fingerprint
+    k1 = fp(b)
+    assert fp(Batch.from_data_list(gs)) == k1                       # same content, new object -> same key
+    b2 = Batch.from_data_list(gs)
+    b2["ligand"].pos = b2["ligand"].pos + 1.0                      # diffusion state is not part of the key
+    assert fp(b2) == k1
+    other = synthetic.synthetic_pairs(4, 3, (8, 12), (1, 3), (6, 9))
+    keys = {k1}
+    for variant in (Batch.from_data_list(other), Batch.from_data_list(gs[::-1]), Batch.from_data_list(gs[:2])):
+        keys.add(fp(variant))
+    assert len(keys) == 4
+    b3 = Batch.from_data_list(gs)
+    b3["ligand"].x = b3["ligand"].x.clone()
+    b3["ligand"].x[0, 1] = (b3["ligand"].x[0, 1] + 1) % 4          # an in-place edit of a static field changes the key
+    assert fp(b3) != k1

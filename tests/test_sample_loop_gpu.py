@@ -1,0 +1,81 @@
+"""dp_sample (the whole reverse-diffusion loop in one C call), its hipGraph replay and dp_forward's optional second stream are
+re-arrangements of the SAME launches: final coordinates must be bit-identical to the per-step path (sampling.py:204-255 loop body)."""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffphore_amd import config, synthetic, weights  # noqa: E402
+from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn  # noqa: E402
+from diffphore_amd.sampling import sampling_phore  # noqa: E402
+from diffphore_amd.score_model import TensorProductScoreModel  # noqa: E402
+
+
+def _args():
+    cfg = config.ModelConfig()
+    return types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+
+
+def _run(gs, noise, S, monkeypatch, **env):
+    for k in ("DIFFPHORE_WHOLE_LOOP", "DIFFPHORE_GRAPH", "DIFFPHORE_TWO_STREAMS", "DIFFPHORE_CONV_ALGO"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    args = _args()
+    m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+    sched = get_t_schedule(20)[:S + 1]
+    out, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, batch_size=4, noise=noise,
+                            no_final_step_noise=True)
+    return torch.cat([g["ligand"].pos for g in out]).numpy(), torch.cat([g["ligand"].norm for g in out]).numpy()
+
+
+@pytest.mark.parametrize("algo", ["edge", "node"])
+def test_whole_loop_graph_and_two_streams_are_bit_identical_to_per_step(monkeypatch, algo):
+    gs = synthetic.synthetic_pairs(91, 7, (8, 30), (0, 6), (5, 34))
+    S = 5
+    gen = torch.Generator().manual_seed(3)
+    nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
+    noise = dict(tr=torch.randn(S, len(gs), 3, generator=gen), rot=torch.randn(S, len(gs), 3, generator=gen), tor=torch.randn(S, nT, generator=gen))
+    base = _run(gs, noise, S, monkeypatch, DIFFPHORE_WHOLE_LOOP="0", DIFFPHORE_TWO_STREAMS="0", DIFFPHORE_CONV_ALGO=algo)
+    assert np.all(np.isfinite(base[0]))
+    variants = {
+        "dp_sample eager": dict(DIFFPHORE_GRAPH="0", DIFFPHORE_TWO_STREAMS="0"),
+        "dp_sample graph": dict(DIFFPHORE_GRAPH="1", DIFFPHORE_TWO_STREAMS="0"),
+        "two streams, per step": dict(DIFFPHORE_WHOLE_LOOP="0", DIFFPHORE_TWO_STREAMS="1"),
+        "two streams, graph": dict(DIFFPHORE_GRAPH="1", DIFFPHORE_TWO_STREAMS="1"),
+    }
+    for name, env in variants.items():
+        got = _run(gs, noise, S, monkeypatch, DIFFPHORE_CONV_ALGO=algo, **env)
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), name
+
+
+def test_graph_replay_reproduces_the_run():
+    """replaying the captured loop after resetting the state gives the same trajectory (what a screening driver does per batch)"""
+    from diffphore_amd.engine import DeviceModel, Engine, PackedBatch
+    from diffphore_amd.sampling import _step_params
+    args = _args()
+    gs = synthetic.synthetic_pairs(92, 4, 14, 3, 12)
+    model = DeviceModel(weights.init_state_dict(), config.ModelConfig(), "cuda")
+    pb = PackedBatch(gs, "cuda")
+    eng = Engine(model, pb)
+    S = 4
+    sched = get_t_schedule(20)
+    sps = [_step_params(t, S, sched, sched, sched, t_to_sigma_fn(args), args, False, False) for t in range(S)]
+    T = torch.tensor([[float(sched[t])] * 3 for t in range(S)], device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ztr, zrot = torch.randn(S, pb.B, 3, device="cuda", generator=g), torch.randn(S, pb.B, 3, device="cuda", generator=g)
+    ztor = torch.randn(S, int(pb.tor_ptr[-1]), device="cuda", generator=g)
+    pos0, norm0 = pb.pos.clone(), pb.norm.clone()
+    eng.sample(sps, T, ztr, zrot, ztor, graph=True)
+    a = pb.pos.clone()
+    pb.pos.copy_(pos0)
+    pb.norm.copy_(norm0)
+    eng.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(pb.pos, a) and not torch.equal(a, pos0)
+    assert int(eng.ws.t["status"].abs().sum()) == 0
