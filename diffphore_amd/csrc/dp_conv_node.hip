@@ -36,7 +36,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte load from a 4-byte aligned address
 
 constexpr int NB = 16;        // nodes per workgroup = N of the GEMM-B MFMAs
+constexpr int NPAIR = 2;      // nodes whose GEMM-A chains are interleaved
 constexpr int TCOLS = 15;     // columns of a T tile that are stored (3 m-groups x 5 in-channels, or 10 in-channels of a scalar-output path)
+constexpr int TSTRIDE = TCOLS * NB * 16 + 16;   // floats per wave: 15 column rows of 1 KiB + the dummy 16-byte slots of lanes c == 15
 constexpr int SCOMP = 9;      // per-edge factors staged in LDS: sh1[0..2], M00, M01, M02, M11, M12, M22
 constexpr int HIDN = 60;      // hidden units of the radial MLP (kinds 0-3); unit 60 is the constant one
 
@@ -220,33 +222,46 @@ struct PathStage {
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM-A: T[16 k x 16 cols] per node, through LDS ----------------------------------------------------------------
+        // NPAIR nodes at a time: their MFMA chains are independent, so they issue back to back (a lone 8-deep chain on one
+        // accumulator pays the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 per step instead of the 32-cycle issue rate).
+        // Lanes of the unused 16th column store into a per-wave dummy slot instead of being masked off (no exec juggling).
+        const int twr = c < TCOLS ? c * (NB * 16) : TCOLS * (NB * 16);
 #pragma unroll
-        for (int nn = 0; nn < NB; ++nn) {
-          f32x4 D = {0.f, 0.f, 0.f, 0.f};
+        for (int nn0 = 0; nn0 < NB; nn0 += NPAIR) {
+          f32x4 D[NPAIR];
+#pragma unroll
+          for (int pi = 0; pi < NPAIR; ++pi) D[pi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int t2 = 0; t2 < 2; ++t2) {
-            float z[4];
-            if constexpr (needs_s<ZT>()) {
-              f32x4 sv[NTERM];
+            float z[NPAIR][4];
 #pragma unroll
-              for (int t = 0; t < NTERM; ++t)
-                sv[t] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sS) + nn * (SCOMP * 32 * 4) + t2 * 64 + soff[t]);
+            for (int pi = 0; pi < NPAIR; ++pi) {
+              if constexpr (needs_s<ZT>()) {
+                f32x4 sv[NTERM];
 #pragma unroll
-              for (int rr = 0; rr < 4; ++rr) {
-                float zz = xa[0][4 * t2 + rr] * sv[0][rr];
+                for (int t = 0; t < NTERM; ++t)
+                  sv[t] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sS) + (nn0 + pi) * (SCOMP * 32 * 4) + t2 * 64 + soff[t]);
 #pragma unroll
-                for (int t = 1; t < NTERM; ++t) zz = fmaf(xa[t][4 * t2 + rr], sv[t][rr], zz);
-                z[rr] = zz;
+                for (int rr = 0; rr < 4; ++rr) {
+                  float zz = xa[0][4 * t2 + rr] * sv[0][rr];
+#pragma unroll
+                  for (int t = 1; t < NTERM; ++t) zz = fmaf(xa[t][4 * t2 + rr], sv[t][rr], zz);
+                  z[pi][rr] = zz;
+                }
+              } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) z[pi][rr] = xa[0][4 * t2 + rr];
               }
-            } else {
-#pragma unroll
-              for (int rr = 0; rr < 4; ++rr) z[rr] = xa[0][4 * t2 + rr];
             }
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) D = mfma16(hid[nn][4 * t2 + rr], z[rr], D);
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+              for (int pi = 0; pi < NPAIR; ++pi) D[pi] = mfma16(hid[nn0 + pi][4 * t2 + rr], z[pi][rr], D[pi]);
           }
-          if (c < TCOLS) *reinterpret_cast<f32x4*>(sT + (size_t)c * (NB * 16) + ((((nn << 2) | g) ^ (c & 7)) << 2)) = D;
-          __builtin_amdgcn_sched_barrier(0);       // keep the 16 node bodies apart: hoisting their LDS reads together spills
+#pragma unroll
+          for (int pi = 0; pi < NPAIR; ++pi)
+            *reinterpret_cast<f32x4*>(sT + twr + (c < TCOLS ? (((((nn0 + pi) << 2) | g) ^ (c & 7)) << 2) : (g << 2))) = D[pi];
+          __builtin_amdgcn_sched_barrier(0);       // keep the node bodies apart: hoisting all their LDS reads together spills
         }
         // ---- GEMM-B: out[w][node] += W2[w][(u,k)] T[(u,k)][node] -------------------------------------------------------------
         {
@@ -310,13 +325,13 @@ struct AccStore {
 template <int KIND, int MODE>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
   using S = Spec<KIND>;
-  __shared__ __attribute__((aligned(16))) float s_T[4 * TCOLS * NB * 16];     // wave-private T tiles; reused for the final reduction
+  __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE];              // wave-private T tiles (+ a dummy slot); reused for the final reduction
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];         // per-edge sh factors of the current pass
-  static_assert(4 * NB * S::D_OUT <= 4 * TCOLS * NB * 16, "reduction scratch fits in the T buffers");
+  static_assert(4 * NB * S::D_OUT <= 4 * TSTRIDE, "reduction scratch fits in the T buffers");
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
   const Wg r = wg_of<MODE>(a);
   if (r.n_loc <= 0) return;
-  float* sT = s_T + q * (TCOLS * NB * 16);
+  float* sT = s_T + q * TSTRIDE;
 
   f32x4 acc[n_acc4<KIND>()];
 #pragma unroll
