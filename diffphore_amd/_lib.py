@@ -18,7 +18,7 @@ CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
 PREC_BF16X9 = 4
 PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16x9": PREC_BF16X9}
-EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER = range(4)
+EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER, EDGES_LLPAIR = range(5)
 ALGO_AUTO, ALGO_EDGE, ALGO_NODE = range(3)
 
 
@@ -35,6 +35,7 @@ class DpConvArgs(C.Structure):
         ("out", VOIDP), ("out_stride", c_i32), ("accumulate", c_i32),
         ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32), ("phase_split", c_i32),
         ("w1n", VOIDP), ("w2n", VOIDP), ("algo", c_i32),
+        ("pair_a", VOIDP), ("pair_b", VOIDP), ("pair_ptr", VOIDP),
     ]
 
 

@@ -29,6 +29,28 @@
 #include "../../include/diffphore_amd.h"
 #include "dp_spec.h"
 
+#ifdef DP_PROF   // cycle-stamp breakdown (ablation builds only; tools/bench_conv.py --prof): wave 0 of every workgroup adds its segment times
+__device__ unsigned long long dpn_prof[16];
+struct NProf { unsigned long long prev, acc[5]; };
+__device__ __forceinline__ void nprof_mark(int seg, NProf& p) {
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long now = __builtin_readcyclecounter();
+  if (seg >= 0) p.acc[seg] += now - p.prev;
+  p.prev = now;
+  __builtin_amdgcn_sched_barrier(0);
+}
+#define NPROF(seg) nprof_mark(seg, prof_prev)
+extern "C" int dp_debug_prof_node(unsigned long long* host16, int reset) {
+  if (host16 && hipMemcpyFromSymbol(host16, HIP_SYMBOL(dpn_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(dpn_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+typedef NProf NProfT;
+#else
+#define NPROF(seg)
+typedef int NProfT;
+#endif
+
 namespace dpn {
 using namespace dp;
 
@@ -36,7 +58,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte load from a 4-byte aligned address
 
 constexpr int NB = 16;        // nodes per workgroup = N of the GEMM-B MFMAs
-constexpr int NPAIR = 2;      // nodes whose GEMM-A chains are interleaved
 constexpr int TCOLS = 15;     // columns of a T tile that are stored (3 m-groups x 5 in-channels, or 10 in-channels of a scalar-output path)
 constexpr int TSTRIDE = TCOLS * NB * 16 + 16;   // floats per wave: 15 column rows of 1 KiB + the dummy 16-byte slots of lanes c == 15
 constexpr int SCOMP = 9;      // per-edge factors staged in LDS: sh1[0..2], M00, M01, M02, M11, M12, M22
@@ -128,8 +149,9 @@ template <int KIND> void pack_w2n(const float* fc3_w, const float* fc3_b, float*
 // device
 // -------------------------------------------------------------------------------------------------------------------------
 struct Wg {
-  int pose, n_lo, n_loc, l0, p0, NL, NP, x0, En;
+  int pose, n_lo, n_loc, l0, p0, NL, NP, x0, En, pair0;
 };
+constexpr int LL = DP_EDGES_LLPAIR;
 
 template <int MODE> __device__ __forceinline__ Wg wg_of(const DpConvArgs& a) {
   Wg r;
@@ -142,9 +164,14 @@ template <int MODE> __device__ __forceinline__ Wg wg_of(const DpConvArgs& a) {
   r.n_loc = hi - lo;
   r.l0 = a.lig_ptr[r.pose];
   r.NL = a.lig_ptr[r.pose + 1] - r.l0;
-  r.p0 = a.ph_ptr[r.pose];
-  r.NP = a.ph_ptr[r.pose + 1] - r.p0;
-  r.x0 = a.x_ptr[r.pose];
+  r.p0 = r.NP = r.x0 = r.pair0 = 0;
+  if constexpr (MODE == LL) {
+    r.pair0 = a.pair_ptr[r.pose];
+  } else {
+    r.p0 = a.ph_ptr[r.pose];
+    r.NP = a.ph_ptr[r.pose + 1] - r.p0;
+    r.x0 = a.x_ptr[r.pose];
+  }
   r.En = MODE == DP_EDGES_P2L ? r.NP : r.NL;
   return r;
 }
@@ -154,6 +181,13 @@ template <int MODE> __device__ __forceinline__ int feat_row(const Wg& r, int nod
   return MODE == DP_EDGES_P2L ? r.x0 + (node - r.l0) * r.NP + e : r.x0 + e * r.NP + (node - r.p0);
 }
 template <int MODE> __device__ __forceinline__ int gather_row(const Wg& r, int e) { return MODE == DP_EDGES_P2L ? r.p0 + e : r.l0 + e; }
+// LL mode (ligand-ligand, pair-dense): slot e of scatter atom `node` is the atom pair (node, l0 + e); it carries up to two edges of
+// the reference's multigraph - the radius edge and the bond edge (build_lig_conv_graph concatenates both, :721) - whose edge slots
+// in the CSR-ordered feature arrays come from two pair maps (-1 = no such edge).  Both edges share the geometry (same sh, same
+// gathered row), so T = sum_e hid[e] z[e] only needs the SUM of their hidden vectors: two GEMM1 evaluations, one GEMM-A.
+template <int WHICH> __device__ __forceinline__ int pair_slot(const DpConvArgs& a, const Wg& r, int node, int e) {
+  return (WHICH == 0 ? a.pair_a : a.pair_b)[r.pair0 + (node - r.l0) * r.NL + e];
+}
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -180,10 +214,42 @@ template <int ZT> __device__ __forceinline__ Term term_of(int t, int m) {
   }
 }
 
+// raw gathered operands of column tile (path P, in-channel tile ut) for this lane's 8 edges; masking and sign are applied when the tile
+// starts (finish below), so the loads can be issued a whole GEMM-B ahead
+template <int KIND, int MODE, int P>
+__device__ __forceinline__ void load_x(const DpConvArgs& a, const Wg& r, int et, int lane_l, int ut, float (&xr)[3][8]) {
+  using S = Spec<KIND>;
+  if constexpr (P < S::NPATH) {
+    constexpr PathC pc = S::P[P];
+    constexpr int ZT = pc.ztype;
+    constexpr bool VEC = d_out_of(ZT) == 3;
+    constexpr int NU = VEC ? 5 : 10, DIN = d_in_of(ZT), NTERM = n_terms<ZT>();
+    const int g = lane_l >> 4, c = lane_l & 15;
+    const int m = VEC ? (c >= 10 ? 2 : (c >= 5 ? 1 : 0)) : 0;
+    const int ul = VEC ? c - 5 * m : c;
+    const bool colv = VEC ? c < 15 : c < 10;
+    const int u = colv ? NU * ut + ul : 0;
+    // uniform base + 32-bit lane offset (saddr addressing): no 64-bit address arithmetic per load
+    const float* __restrict__ base = a.gather_tab;
+    unsigned coff[NTERM];
+#pragma unroll
+    for (int t = 0; t < NTERM; ++t) coff[t] = (unsigned)(pc.in_off + u * DIN + term_of<ZT>(t, m).xcomp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = 32 * et + 16 * (j >> 2) + 4 * g + (j & 3);
+      const unsigned roff = (unsigned)gather_row<MODE>(r, e < r.En ? e : 0) * (unsigned)a.gather_stride;
+#pragma unroll
+      for (int t = 0; t < NTERM; ++t) xr[t][j] = base[roff + coff[t]];
+    }
+  }
+}
+
 template <int KIND, int MODE, int P>
 struct PathStage {
+  // `xr`: raw gathered operands of this path's first tile, requested by the previous stage (or the kernel) a GEMM-B earlier
   static __device__ __forceinline__ void run(const DpConvArgs& a, const Wg& r, int et, int q, int lane, const float (&hid)[NB][8],
-                                             float* sT, const float* sS, f32x4 (&acc)[n_acc4<KIND>()]) {
+                                             float* sT, const float* sS, f32x4 (&acc)[n_acc4<KIND>()], float (&xr)[3][8],
+                                             NProfT& prof_prev) {
     using S = Spec<KIND>;
     if constexpr (P < S::NPATH) {
       constexpr PathC pc = S::P[P];
@@ -205,94 +271,128 @@ struct PathStage {
         // ---- gathered operand of this tile's column, for the lane's 8 edges (same rows for every node of the batch) -----------
         float xa[NTERM][8];
         int soff[NTERM];
-        {
-          const int u = NU * ut + ul;
 #pragma unroll
-          for (int t = 0; t < NTERM; ++t) {
-            const Term tm = term_of<ZT>(t, m);
-            soff[t] = (tm.scomp * 32 + 4 * g) * 4;
+        for (int t = 0; t < NTERM; ++t) {
+          const Term tm = term_of<ZT>(t, m);
+          soff[t] = (tm.scomp * 16 + 4 * g) * 4;        // s_S[(nn, t2)][comp][4 g + rr]: a step's 9 comps are 576 contiguous bytes, so the
+                                                        // <= 3 comps a lane group mixes sit in different quarters of the 64 banks
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int e = 32 * et + 16 * (j >> 2) + 4 * g + (j & 3);
-              const bool ok = colv && e < r.En;
-              const float v = a.gather_tab[(size_t)gather_row<MODE>(r, ok ? e : 0) * a.gather_stride + pc.in_off + u * DIN + tm.xcomp];
-              xa[t][j] = ok ? tm.sign * v : 0.f;
-            }
+          for (int j = 0; j < 8; ++j) {
+            const int e = 32 * et + 16 * (j >> 2) + 4 * g + (j & 3);
+            xa[t][j] = (colv && e < r.En) ? tm.sign * xr[t][j] : 0.f;
           }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM-A: T[16 k x 16 cols] per node, through LDS ----------------------------------------------------------------
-        // NPAIR nodes at a time: their MFMA chains are independent, so they issue back to back (a lone 8-deep chain on one
-        // accumulator pays the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 per step instead of the 32-cycle issue rate).
+        // Software pipeline over the 32 "quad steps" (node nn = qs / 2, edge quad t2 = qs % 2) of the batch:
+        //     step qs:  request the sh factors of step qs + 2  |  4 MFMAs of step qs (B operand z_cur)
+        //               ... with the VALU that turns the factors of step qs + 1 (requested one step earlier) into z_nxt in their shadows
+        // so neither the LDS latency nor the z arithmetic sits between two MFMA groups of the same wave.  sched_group_barrier pins
+        // the MFMA / VALU interleave inside a step, sched_barrier keeps steps apart (hoisting all LDS reads together spills).
         // Lanes of the unused 16th column store into a per-wave dummy slot instead of being masked off (no exec juggling).
         const int twr = c < TCOLS ? c * (NB * 16) : TCOLS * (NB * 16);
+        if constexpr (needs_s<ZT>()) {
+          const char* sbase = reinterpret_cast<const char*>(sS);
+          auto loadS = [&](int qs, f32x4 (&sv)[NTERM]) {
 #pragma unroll
-        for (int nn0 = 0; nn0 < NB; nn0 += NPAIR) {
-          f32x4 D[NPAIR];
+            for (int t = 0; t < NTERM; ++t) sv[t] = *reinterpret_cast<const f32x4*>(sbase + qs * (SCOMP * 64) + soff[t]);
+          };
+          auto makeZ = [&](int t2, const f32x4 (&sv)[NTERM], float (&z)[4]) {
 #pragma unroll
-          for (int pi = 0; pi < NPAIR; ++pi) D[pi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rr = 0; rr < 4; ++rr) {
+              float zz = xa[0][4 * t2 + rr] * sv[0][rr];
 #pragma unroll
-          for (int t2 = 0; t2 < 2; ++t2) {
-            float z[NPAIR][4];
+              for (int t = 1; t < NTERM; ++t) zz = fmaf(xa[t][4 * t2 + rr], sv[t][rr], zz);
+              z[rr] = zz;
+            }
+          };
+          f32x4 sv_nxt[NTERM], sv_nn[NTERM];
+          float z_cur[4], z_nxt[4];
+          loadS(0, sv_nn);
+          loadS(1, sv_nxt);
+          makeZ(0, sv_nn, z_cur);
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 D[2];
+          const int twl = c < TCOLS ? 0 : 1;
+          auto tslot = [&](int nn) { return sT + twr + (twl ? (g << 2) : ((((nn << 2) | g) ^ (c & 7)) << 2)); };
 #pragma unroll
-            for (int pi = 0; pi < NPAIR; ++pi) {
-              if constexpr (needs_s<ZT>()) {
-                f32x4 sv[NTERM];
+          for (int qs = 0; qs < 2 * NB; ++qs) {
+            const int nn = qs >> 1, t2 = qs & 1;
+            if (qs + 2 < 2 * NB) loadS(qs + 2, sv_nn);
+            if (qs + 1 < 2 * NB) makeZ((qs + 1) & 1, sv_nxt, z_nxt);
+            if (t2 == 0) D[nn & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < NTERM; ++t)
-                  sv[t] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sS) + (nn0 + pi) * (SCOMP * 32 * 4) + t2 * 64 + soff[t]);
+            for (int rr = 0; rr < 4; ++rr) D[nn & 1] = mfma16(hid[nn][4 * t2 + rr], z_cur[rr], D[nn & 1]);
+            // the finished tile of the PREVIOUS node is stored one step late, behind this step's MFMAs: its last MFMA has long retired
+            if (t2 == 0 && nn > 0) *reinterpret_cast<f32x4*>(tslot(nn - 1)) = D[(nn - 1) & 1];
+            if (qs + 2 < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, NTERM, 0);       // the prefetch reads go first
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                  float zz = xa[0][4 * t2 + rr] * sv[0][rr];
+            for (int rr = 0; rr < 4; ++rr) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // one MFMA ...
+              if (qs + 1 < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x002, NTERM, 0);     // ... then one z value's mul / fma chain
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                  for (int t = 1; t < NTERM; ++t) zz = fmaf(xa[t][4 * t2 + rr], sv[t][rr], zz);
-                  z[pi][rr] = zz;
-                }
-              } else {
+            for (int rr = 0; rr < 4; ++rr) z_cur[rr] = z_nxt[rr];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) z[pi][rr] = xa[0][4 * t2 + rr];
-              }
+            for (int t = 0; t < NTERM; ++t) sv_nxt[t] = sv_nn[t];
+          }
+          *reinterpret_cast<f32x4*>(tslot(NB - 1)) = D[(NB - 1) & 1];
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          // z is the gathered input itself (sh_0 = 1): nothing to fetch or compute per node
+#pragma unroll
+          for (int nn = 0; nn < NB; ++nn) {
+            f32x4 D = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) D = mfma16(hid[nn][j], xa[0][j], D);
+            *reinterpret_cast<f32x4*>(sT + twr + (c < TCOLS ? ((((nn << 2) | g) ^ (c & 7)) << 2) : (g << 2))) = D;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        NPROF(2);
+        // ---- GEMM-B: out[w][node] += W2[w][(u,k)] T[(u,k)][node] -------------------------------------------------------------
+        {
+          const float* wsrc = a.w2n + w2n_path_off<KIND>(P) + (size_t)(ut * MT) * w2n_tile_floats<KIND>(P) + (size_t)(q * 64 + lane_l) * STEPS;
+          f32x4 wf[MT], wn[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) wf[mt] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)mt * w2n_tile_floats<KIND>(P));
+          // i-outer / m-group-inner: one W2 fragment (per M tile) is live at a time and serves the three m components; the next
+          // in-channel's fragment (L2) and the next step's T fragment (LDS) are requested before the current ones are consumed
+          auto readT = [&](int st) {
+            const int col = (VEC ? 5 * (st % NG) : 0) + st / NG;
+            return *reinterpret_cast<const f32x4*>(sT + (size_t)col * (NB * 16) + ((lane_slot ^ (col & 7)) << 2));
+          };
+          f32x4 tv = readT(0), tn;
+#pragma unroll
+          for (int st = 0; st < NU * NG; ++st) {
+            const int i = st / NG, grp = st % NG;
+            if (st + 1 < NU * NG) tn = readT(st + 1);
+            if (grp == 0 && i + 1 < NU) {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) wn[mt] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)mt * w2n_tile_floats<KIND>(P) + 4 * (i + 1));
+            }
+            if (grp == 0 && i == NU - 2) {
+              // the NEXT tile's gathered operands (this path's next in-channel tile, or the next path's first) travel during the tail of
+              // this GEMM-B - behind the last W2 fragment request: vector-memory returns are in order, an earlier burst would delay it
+              if (ut + 1 < pc.mul_in / NU) load_x<KIND, MODE, P>(a, r, et, lane_l, ut + 1, xr);
+              else load_x<KIND, MODE, P + 1>(a, r, et, lane_l, 0, xr);
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-              for (int pi = 0; pi < NPAIR; ++pi) D[pi] = mfma16(hid[nn0 + pi][4 * t2 + rr], z[pi][rr], D[pi]);
-          }
-#pragma unroll
-          for (int pi = 0; pi < NPAIR; ++pi)
-            *reinterpret_cast<f32x4*>(sT + twr + (c < TCOLS ? (((((nn0 + pi) << 2) | g) ^ (c & 7)) << 2) : (g << 2))) = D[pi];
-          __builtin_amdgcn_sched_barrier(0);       // keep the node bodies apart: hoisting all their LDS reads together spills
-        }
-        // ---- GEMM-B: out[w][node] += W2[w][(u,k)] T[(u,k)][node] -------------------------------------------------------------
-        {
-          const float* wsrc = a.w2n + w2n_path_off<KIND>(P) + (size_t)(ut * MT) * w2n_tile_floats<KIND>(P) + (size_t)(q * 64 + lane_l) * STEPS;
-          // i-outer / m-group-inner: one W2 fragment (per M tile) is live at a time and serves the three m components; the next
-          // in-channel's fragment is requested before the current one is consumed
-          f32x4 wf[MT], wn[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) wf[mt] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)mt * w2n_tile_floats<KIND>(P));
-#pragma unroll
-          for (int i = 0; i < NU; ++i) {
-            if (i + 1 < NU) {
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) wn[mt] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)mt * w2n_tile_floats<KIND>(P) + 4 * (i + 1));
-            }
-#pragma unroll
-            for (int grp = 0; grp < NG; ++grp) {
-              const int col = (VEC ? 5 * grp : 0) + i;
-              const f32x4 tv = *reinterpret_cast<const f32x4*>(sT + (size_t)col * (NB * 16) + ((lane_slot ^ (col & 7)) << 2));
-#pragma unroll
-              for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[AB + grp * MT + mt] = mfma16(wf[mt][rr], tv[rr], acc[AB + grp * MT + mt]);
-            }
+              for (int mt = 0; mt < MT; ++mt) acc[AB + grp * MT + mt] = mfma16(wf[mt][rr], tv[rr], acc[AB + grp * MT + mt]);
             __builtin_amdgcn_sched_barrier(0);
+            tv = tn;
+            if (grp == NG - 1) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) wf[mt] = wn[mt];
+              for (int mt = 0; mt < MT; ++mt) wf[mt] = wn[mt];
+            }
           }
         }
+        NPROF(3);
       }
-      PathStage<KIND, MODE, P + 1>::run(a, r, et, q, lane, hid, sT, sS, acc);
+      PathStage<KIND, MODE, P + 1>::run(a, r, et, q, lane, hid, sT, sS, acc, xr, prof_prev);
     }
   }
 };
@@ -338,72 +438,137 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
   for (int i = 0; i < n_acc4<KIND>(); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int n_et = (r.En + 31) >> 5;
+  NProfT prof_prev{};
+  (void)prof_prev;
+  NPROF(-1);
 #pragma unroll 1
   for (int et = 0; et < n_et; ++et) {
     __syncthreads();                               // readers of the previous pass's factors are done
     for (int idx = tid; idx < NB * 32; idx += 256) {
       const int nn = idx >> 5, el = idx & 31, e = 32 * et + el;
-      const bool ok = nn < r.n_loc && e < r.En;
+      bool ok = nn < r.n_loc && e < r.En;
+      int frow = 0;
+      if (ok) {
+        if constexpr (MODE == LL) {
+          const int sa = pair_slot<0>(a, r, r.n_lo + nn, e), sb = pair_slot<1>(a, r, r.n_lo + nn, e);
+          frow = sa >= 0 ? sa : sb;
+          ok = frow >= 0;
+        } else {
+          frow = feat_row<MODE>(r, r.n_lo + nn, e);
+        }
+      }
       float v[SCOMP];
 #pragma unroll
       for (int i = 0; i < SCOMP; ++i) v[i] = 0.f;
       if (ok) {
-        const float* ps = a.edge_sh + (size_t)feat_row<MODE>(r, r.n_lo + nn, e) * a.sh_stride;
+        const float* ps = a.edge_sh + (size_t)frow * a.sh_stride;
         const float cc = 0.57735026918962576451f * ps[6];
         v[0] = ps[1]; v[1] = ps[2]; v[2] = ps[3];
         v[3] = -cc - ps[8]; v[4] = ps[5]; v[5] = ps[4]; v[6] = 2.f * cc; v[7] = ps[7]; v[8] = -cc + ps[8];
       }
 #pragma unroll
-      for (int i = 0; i < SCOMP; ++i) s_S[(nn * SCOMP + i) * 32 + el] = v[i];
+      for (int i = 0; i < SCOMP; ++i) s_S[((nn * 2 + (el >> 4)) * SCOMP + i) * 16 + (el & 15)] = v[i];
     }
     __syncthreads();
+    NPROF(0);
 
     // ---- GEMM1: hidden rows 16q..16q+15 of the 32 edges of every node of the batch ---------------------------------------------
     float hid[NB][8];
     float w1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) w1[s] = a.w1n[(q * 16 + s) * 64 + lane];
-#pragma unroll
-    for (int nn = 0; nn < NB; ++nn) {
-      const int node = r.n_lo + (nn < r.n_loc ? nn : 0);
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        int e = 32 * et + 16 * t2 + c;               // GEMM1 view: lane (g, c) feeds attr[edge c][group g]
-        e = e < r.En ? e : 0;
-        const float* pe = a.edge_emb + (size_t)feat_row<MODE>(r, node, e) * 20 + 5 * g;
-        const int r1 = MODE == DP_EDGES_P2L ? node : r.l0 + e, r2 = MODE == DP_EDGES_P2L ? r.p0 + e : node;
-        const float* p1 = a.attr1_tab + (size_t)r1 * a.attr1_stride + 5 * g;
-        const float* p2 = a.attr2_tab + (size_t)r2 * a.attr2_stride + 5 * g;
-        float av[15];
-        {
-          const f4u v0 = *reinterpret_cast<const f4u*>(pe), v1 = *reinterpret_cast<const f4u*>(p1), v2 = *reinterpret_cast<const f4u*>(p2);
-          av[0] = v0.x; av[1] = v0.y; av[2] = v0.z; av[3] = v0.w; av[4] = pe[4];
-          av[5] = v1.x; av[6] = v1.y; av[7] = v1.z; av[8] = v1.w; av[9] = p1[4];
-          av[10] = v2.x; av[11] = v2.y; av[12] = v2.z; av[13] = v2.w; av[14] = p2[4];
-        }
-        f32x4 D = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 15; ++s) D = mfma16(av[s], w1[s], D);
-        D = mfma16(g == 0 ? 1.f : 0.f, w1[15], D);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] = fmaxf(D[rr], 0.f);
+    // attr operands of one (node, 16-edge tile): five consecutive floats of [edge_emb | attr1[:20] | attr2[:20]] per lane group;
+    // the loads of step i + 1 are issued before the MFMAs of step i (steps = 16 nodes x 2 tiles)
+    // An edge that does not exist (e >= En, or no radius / bond edge for the pair) gets an all-zero A operand INCLUDING the bias step's
+    // 1.0: its pre-activation is 0, so its hidden vector - constant-one unit included - is exactly 0 and it drops out of T.
+    auto load_av = [&](int step, f4u (&v4)[3], float (&v1)[3], float& one, int which) {
+      int nn_o = step >> 1;                          // opaque copy: keeps the 16 nodes' row pointers from being hoisted out of the pass loop (spills)
+      asm volatile("" : "+s"(nn_o));
+      const int node = r.n_lo + (nn_o < r.n_loc ? nn_o : 0);
+      const int e0 = 32 * et + 16 * (step & 1) + c;  // GEMM1 view: lane (g, c) feeds attr[edge c][group g]
+      bool ok = e0 < r.En;
+      const int e = ok ? e0 : 0;
+      int frow;
+      if constexpr (MODE == LL) {
+        frow = which == 0 ? pair_slot<0>(a, r, node, e) : pair_slot<1>(a, r, node, e);
+        ok = ok && frow >= 0;
+        frow = frow >= 0 ? frow : 0;
+      } else {
+        frow = feat_row<MODE>(r, node, e);
       }
+      const float* pe = a.edge_emb + (size_t)frow * 20 + 5 * g;
+      const int r1 = MODE == DP_EDGES_L2P ? r.l0 + e : node, r2 = MODE == DP_EDGES_P2L ? r.p0 + e : (MODE == LL ? r.l0 + e : node);
+      const float* p1 = a.attr1_tab + (size_t)r1 * a.attr1_stride + 5 * g;
+      const float* p2 = a.attr2_tab + (size_t)r2 * a.attr2_stride + 5 * g;
+      const f4u z4 = {0.f, 0.f, 0.f, 0.f};
+      v4[0] = *reinterpret_cast<const f4u*>(pe); v1[0] = pe[4];
+      v4[1] = *reinterpret_cast<const f4u*>(p1); v1[1] = p1[4];
+      v4[2] = *reinterpret_cast<const f4u*>(p2); v1[2] = p2[4];
+      if (!ok) {
+#pragma unroll
+        for (int b3 = 0; b3 < 3; ++b3) { v4[b3] = z4; v1[b3] = 0.f; }
+      }
+      one = (ok && g == 0) ? 1.f : 0.f;
+    };
+    auto gemm1 = [&](const f4u (&v4)[3], const float (&v1)[3], float one) {
+      f32x4 D = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b3 = 0; b3 < 3; ++b3) {
+        D = mfma16(v4[b3].x, w1[5 * b3 + 0], D);
+        D = mfma16(v4[b3].y, w1[5 * b3 + 1], D);
+        D = mfma16(v4[b3].z, w1[5 * b3 + 2], D);
+        D = mfma16(v4[b3].w, w1[5 * b3 + 3], D);
+        D = mfma16(v1[b3], w1[5 * b3 + 4], D);
+      }
+      return mfma16(one, w1[15], D);
+    };
+    f4u a4[3], b4[3], n4[3];
+    float a1[3], b1[3], n1[3], ao, bo, no;
+    load_av(0, a4, a1, ao, 0);
+    load_av(1, b4, b1, bo, 0);
+    float xr0[3][8];
+#pragma unroll
+    for (int step = 0; step < 2 * NB; ++step) {
+      const int nn = step >> 1, t2 = step & 1;
+      if (step + 2 < 2 * NB) load_av(step + 2, n4, n1, no, 0);   // two steps (32 MFMAs) ahead
+      if (step == 2 * NB - 3) load_x<KIND, MODE, 0>(a, r, et, lane, 0, xr0);   // first column tile's operands: behind the last attr request
+      const f32x4 D = gemm1(a4, a1, ao);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] = fmaxf(D[rr], 0.f);
       __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b3 = 0; b3 < 3; ++b3) { a4[b3] = b4[b3]; a1[b3] = b1[b3]; b4[b3] = n4[b3]; b1[b3] = n1[b3]; }
+      ao = bo; bo = no;
     }
-    PathStage<KIND, MODE, 0>::run(a, r, et, q, lane, hid, sT, s_S, acc);
+    if constexpr (MODE == LL) {
+      // second GEMM1 over the bond edges of the same pairs (1-4 per atom): skipped per 16-pair tile when none of them is bonded
+#pragma unroll
+      for (int step = 0; step < 2 * NB; ++step) {
+        const int nn = step >> 1, t2 = step & 1;
+        load_av(step, a4, a1, ao, 1);
+        if (__builtin_amdgcn_ballot_w64(ao != 0.f) != 0) {       // lane group 0 carries the validity of the tile's 16 pairs
+          const f32x4 D = gemm1(a4, a1, ao);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] += fmaxf(D[rr], 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    NPROF(1);
+    PathStage<KIND, MODE, 0>::run(a, r, et, q, lane, hid, sT, s_S, acc, xr0, prof_prev);
   }
 
   // ---- sum the four k-partials, mean, BatchNorm affine, residual stream ------------------------------------------------------------
   __syncthreads();
   AccStore<KIND, 0>::run(acc, s_T + q * (NB * S::D_OUT), lane);
   __syncthreads();
-  const float inv = 1.f / (float)max(r.En, 1);
   for (int i = tid; i < r.n_loc * S::D_OUT; i += 256) {
     const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
-    float v = ((s_T[i] + s_T[NB * S::D_OUT + i]) + s_T[2 * NB * S::D_OUT + i]) + s_T[3 * NB * S::D_OUT + i];
-    v = v * inv;
-    v = v * a.bn_scale[ch] + a.bn_shift[ch];
     const int node = r.n_lo + n;
+    const int deg = MODE == LL ? a.rowend[node] - a.rowptr[node] : r.En;       // scatter MEAN over the node's edges (torch_scatter: / max(count, 1))
+    float v = ((s_T[i] + s_T[NB * S::D_OUT + i]) + s_T[2 * NB * S::D_OUT + i]) + s_T[3 * NB * S::D_OUT + i];
+    v = v / (float)max(deg, 1);
+    v = v * a.bn_scale[ch] + a.bn_shift[ch];
     float* o = a.out + (size_t)node * a.out_stride + ch;
     if (a.accumulate) {
       *o += v;
@@ -412,12 +577,18 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
       *o = v;
     }
   }
+  NPROF(4);
+#ifdef DP_PROF
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&dpn_prof[i], prof_prev.acc[i]);
+#endif
 }
 
 template <int KIND> int launch(const DpConvArgs& a, hipStream_t st) {
   dim3 grid((unsigned)(a.B * a.slices));
   if (a.mode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_kernel<KIND, DP_EDGES_P2L>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((tp_conv_node_kernel<KIND, DP_EDGES_L2P>), grid, dim3(256), 0, st, a);
+  else if (a.mode == DP_EDGES_L2P) hipLaunchKernelGGL((tp_conv_node_kernel<KIND, DP_EDGES_L2P>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((tp_conv_node_kernel<KIND, DP_EDGES_LLPAIR>), grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 
@@ -448,10 +619,11 @@ int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0
 
 // node-side launch of one layer conv (kinds 0-3, dense cross edge sets only); called by dp_tp_conv when DpConvArgs.algo asks for it
 int dp_tp_conv_node(const DpConvArgs* a, void* stream) {
-  if (!a || a->B <= 0 || a->slices <= 0 || !a->scat_ptr || !a->lig_ptr || !a->ph_ptr || !a->x_ptr || !a->gather_tab || !a->attr1_tab ||
+  if (!a || a->B <= 0 || a->slices <= 0 || !a->scat_ptr || !a->lig_ptr || !a->gather_tab || !a->attr1_tab ||
       !a->attr2_tab || !a->edge_emb || !a->edge_sh || !a->w1n || !a->w2n || !a->bn_scale || !a->bn_shift || !a->out)
     return DP_E_BADARG;
-  if (a->mode != DP_EDGES_P2L && a->mode != DP_EDGES_L2P) return DP_E_UNSUPPORTED;
+  if (a->mode != DP_EDGES_P2L && a->mode != DP_EDGES_L2P && a->mode != DP_EDGES_LLPAIR) return DP_E_UNSUPPORTED;
+  if (a->mode == DP_EDGES_LLPAIR ? (!a->pair_a || !a->pair_b || !a->pair_ptr || !a->rowptr || !a->rowend) : (!a->ph_ptr || !a->x_ptr)) return DP_E_BADARG;
   if (a->kind < 0 || a->kind > 3 || a->sh_stride < 9) return DP_E_UNSUPPORTED;
   if (a->max_scatter <= 0) return DP_E_BADARG;
   if ((a->max_scatter + a->slices - 1) / a->slices > dpn::NB) return DP_E_TOOLARGE;

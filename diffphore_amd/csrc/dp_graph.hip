@@ -10,6 +10,10 @@
 
 #include "dp_dev.h"
 
+#ifndef DP_NODE_LL_MAX_ATOMS
+#define DP_NODE_LL_MAX_ATOMS 64      // above this the pair-dense lig-lig passes cost more than the edge-side kernel
+#endif
+
 namespace dp {
 
 constexpr int LIG_DIMS[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};   // process_mols.py:162-179
@@ -144,6 +148,10 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
   const int words = (N + 31) / 32;
   for (int i = tid; i < N * 3; i += 256) s_pos[i] = b.pos[(size_t)l0 * 3 + i];
   for (int i = tid; i < N * words; i += 256) s_adj[i] = 0u;
+  const int pr0 = b.llp_ptr ? b.llp_ptr[p] : 0;
+  const bool pairs = b.llp_ptr != nullptr && k.ll_pair_rad != nullptr && k.ll_pair_bond != nullptr;
+  if (pairs)
+    for (int i = tid; i < N * N; i += 256) { k.ll_pair_rad[pr0 + i] = -1; k.ll_pair_bond[pr0 + i] = -1; }
   if (tid < NS) {   // layer-0 bias + sigma-embedding part of the edge MLP (same for every edge of the pose)
     const float* se = k.tparams + (size_t)p * TP_STRIDE;
     float a = w.lig_edge.b0[tid];
@@ -203,6 +211,7 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
     const int packed = k.ll_src[o];
     const int bt = (packed >> 28) & 7, src = packed & 0x0fffffff, dst = k.ll_nbr[o];
     k.ll_src[o] = src;
+    if (pairs) (bt < 4 ? k.ll_pair_bond : k.ll_pair_rad)[pr0 + (src - l0) * N + (dst - l0)] = o;    // pair tables of the node-side lig-lig conv
     const float vx = s_pos[(dst - l0) * 3] - s_pos[(src - l0) * 3];
     const float vy = s_pos[(dst - l0) * 3 + 1] - s_pos[(src - l0) * 3 + 1];
     const float vz = s_pos[(dst - l0) * 3 + 2] - s_pos[(src - l0) * 3 + 2];
@@ -216,6 +225,15 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
     matvec_acc<NS, NS>(w.lig_edge.w0, 44, 24, g, h);
     mlp_tail20(w.lig_edge, h, out);
     store_row<NS>(k.ll_emb + (size_t)o * NS, out);
+  }
+  if (pairs) {
+    // every edge must own its table entry: a ligand graph that lists the same ordered bond twice would lose one here -> flag the pose
+    __syncthreads();
+    for (int a = tid; a < N; a += 256) {
+      int cnt = 0;
+      for (int y = 0; y < N; ++y) cnt += (k.ll_pair_rad[pr0 + a * N + y] >= 0 ? 1 : 0) + (k.ll_pair_bond[pr0 + a * N + y] >= 0 ? 1 : 0);
+      if (cnt != s_deg[a]) atomicOr(&k.status[p], 2);
+    }
   }
 }
 
@@ -589,6 +607,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   const bool node_side = dp_resolve_conv_algo(k->conv_algo, w->precision, B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
   const int nb = dp_conv_node_max_nodes();
   const int slices_pl = (b->max_nl + nb - 1) / nb, slices_lp = (b->max_np + nb - 1) / nb;
+  // lig-lig conv on the node-side kernel too (pair-dense form): pays while a pose's atoms fit a few 32-slot passes
+  const bool node_ll = node_side && w->lig_conv[0].w2n != nullptr && b->llp_ptr != nullptr && k->ll_pair_rad != nullptr &&
+                       b->max_nl <= DP_NODE_LL_MAX_ATOMS;
   // optional second stream: phore-side convs of a layer (and the torsion head) run beside the ligand-side ones
   hipStream_t aux = (k->aux_stream && k->ev_fork && k->ev_join) ? (hipStream_t)k->aux_stream : nullptr;
   auto fork = [&]() {
@@ -628,6 +649,10 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_scat = k->ll_src; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hl; c.edge_emb = k->ll_emb; c.edge_sh = k->ll_sh;
       c.w1p = w->lig_conv[l].w1p; c.w2p = w->lig_conv[l].w2p; c.bn_scale = w->lig_conv[l].bn_scale; c.bn_shift = w->lig_conv[l].bn_shift;
       c.out = hl2; c.accumulate = 0; c.resid = hl; c.resid_width = din;
+      if (node_ll) {
+        c.algo = DP_ALGO_NODE; c.mode = DP_EDGES_LLPAIR; c.w1n = w->lig_conv[l].w1n; c.w2n = w->lig_conv[l].w2n; c.slices = slices_pl; c.phase_split = 0;
+        c.pair_a = k->ll_pair_rad; c.pair_b = k->ll_pair_bond; c.pair_ptr = b->llp_ptr;
+      }
       if ((rc = timed(c, l, 0, st))) return rc;
     }
     for (int nv = 0; nv < 2; ++nv) {

@@ -47,6 +47,8 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   w.ll_src = c.take<int32_t>(cap);
   w.ll_emb = c.take<float>(cap * 20);
   w.ll_sh = c.take<float>(cap * 9);
+  w.ll_pair_rad = c.take<int32_t>((size_t)b->n_llp);
+  w.ll_pair_bond = c.take<int32_t>((size_t)b->n_llp);
   w.pp_emb = c.take<float>(npp * 20);
   w.x_emb = c.take<float>(nx * 20);
   w.x_sh = c.take<float>(nx * 9);
@@ -124,7 +126,7 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
       snprintf(nm, sizeof(nm), "%s.%d.w2p", FAMS[f], l); s.add(nm, dp_conv_w2p_floats(l, precision));
       snprintf(nm, sizeof(nm), "%s.%d.bn_scale", FAMS[f], l); s.add(nm, D_OUT_KIND[l]);
       snprintf(nm, sizeof(nm), "%s.%d.bn_shift", FAMS[f], l); s.add(nm, D_OUT_KIND[l]);
-      if (f >= 2 && precision == DP_PREC_F32) {       // dense cross families: node-side layout as well
+      if (f != 1 && precision == DP_PREC_F32) {       // every family but phore-phore (low degree: edge-side stays better): node-side layout as well
         snprintf(nm, sizeof(nm), "%s.%d.w1n", FAMS[f], l); s.add(nm, dp_conv_w1n_floats(l));
         snprintf(nm, sizeof(nm), "%s.%d.w2n", FAMS[f], l); s.add(nm, dp_conv_w2n_floats(l));
       }

@@ -26,10 +26,10 @@ DEFAULT_PRECISION = "f32"
 # ctypes mirrors of include/diffphore_amd.h
 # ----------------------------------------------------------------------------------------------------------------------
 class DpBatch(C.Structure):
-    _fields_ = ([("B", c_i32)] + [(n, c_i32) for n in ("n_lig", "n_ph", "n_bond", "n_tor", "n_pp", "n_x", "ll_cap")]
+    _fields_ = ([("B", c_i32)] + [(n, c_i32) for n in ("n_lig", "n_ph", "n_bond", "n_tor", "n_pp", "n_x", "ll_cap", "n_llp")]
                 + [(n, c_i32) for n in ("max_nl", "max_np", "max_t")]
                 + [(n, VOIDP) for n in ("lig_ptr", "ph_ptr", "bond_ptr", "tor_ptr", "pp_ptr", "x_ptr", "ll_ptr", "mask_ptr",
-                                        "pose_ptr", "lig_x", "bond_src", "bond_dst", "bond_type", "tor_u", "tor_v",
+                                        "pose_ptr", "llp_ptr", "lig_x", "bond_src", "bond_dst", "bond_type", "tor_u", "tor_v",
                                         "mask_rotate", "phorefp", "norm_angle1", "norm_angle2", "ph_pos", "ph_norm", "ph_x",
                                         "ph_scalar", "ph_type", "pp_src", "pp_dst", "pp_rowptr", "pp_rowend", "pos", "norm",
                                         "t")])
@@ -59,7 +59,7 @@ class DpWeights(C.Structure):
 
 class DpWork(C.Structure):
     _fields_ = ([(n, VOIDP) for n in ("lig_x_emb", "ph_x_emb", "pair_pre", "pair_fm", "pp_pre", "pp_sh", "tparams",
-                                      "ll_rowptr", "ll_rowend", "ll_nbr", "ll_src", "ll_emb", "ll_sh", "pp_emb", "x_emb", "x_sh",
+                                      "ll_rowptr", "ll_rowend", "ll_nbr", "ll_src", "ll_emb", "ll_sh", "ll_pair_rad", "ll_pair_bond", "pp_emb", "x_emb", "x_sh",
                                       "x_nsh", "x_ew")]
                 + [("h_l", VOIDP * 2), ("h_p", VOIDP * 2)]
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
@@ -174,7 +174,7 @@ class DeviceModel:
                     p2l_norm_conv="phore_to_lig_norm_conv_layers")
         for name, fam in fams.items():
             for l in range(4):
-                node = name in ("l2p_conv", "p2l_conv", "l2p_norm_conv", "p2l_norm_conv") and prec == _lib.PREC_F32
+                node = name != "ph_conv" and prec == _lib.PREC_F32
                 for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node).items():
                     H[f"{name}.{l}.{part}"] = t
         for part, t in packing.pack_conv(sd, "final_conv", _lib.CONV_FINAL, prec).items():
@@ -275,6 +275,7 @@ class PackedBatch:
         self.tor_ptr, self.pp_ptr, self.x_ptr = cs(nt), cs(npp), cs(nl * npn)
         self.ll_ptr = cs(nb + nl * np.minimum(np.maximum(nl - 1, 0), 33))
         self.mask_ptr = cs(nt * nl)
+        self.llp_ptr = cs(nl * nl)
         self.B, self.nl, self.np_, self.nt = B, nl, npn, nt
         if max(self.x_ptr[-1], self.ll_ptr[-1]) * 20 >= 2 ** 31:
             raise ValueError("batch too large for int32 indexing; split it")
@@ -295,7 +296,7 @@ class PackedBatch:
         H: Dict[str, np.ndarray] = {}
         for n, a in (("lig_ptr", self.lig_ptr), ("ph_ptr", self.ph_ptr), ("bond_ptr", self.bond_ptr), ("tor_ptr", self.tor_ptr),
                      ("pp_ptr", self.pp_ptr), ("x_ptr", self.x_ptr), ("ll_ptr", self.ll_ptr), ("mask_ptr", self.mask_ptr),
-                     ("pose_ptr", np.arange(B + 1))):
+                     ("pose_ptr", np.arange(B + 1)), ("llp_ptr", self.llp_ptr)):
             H[n] = np.ascontiguousarray(a, dtype=np.int32)
         H["lig_x"] = cat([l.x for l in L], np.int32)
         ei_all = cat([g["ligand", "ligand"].edge_index for g in graphs], np.int64, axis=1) + np.repeat(self.lig_ptr[:-1], nb)[None, :]
@@ -358,6 +359,7 @@ class PackedBatch:
         s.B = B
         s.n_lig, s.n_ph, s.n_bond, s.n_tor = int(self.lig_ptr[-1]), n_ph, int(self.bond_ptr[-1]), int(self.tor_ptr[-1])
         s.n_pp, s.n_x, s.ll_cap = int(self.pp_ptr[-1]), int(self.x_ptr[-1]), int(self.ll_ptr[-1])
+        s.n_llp = int(self.llp_ptr[-1])
         s.max_nl, s.max_np, s.max_t = int(nl.max()), int(npn.max()), int(nt.max())
         for k, v in self.static.items():
             setattr(s, k, v.data_ptr())
@@ -381,7 +383,7 @@ class Workspace:
     _SHAPES = dict(lig_x_emb=("f", "n_lig", 20), ph_x_emb=("f", "n_ph", 20), pair_pre=("f", "n_lig", 220), pair_fm=("f", "n_lig", 11),
                    pp_pre=("f", "n_pp", 20), pp_sh=("f", "n_pp", 9), tparams=("f", "B", 32), ll_rowptr=("i", "n_lig", 1),
                    ll_rowend=("i", "n_lig", 1), ll_nbr=("i", "ll_cap", 1), ll_src=("i", "ll_cap", 1), ll_emb=("f", "ll_cap", 20),
-                   ll_sh=("f", "ll_cap", 9), pp_emb=("f", "n_pp", 20), x_emb=("f", "n_x", 20), x_sh=("f", "n_x", 9), x_nsh=("f", "n_x", 9),
+                   ll_sh=("f", "ll_cap", 9), ll_pair_rad=("i", "n_llp", 1), ll_pair_bond=("i", "n_llp", 1), pp_emb=("f", "n_pp", 20), x_emb=("f", "n_x", 20), x_sh=("f", "n_x", 9), x_nsh=("f", "n_x", 9),
                    x_ew=("f", "n_x", 1), c_emb=("f", "n_lig", 20), c_sh=("f", "n_lig", 9), gpred=("f", "B", 12), t_rowptr=("i", "nT", 1),
                    t_rowend=("i", "nT", 1), t_nbr=("i", "nT", 32), t_src=("i", "nT", 32), t_emb=("f", "nT", 640), t_sh=("f", "nT", 224),
                    t_hb=("f", "nT", 20), t_q=("f", "nT", 40), status=("i", "B", 1))
@@ -402,7 +404,8 @@ class Workspace:
         lead = base - self.block.data_ptr()
         f32 = self.block[lead:lead + nbytes].view(torch.float32)
         i32 = self.block[lead:lead + nbytes].view(torch.int32)
-        dims = dict(n_lig=s.n_lig, n_ph=s.n_ph, n_pp=max(s.n_pp, 1), n_x=s.n_x, ll_cap=max(s.ll_cap, 1), B=s.B, nT=max(s.n_tor, 1))
+        dims = dict(n_lig=s.n_lig, n_ph=s.n_ph, n_pp=max(s.n_pp, 1), n_x=s.n_x, ll_cap=max(s.ll_cap, 1), B=s.B, nT=max(s.n_tor, 1),
+                    n_llp=max(s.n_llp, 1))
 
         def view(ptr, kind, rows, cols):
             off = (int(ptr) - base) // 4

@@ -117,12 +117,21 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
                 vis.add((pos[lo:hi] + part[idx].original_center).detach().cpu(), part=1, order=t_idx + 2)
 
 
+def _check_status(eng):
+    """Per-pose status words of the device loop -> the exceptions the reference's callers expect."""
+    status = eng.ws.t["status"].cpu()
+    if bool((status & 2).any()):
+        raise ValueError("ligand graph lists the same ordered atom pair twice among its bond (or radius) edges for poses "
+                         f"{torch.nonzero(status & 2).flatten().tolist()}: not representable by the node-side ligand-ligand conv "
+                         "(set DIFFPHORE_CONV_ALGO=edge)")
+    if bool((status & 1).any()):
+        # the reference raises from torch.linalg.svd and the caller string-matches this text (inference.py:211)
+        raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status & 1).flatten().tolist()}")
+
+
 def _finish_run(eng, part):
     pb = eng.pb
-    status = eng.ws.t["status"].cpu()
-    if bool((status != 0).any()):
-        # the reference raises from torch.linalg.svd and the caller string-matches this text (inference.py:211)
-        raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status).flatten().tolist()}")
+    _check_status(eng)
     pos, norm = pb.pos.cpu(), pb.norm.cpu()
     for i, g in enumerate(part):
         lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
@@ -332,9 +341,7 @@ def sample_step(complex_graph_batch, model, model_args, tr_sigma, rot_sigma, tor
         z_tr, z_rot = z_tr.to(pb.device, torch.float32).contiguous(), z_rot.to(pb.device, torch.float32).contiguous()
         z_tor = z_tor.to(pb.device, torch.float32).contiguous() if (z_tor is not None and not no_torsion and nT) else None
     eng.sample_step(sp, z_tr, z_rot, z_tor)
-    status = eng.ws.t["status"].cpu()
-    if bool((status != 0).any()):
-        raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status).flatten().tolist()}")
+    _check_status(eng)
     tr_p, rot_p, tor_p = _perturbations(eng, sp, z_tr, z_rot, z_tor, no_torsion)
     data_list = complex_graph_batch.to_data_list()
     pos, norm = pb.pos.cpu(), pb.norm.cpu()
@@ -454,9 +461,7 @@ def sampling_phore_with_fitscore(data_list, model, inference_steps, tr_schedule,
             for idx_, vis in enumerate(visualization_list):
                 lo, hi = int(pb.lig_ptr[idx_]), int(pb.lig_ptr[idx_ + 1])
                 vis.add((pos[lo:hi] + data_list[idx_].original_center).detach().cpu(), part=1, order=t_idx + 2)
-    status = eng.ws.t["status"].cpu()
-    if bool((status != 0).any()):
-        raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status).flatten().tolist()}")
+    _check_status(eng)
     pos, norm = pb.pos.cpu(), pb.norm.cpu()
     for i, g in enumerate(data_list):
         lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])

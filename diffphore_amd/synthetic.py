@@ -239,6 +239,41 @@ def synthetic_pairs(cfg_id: int, n_pairs: int, n_atoms, n_tor, n_phore, seed: Op
     return out
 
 
+def example_complex(sdf_path: str, phore_path: str, seed: int = BASE_SEED + 1, name: str = "sQC_Substrate__STK936575") -> HeteroData:
+    """BASELINE configs[0] on the reference's REAL example inputs: geometry, bond list and bond orders of the ligand from its SDF
+    (`diffphore_amd.sdf_io`, explicit hydrogens removed as `read_mol(..., remove_hs=True)` does, process_mols.py:823), the pharmacophore
+    graph from its `.phore` file (`diffphore_amd.phore_io`, pinned against the reference's own parser), rotatable-bond masks from the
+    real bond graph (`transformation_mask`, torsion.py:13-61).  What RDKit would compute - the 16 categorical atom features beyond the
+    element, pharmacophore fingerprints, normals - is out of scope and drawn like the synthetic ligands (seeded)."""
+    from . import phore_io, sdf_io
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mol = sdf_io.remove_hs(sdf_io.read_mol(sdf_path))
+    n = mol.num_atoms
+    pt = {"H": 1, "B": 5, "C": 6, "N": 7, "O": 8, "F": 9, "Si": 14, "P": 15, "S": 16, "Cl": 17, "Br": 35, "I": 53}
+    x = np.stack([rng.integers(0, d, size=n) for d in LIG_FEATURE_DIMS], axis=1).astype(np.int64)
+    x[:, 0] = [pt.get(sy, 6) - 1 for sy in mol.symbols]          # allowable atomic_num list is 1..118 (process_mols.py:33): index = Z - 1
+    edges, btype = [], []
+    for b in mol.bonds:
+        a1, a2, order = int(b[0]) - 1, int(b[1]) - 1, int(b[2])
+        edges += [(a1, a2), (a2, a1)]
+        btype += [{1: 0, 2: 1, 3: 2, 4: 3}.get(order, 0)] * 2   # single / double / triple / aromatic (process_mols.py:255-284)
+    edge_index = np.asarray(edges, dtype=np.int64).T
+    edge_attr = np.zeros((len(edges), 4), dtype=np.float32)
+    edge_attr[np.arange(len(edges)), btype] = 1.0
+    mask_edges, mask_rotate = transformation_mask(n, edge_index)
+    phorefp = (rng.random((n, NUM_PHORETYPE)) < 0.15).astype(np.float32)
+    phorefp[:, EX_TYPE] = 0.0
+    nv = rng.normal(size=(n, NUM_PHORETYPE, 3))
+    nv /= np.linalg.norm(nv, axis=-1, keepdims=True)
+    ang = np.asarray([0.0, np.pi / 3, np.pi], dtype=np.float32)
+    lig = dict(x=x, pos=np.asarray(mol.coords, dtype=np.float32), edge_index=edge_index, edge_attr=edge_attr, edge_mask=mask_edges,
+               mask_rotate=mask_rotate, phorefp=phorefp, norm=(nv * phorefp[..., None]).astype(np.float32).reshape(n, 33),
+               norm_angle1=(ang[rng.integers(0, 3, size=(n, NUM_PHORETYPE))] * phorefp).astype(np.float32),
+               norm_angle2=(ang[rng.integers(0, 3, size=(n, NUM_PHORETYPE))] * phorefp).astype(np.float32))
+    (ph,) = phore_io.parse_phore(phore_path)
+    return make_complex(lig, phore_io.phore_graph(ph), name=name)
+
+
 # BASELINE.json configs -> shapes (SURVEY.md §8d)
 CONFIGS = {
     1: dict(n_atoms=20, n_tor=5, n_phore=79, samples=40, steps=20),     # shape of STK936575 x sQC phore example

@@ -48,7 +48,9 @@ enum DpEdgeMode {
   DP_EDGES_CSR = 0,     /* explicit CSR: rowptr/rowend per scatter node, nbr[] = gather node (lig-lig, phore-phore, torsion) */
   DP_EDGES_P2L = 1,     /* dense cross, scatter = ligand atom i, gather = phore node j      (:682-689) */
   DP_EDGES_L2P = 2,     /* dense cross, scatter = phore node j, gather = ligand atom i      (:695-700) */
-  DP_EDGES_CENTER = 3   /* scatter = pose, one edge per ligand atom                         (:381-406) */
+  DP_EDGES_CENTER = 3,  /* scatter = pose, one edge per ligand atom                         (:381-406) */
+  DP_EDGES_LLPAIR = 4   /* node-side kernel only: ligand-ligand edges as a dense atom x atom pair table of one pose; pair (i, j) carries
+                           up to two edges (radius + bond, build_lig_conv_graph :715-739) found through pair_a / pair_b */
 };
 
 /* arithmetic of the radial-MLP second layer (the 60 x numel contraction that dominates the path) */
@@ -116,6 +118,9 @@ typedef struct DpConvArgs {
   const float* w1n;
   const float* w2n;
   int32_t algo;              /* DpConvAlgo; AUTO / EDGE -> the edge-side kernel */
+  /* DP_EDGES_LLPAIR: per pose a [N_l x N_l] table at pair_ptr[pose]; entry (i, j) = edge slot (row of edge_emb / edge_sh, CSR order)
+   * of the radius edge scatter i <- gather j (pair_a) / of the bond edge (pair_b), -1 if absent.  rowptr / rowend give the degree. */
+  const int32_t *pair_a, *pair_b, *pair_ptr;
 } DpConvArgs;
 
 /* Fused gather -> radial MLP (MFMA) -> Clebsch-Gordan tensor product -> per-node segmented mean -> e3nn BatchNorm(eval).
@@ -149,11 +154,12 @@ int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, co
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct DpBatch {
   int32_t B;
-  int32_t n_lig, n_ph, n_bond, n_tor, n_pp, n_x, ll_cap;  /* totals over the batch */
+  int32_t n_lig, n_ph, n_bond, n_tor, n_pp, n_x, ll_cap, n_llp;  /* totals over the batch (n_llp = sum N_l^2) */
   int32_t max_nl, max_np, max_t;                           /* per-pose maxima (kernel limits: 256 / 256 / 128) */
   /* pose CSRs, B+1 entries */
   const int32_t *lig_ptr, *ph_ptr, *bond_ptr, *tor_ptr, *pp_ptr, *x_ptr, *ll_ptr, *mask_ptr;
   const int32_t* pose_ptr;    /* [B+1] = 0..B (scatter CSR of the centre conv) */
+  const int32_t* llp_ptr;     /* [B+1] offsets of the per-pose N_l x N_l ligand pair tables (DpWork.ll_pair_*) */
   /* ligand, static */
   const int32_t* lig_x;       /* [n_lig,16] categorical atom features                     process_mols.py:162-179 */
   const int32_t *bond_src, *bond_dst, *bond_type; /* [n_bond] directed bonds, global atom ids, type 0..3 (one-hot index) */
@@ -218,6 +224,7 @@ typedef struct DpWork {
   int32_t *ll_rowptr, *ll_rowend;   /* [n_lig] */
   int32_t *ll_nbr, *ll_src;         /* [ll_cap] */
   float *ll_emb, *ll_sh;            /* [ll_cap,20], [ll_cap,9] */
+  int32_t *ll_pair_rad, *ll_pair_bond;  /* [n_llp] pair (scatter i, gather j) -> lig-lig edge slot of the radius / bond edge, -1 = none */
   float* pp_emb;                    /* [n_pp,20] */
   float *x_emb, *x_sh, *x_nsh;      /* [n_x,20], [n_x,9], [n_x,9] */
   float* x_ew;                      /* [n_x] exp(total_weight) */
@@ -226,7 +233,8 @@ typedef struct DpWork {
   float* gpred;                     /* [B,12] */
   int32_t *t_rowptr, *t_rowend, *t_nbr, *t_src;   /* [n_tor], [n_tor], [n_tor*32], [n_tor*32] */
   float *t_emb, *t_sh, *t_hb, *t_q;               /* [n_tor*32,20], [n_tor*32,7], [n_tor,20], [n_tor,40] */
-  int32_t* status;                  /* [B] 0 ok, bit0 Kabsch degenerate / non-finite */
+  int32_t* status;                  /* [B] 0 ok, bit0 Kabsch degenerate / non-finite, bit1 ligand graph with a repeated (bond or radius) edge
+                                       between the same ordered atom pair (not representable in the pair tables of the node-side lig-lig conv) */
   /* optional timing hook: if prof_start/prof_stop are hipEvent_t handles, dp_forward records them on the launch stream
    * immediately before / after the tensor-product conv (prof_layer, prof_conv); prof_conv: 0 lig-lig, 1 phore->lig,
    * 2 phore->lig (normals), 3 phore-phore, 4 lig->phore, 5 lig->phore (normals). */

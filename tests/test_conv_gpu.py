@@ -243,6 +243,78 @@ def test_conv_node_side_dense_cross(kind, mode):
     assert torch.equal(out3.cpu().double(), got)
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_conv_node_side_ligand_pairs(kind):
+    """Node-side lig-lig conv (DP_EDGES_LLPAIR): the ligand multigraph (radius edges + bond edges, bonded pairs carry BOTH) as a dense
+    atom x atom pair table.  Held to the fp64 oracle run on the explicit edge list and to the edge-side CSR kernel on the same edges."""
+    g = torch.Generator().manual_seed(900 + kind)
+    sd = weights.init_state_dict(11)
+    prefix = f"encoder.lig_conv_layers.{kind}"
+    dims = _lib.conv_dims(kind)
+    NL = [9, 30, 1, 45, 17]
+    B = len(NL)
+    lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+    N = int(lig_ptr[-1])
+    h = torch.randn(N, dims["d_in"], generator=g)
+    rowptr, rowend, nbr, scat, pair_rad, pair_bond, is_bond = [], [], [], [], [], [], []
+    pair_ptr = np.concatenate([[0], np.cumsum(np.asarray(NL) ** 2)])
+    e0 = 0
+    for b in range(B):
+        n = NL[b]
+        adj = (torch.rand(n, n, generator=g) < 0.6).numpy()
+        np.fill_diagonal(adj, False)
+        bond = (torch.rand(n, n, generator=g) < 0.08).numpy() & ~np.eye(n, dtype=bool)
+        adj[3 % n] = False                                        # an atom without radius edges
+        if n > 5:
+            adj[5], bond[5] = False, False                        # ... and one without any edge
+        pr, pb_ = -np.ones((n, n), dtype=np.int32), -np.ones((n, n), dtype=np.int32)
+        for a_ in range(n):
+            rowptr.append(e0)
+            for y in np.nonzero(bond[a_])[0]:                      # bond edges first, as lig_graph_kernel lays a row out
+                pb_[a_, y] = e0
+                nbr.append(int(lig_ptr[b]) + int(y)); scat.append(int(lig_ptr[b]) + a_); is_bond.append(True)
+                e0 += 1
+            for y in np.nonzero(adj[a_])[0]:
+                pr[a_, y] = e0
+                nbr.append(int(lig_ptr[b]) + int(y)); scat.append(int(lig_ptr[b]) + a_); is_bond.append(False)
+                e0 += 1
+            rowend.append(e0)
+        pair_rad.append(pr.reshape(-1)); pair_bond.append(pb_.reshape(-1))
+    E = e0
+    nbr_t, scat_t = torch.tensor(nbr), torch.tensor(scat)
+    # geometry is a property of the PAIR: the radius and the bond edge of a pair share sh (and the gathered row), only emb differs
+    pos = torch.randn(N, 3, generator=g)
+    from oracle import e3
+    sh = e3.spherical_harmonics_lmax2((pos[nbr_t] - pos[scat_t]).double()).float()
+    emb = torch.randn(E, 20, generator=g)
+    attr = torch.cat([emb, h[scat_t, :20], h[nbr_t, :20]], 1)
+    ref = _oracle_conv(sd, prefix, kind, h[nbr_t], attr, sh, scat_t, N)
+    pk = packing.pack_conv(sd, prefix, kind, _lib.PREC_F32, node_side=True)
+    nb = _lib.lib().dp_conv_node_max_nodes()
+    resid = torch.randn(N, dims["d_in"], generator=g)
+    out = torch.full((N, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    common = dict(kind=kind, B=B, precision=_lib.PREC_F32, max_scatter=max(NL), scat_ptr=_dev(_i32(lig_ptr)), lig_ptr=_dev(_i32(lig_ptr)),
+                  rowptr=_dev(_i32(rowptr)), rowend=_dev(_i32(rowend)), nbr=_dev(_i32(nbr)), edge_scat=_dev(_i32(scat)),
+                  gather_tab=_dev(h), gather_stride=dims["d_in"], attr1_tab=_dev(h), attr1_stride=dims["d_in"], attr2_tab=_dev(h),
+                  attr2_stride=dims["d_in"], attr_swap=0, edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9, w1p=_dev(pk["w1p"]),
+                  w2p=_dev(pk["w2p"]), w1n=_dev(pk["w1n"]), w2n=_dev(pk["w2n"]), bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]),
+                  out_stride=dims["d_out"], accumulate=0, resid=_dev(resid), resid_stride=dims["d_in"], resid_width=dims["d_in"],
+                  pair_a=_dev(_i32(np.concatenate(pair_rad))), pair_b=_dev(_i32(np.concatenate(pair_bond))), pair_ptr=_dev(_i32(pair_ptr)))
+    _run(dict(common, mode=_lib.EDGES_LLPAIR, algo=_lib.ALGO_NODE, slices=(max(NL) + nb - 1) // nb, out=out), keep)
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item() / scale
+    assert err < TOL["f32"], err
+    out2 = torch.full((N, dims["d_out"]), float("nan")).cuda()
+    _run(dict(common, mode=_lib.EDGES_CSR, algo=_lib.ALGO_EDGE, slices=2, out=out2), keep)
+    err = (out2.cpu().double() - got).abs().max().item() / scale
+    assert err < TOL["f32"], err
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_conv_center_and_torsion_kinds(prec):
     g = torch.Generator().manual_seed(500)

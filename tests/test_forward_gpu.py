@@ -1,12 +1,14 @@
 """GPU parity of the whole hot path (through the C ABI) against the CPU oracle and the reference's golden vectors.
 
-Tolerances (fp32 device path vs fp64 oracle, identical weights / tables / noise):
-    per-forward scores            <= 2e-4 of the tensor's max magnitude (4 layers x 21 fused convs of fp32 accumulation)
-    node features after 4 layers  <= 1e-4 of max
+Tolerances (fp32 device path vs fp64 oracle, identical weights / tables / noise; relative = max |diff| / max |ref| per tensor):
+    per-forward scores, pooled head output, node features after 4 layers   <= 2e-5  (SURVEY.md 8c asks 1e-5 "relative"; measured
+                                  1e-6..8e-6 over precisions / conv formulations on these batches, the bound leaves 2.5x)
+    per-edge embeddings / spherical harmonics                              <= 2e-5 (measured ~1e-6)
     conformer update vs reference golden vectors   <= 3e-6 A  (reference itself is fp32 + fp32 SVD)
-    end-to-end trajectory         median RMSD <= 1e-4 A over poses; discontinuous decisions of the reference algorithm
-                                  (sign of an MLP output, d < 5 A radius cut, <=k thresholds) may flip for individual poses
-                                  between fp32 and fp64, so the bound is on the median and on 90 % of the poses.
+    end-to-end trajectory         EVERY pose <= 1e-4 A RMSD from the fp64 oracle, unless the reference algorithm's own discontinuous
+                                  decisions (sign of an MLP output, d < 5 A radius cut, <= k thresholds) flip in fp32: a pose may
+                                  exceed the bound only if the fp32 CPU oracle - same arithmetic class, no GPU - leaves the fp64
+                                  trajectory for that same pose as well (`_assert_poses_or_fp32_flip`).
 """
 import copy
 import ctypes as C
@@ -45,9 +47,10 @@ def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x9", "bf16x3"])
-def test_forward_matches_oracle(prec):
+@pytest.mark.parametrize("prec,algo", [("f32", "edge"), ("f32", "node"), ("bf16x6", "edge"), ("bf16x9", "edge"), ("bf16x3", "edge")])
+def test_forward_matches_oracle(prec, algo, monkeypatch):
     from diffphore_amd.score_model import TensorProductScoreModel
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
     tol = 1.0 if prec != "bf16x3" else 20.0
     from oracle import sampler as osampler
     gs = _mixed_graphs()
@@ -71,11 +74,14 @@ def test_forward_matches_oracle(prec):
     assert _rel(ws.t["x_emb"], dbg["e_x"]) < 2e-5
     assert _rel(ws.t["x_sh"], dbg["x_sh"]) < 2e-5
     assert _rel(ws.t["x_nsh"], dbg["x_nsh"]) < 2e-5
-    assert _rel(ws.t["pp_emb"], dbg["e_pp"]) < 2e-5 or True
-    assert _rel(ws.t["h_l0"][:, :100], dbg["h_l4"]) < 1e-4 * tol      # after 4 layers the result sits in buffer 0
-    assert _rel(ws.t["gpred"], dbg["global_pred"]) < 2e-4 * tol
+    # phore-phore edges are packed sorted by source node (stable), the oracle keeps the batch's edge order
+    order = torch.argsort(batch["phore", "phore"].edge_index[0], stable=True)
+    assert _rel(ws.t["pp_emb"], dbg["e_pp"][order]) < 2e-5
+    errs = dict(h_l4=_rel(ws.t["h_l0"][:, :100], dbg["h_l4"]), gpred=_rel(ws.t["gpred"], dbg["global_pred"]), tr=_rel(tr, tr_o),
+                rot=_rel(rot, rot_o), tor=_rel(tor, tor_o))                  # after 4 layers the node features sit in buffer 0
+    print(prec, algo, "relative errors vs fp64 oracle:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert tor.shape == tor_o.shape and tr.shape == (len(gs), 3)
-    assert _rel(tr, tr_o) < 2e-4 * tol and _rel(rot, rot_o) < 2e-4 * tol and _rel(tor, tor_o) < 2e-4 * tol
+    assert all(v < 2e-5 * tol for v in errs.values()), errs
     # side effects the reference leaves on the batch
     assert batch.graph_sigma_emb.shape == (len(gs), 20) and batch["phore"].node_sigma_emb.shape[0] == batch["phore"].pos.shape[0]
     assert n_l == batch["ligand"].node_sigma_emb.shape[0]
@@ -178,8 +184,23 @@ def _rmsd(a, b):
     return float(np.sqrt(((a - b) ** 2).sum(-1).mean()))
 
 
-@pytest.mark.parametrize("ode,prec", [(False, "f32"), (True, "f32"), (False, "bf16x6")])
-def test_sampler_trajectory_matches_oracle(ode, prec):
+def _assert_poses_or_fp32_flip(r, run_fp32_oracle, what, bound=1e-4):
+    """Every pose within `bound` of the fp64 oracle - or, for the poses that are not, the fp32 CPU oracle (run lazily, same inputs)
+    must have left the fp64 trajectory too: then the divergence is one of the reference algorithm's discontinuous decisions flipping
+    under fp32 rounding, not a property of the HIP kernels."""
+    bad = np.nonzero(~(r < bound))[0]
+    if bad.size == 0:
+        return
+    r32 = run_fp32_oracle()
+    print(what, "poses beyond the bound:", bad.tolist(), "HIP:", r[bad], "fp32 oracle:", r32[bad])
+    assert np.isfinite(r).all() and bad.size <= max(1, len(r) // 4), (what, r)
+    assert all(r32[i] > bound for i in bad), (what, "HIP diverges where the fp32 CPU oracle does not", r, r32)
+
+
+@pytest.mark.parametrize("ode,prec,algo", [(False, "f32", "edge"), (True, "f32", "edge"), (False, "f32", "node"), (True, "f32", "node"),
+                                           (False, "bf16x6", "edge"), (False, "bf16x9", "edge")])
+def test_sampler_trajectory_matches_oracle(ode, prec, algo, monkeypatch):
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
     from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
     from diffphore_amd.sampling import sampling_phore
     from diffphore_amd.score_model import TensorProductScoreModel
@@ -210,12 +231,16 @@ def test_sampler_trajectory_matches_oracle(ode, prec):
     b, _ = sampling_phore(b, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, ode=ode, batch_size=5, noise=noise)
     r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b)])
     print("per-pose RMSD (A):", r)
-    assert np.median(r) < 1e-4, r
-    assert np.quantile(r, 0.9) < 1e-3 or (r < 1e-3).sum() >= len(r) - 1, r
+
+    def fp32_oracle():
+        _, om32 = _model(torch.float32)
+        c, _ = osampler.sampling_phore(copy.deepcopy(gs), om32, S, sched, sched, sched, t_to_sigma_fn(args), args, ode=ode, batch_size=5, noise=noise)
+        return np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
+    _assert_poses_or_fp32_flip(r, fp32_oracle, f"6-step {prec}/{algo}")
 
 
 @pytest.mark.parametrize("shape", [(20, 5, 79), (80, 25, 32), (3, 0, 8)])
-def test_forward_other_baseline_shapes(shape):
+def test_forward_other_baseline_shapes(shape, monkeypatch):
     """BASELINE configs[0]-like (20 atoms x 79 phore nodes: 3 workgroup slices per pose), configs[2] (80 atoms, 25 torsions: the
     32-neighbour cap binds), and a degenerate 3-atom ligand without torsions (the phore keeps >=1 exclusion sphere: without one
     the reference feeds d_min = 1e9 into a Linear layer, :912, and overflows)."""
@@ -227,13 +252,14 @@ def test_forward_other_baseline_shapes(shape):
     batch = Batch.from_data_list(gs)
     osampler.set_time_phore(batch, 0.55, 0.55, 0.55, batch.num_graphs)
     tr_o, rot_o, tor_o = om(batch)
-    for prec in ("f32", "bf16x6"):
+    for prec, algo in (("f32", "edge"), ("f32", "node"), ("bf16x6", "edge"), ("bf16x9", "edge")):
+        monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
         m = TensorProductScoreModel(device="cuda", precision=prec).load_state_dict(sd)
         tr, rot, tor = m(batch)
         assert tor.shape == tor_o.shape
-        assert _rel(tr, tr_o) < 2e-4 and _rel(rot, rot_o) < 2e-4, (prec, _rel(tr, tr_o), _rel(rot, rot_o))
+        assert _rel(tr, tr_o) < 2e-5 and _rel(rot, rot_o) < 2e-5, (prec, algo, _rel(tr, tr_o), _rel(rot, rot_o))
         if tor_o.numel():
-            assert _rel(tor, tor_o) < 2e-4, (prec, _rel(tor, tor_o))
+            assert _rel(tor, tor_o) < 2e-5, (prec, algo, _rel(tor, tor_o))
 
 
 def test_sampler_chunking_and_keep_update():
@@ -285,13 +311,15 @@ def test_fit_complexes_driver_single_rank():
         assert np.abs(p[0] - p[1]).max() > 1e-2
 
 
-def test_hip_path_matches_reference_model_and_sampler_golden(golden_dir):
+@pytest.mark.parametrize("algo", ["edge", "node"])
+def test_hip_path_matches_reference_model_and_sampler_golden(golden_dir, algo, monkeypatch):
     """The HIP path held DIRECTLY to outputs of the reference's own model / sampler code (tests/golden/make_model_golden.py;
     third-party packages adapted onto the oracle's restatements there - see that file's header for what this does and does not pin)."""
     from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
     from diffphore_amd.sampling import randomize_position, sampling_phore
     from diffphore_amd.score_model import TensorProductScoreModel
     from oracle import sampler as osampler
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
     G = np.load(os.path.join(golden_dir, "ref_model_glue.npz"))
     m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
     for ci in range(5):
@@ -300,9 +328,10 @@ def test_hip_path_matches_reference_model_and_sampler_golden(golden_dir):
         batch = Batch.from_data_list(synthetic.synthetic_pairs(seed, n, nl, nt, npn))
         osampler.set_time_phore(batch, t, t, t, batch.num_graphs)
         tr, rot, tor = m(batch)
-        assert _rel(tr, torch.from_numpy(G[f"case{ci}_tr"])) < 2e-4 and _rel(rot, torch.from_numpy(G[f"case{ci}_rot"])) < 2e-4
+        # the golden run is the reference model in fp32 on CPU: both sides round, hence 5e-5 here against 2e-5 vs the fp64 oracle
+        assert _rel(tr, torch.from_numpy(G[f"case{ci}_tr"])) < 5e-5 and _rel(rot, torch.from_numpy(G[f"case{ci}_rot"])) < 5e-5
         if tor.numel():
-            assert _rel(tor, torch.from_numpy(G[f"case{ci}_tor"])) < 2e-4
+            assert _rel(tor, torch.from_numpy(G[f"case{ci}_tor"])) < 5e-5
     cfg = config.ModelConfig()
     args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
                                                                  "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
@@ -318,7 +347,7 @@ def test_hip_path_matches_reference_model_and_sampler_golden(golden_dir):
         pos = np.stack([g["ligand"].pos.numpy() for g in res])
         r = np.sqrt(((pos - G[f"samp_{name}_pos"]) ** 2).sum(-1).mean(-1))
         print(name, "RMSD vs reference sampler (A):", r)
-        assert np.median(r) < 1e-4 and r.max() < 1e-3, r
+        assert r.max() < 1e-4, r
         nrm = np.stack([g["ligand"].norm.numpy().reshape(18, 33) for g in res])
         assert np.abs(nrm - G[f"samp_{name}_norm"]).max() < 1e-3
 
@@ -357,7 +386,7 @@ def test_sampler_without_any_torsion_and_no_torsion_flag():
             assert (d0 - d1).abs().max() < 2e-4
 
 
-def test_full_schedule_20_steps_matches_oracle():
+def test_full_schedule_20_steps_matches_oracle(monkeypatch):
     """SURVEY.md 8c's parity definition, literally: the full 20-step schedule (BASELINE's inference_steps), final coordinates within
     1e-4 A RMSD of the CPU oracle (fp64 score model) on the same weights, tables and pre-drawn noise."""
     from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
@@ -384,13 +413,23 @@ def test_full_schedule_20_steps_matches_oracle():
     sd, om = _model()
     a, _ = osampler.sampling_phore(copy.deepcopy(gs), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=8, noise=noise,
                                    no_final_step_noise=True)
-    for prec in ("f32", "bf16x6"):
+    cache = {}
+
+    def fp32_oracle():
+        if "r" not in cache:
+            _, om32 = _model(torch.float32)
+            c, _ = osampler.sampling_phore(copy.deepcopy(gs), om32, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=8, noise=noise,
+                                           no_final_step_noise=True)
+            cache["r"] = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
+        return cache["r"]
+    for prec, algo in (("f32", "edge"), ("f32", "node"), ("bf16x6", "edge"), ("bf16x9", "edge")):
+        monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
         m = TensorProductScoreModel(device="cuda", precision=prec).load_state_dict(sd)
         b, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, batch_size=8, noise=noise,
                               no_final_step_noise=True)
         r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b)])
-        print(prec, "20-step per-pose RMSD (A):", r)
-        assert np.median(r) < 1e-4 and (r < 1e-3).sum() >= len(r) - 1, (prec, r)
+        print(prec, algo, "20-step per-pose RMSD (A):", r)
+        _assert_poses_or_fp32_flip(r, fp32_oracle, f"20-step {prec}/{algo}")
 
 
 def test_random_shapes_soak():
@@ -432,3 +471,57 @@ def test_random_shapes_soak():
             over += e > 3e-4
             assert e < 5e-2, (bi, e)
     assert over <= 1, over
+
+
+def test_configs0_real_example_inputs(golden_dir, monkeypatch):
+    """BASELINE configs[0] on the reference's shipped example: the sQC pharmacophore parsed by `phore_io` (79 nodes / 811 edges) and
+    ligand STK936575 with its real geometry, bonds and rotatable-bond masks (`synthetic.example_complex`), 40 samples x 20 steps as
+    `inference.py --sample_per_complex 40 --inference_steps 20 --batch_size 20` runs it.  The fp64 oracle covers the first 8 samples
+    (poses are independent, so they are the same trajectories inside the 40-sample device batch); all 40 must stay finite, keep the
+    ligand's bond lengths and differ from each other."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import conformer, sampler as osampler
+    from scipy.spatial.transform import Rotation
+    g0 = synthetic.example_complex(os.path.join(golden_dir, "STK936575.sdf"), os.path.join(golden_dir, "sQC_QFA_complex.phore"))
+    assert g0["ligand"].pos.shape[0] == 20 and g0["phore"].pos.shape[0] == 79 and g0["phore", "phore"].edge_index.shape[1] == 811
+    assert g0["ligand", "ligand"].edge_index.shape[1] == 44
+    N, S, NO = 40, 20, 8
+    gs = [g0.sample_copy() for _ in range(N)]
+    rng = np.random.default_rng(17)
+    draws = [dict(tor=rng.uniform(-np.pi, np.pi, size=int(g["ligand"].edge_mask.sum())),
+                  rot=Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix(),
+                  tr=torch.from_numpy(rng.normal(scale=5.0, size=(1, 3)).astype(np.float32))) for g in gs]
+    conformer.randomize_position(gs, False, False, 5.0, draws=draws)
+    for g in gs:
+        g["ligand"].norm = g["ligand"].norm.reshape(-1, 33)
+    sched = get_t_schedule(S)
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    gen = torch.Generator().manual_seed(40)
+    T = int(g0["ligand"].edge_mask.sum())
+    noise = dict(tr=torch.randn(S, N, 3, generator=gen), rot=torch.randn(S, N, 3, generator=gen), tor=torch.randn(S, N * T, generator=gen))
+    sub = dict(tr=noise["tr"][:, :NO], rot=noise["rot"][:, :NO], tor=noise["tor"][:, :NO * T])
+    sd, om = _model()
+    a, _ = osampler.sampling_phore(copy.deepcopy(gs[:NO]), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=NO, noise=sub)
+
+    def fp32_oracle():
+        _, om32 = _model(torch.float32)
+        c, _ = osampler.sampling_phore(copy.deepcopy(gs[:NO]), om32, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=NO, noise=sub)
+        return np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
+    ei = g0["ligand", "ligand"].edge_index.numpy()
+    d0 = np.linalg.norm(g0["ligand"].pos.numpy()[ei[0]] - g0["ligand"].pos.numpy()[ei[1]], axis=1)
+    for algo in ("edge", "node"):
+        monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
+        m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+        b, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, batch_size=20, noise=noise)
+        pos = np.stack([g["ligand"].pos.numpy() for g in b])
+        assert np.isfinite(pos).all()
+        r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b[:NO])])
+        print(algo, "configs[0] 20-step per-pose RMSD vs fp64 oracle (A):", r)
+        _assert_poses_or_fp32_flip(r, fp32_oracle, f"configs[0] {algo}")
+        for s_ in range(N):
+            np.testing.assert_allclose(np.linalg.norm(pos[s_][ei[0]] - pos[s_][ei[1]], axis=1), d0, atol=5e-4)
+        assert np.abs(pos[0] - pos[1]).max() > 1e-2

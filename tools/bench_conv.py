@@ -78,7 +78,16 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    if a.prof:
+    if a.prof and a.algo == "node":
+        buf = (C.c_ulonglong * 16)()
+        L.dp_debug_prof_node(None, 1)
+        L.dp_tp_conv(C.byref(args), st)
+        torch.cuda.synchronize()
+        L.dp_debug_prof_node(buf, 0)
+        tot = sum(buf[:5]) or 1
+        for n, v in zip(["sh staging+barriers", "GEMM1", "GEMM-A (+operand fetch)", "GEMM-B", "reduce+epilogue"], buf[:5]):
+            print(f"  {n:24s} {v:14d} ticks  {100.0 * v / tot:5.1f} %")
+    elif a.prof:
         buf = (C.c_ulonglong * 16)()
         L.dp_debug_prof(None, 1)
         L.dp_tp_conv(C.byref(args), st)
