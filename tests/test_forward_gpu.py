@@ -1,14 +1,14 @@
 """GPU parity of the whole hot path (through the C ABI) against the CPU oracle and the reference's golden vectors.
 
 Tolerances (fp32 device path vs fp64 oracle, identical weights / tables / noise; relative = max |diff| / max |ref| per tensor):
-    per-forward scores, pooled head output, node features after 4 layers   <= 2e-5  (SURVEY.md 8c asks 1e-5 "relative"; measured
-                                  1e-6..8e-6 over precisions / conv formulations on these batches, the bound leaves 2.5x)
+    per-forward scores, pooled head output, node features after 4 layers   <= 1e-5  (SURVEY.md 8c's bound; measured 1e-7..1e-6 for
+                                  f32 / bf16x6 / bf16x9 and both conv formulations; bf16x3: 1e-4 allowed, 9e-6 measured)
     per-edge embeddings / spherical harmonics                              <= 2e-5 (measured ~1e-6)
     conformer update vs reference golden vectors   <= 3e-6 A  (reference itself is fp32 + fp32 SVD)
-    end-to-end trajectory         EVERY pose <= 1e-4 A RMSD from the fp64 oracle, unless the reference algorithm's own discontinuous
-                                  decisions (sign of an MLP output, d < 5 A radius cut, <= k thresholds) flip in fp32: a pose may
-                                  exceed the bound only if the fp32 CPU oracle - same arithmetic class, no GPU - leaves the fp64
-                                  trajectory for that same pose as well (`_assert_poses_or_fp32_flip`).
+    end-to-end trajectory         EVERY pose <= 1e-4 A RMSD from the fp64 oracle, unless the reference algorithm itself is ill-conditioned
+                                  at that pose: its discontinuous decisions (sign of an MLP output, d < 5 A radius cut, <= k thresholds)
+                                  flip within fp32 resolution.  A pose may exceed the bound only if the fp64 oracle leaves its OWN
+                                  trajectory by more than the bound when the start is moved by 2e-6 A (`_assert_poses_or_ill_conditioned`).
 """
 import copy
 import ctypes as C
@@ -51,7 +51,7 @@ def _rel(a, b):
 def test_forward_matches_oracle(prec, algo, monkeypatch):
     from diffphore_amd.score_model import TensorProductScoreModel
     monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
-    tol = 1.0 if prec != "bf16x3" else 20.0
+    tol = 1.0 if prec != "bf16x3" else 10.0       # measured: 1e-7..1e-6 (f32, bf16x6, bf16x9; both conv formulations), 9e-6 (bf16x3)
     from oracle import sampler as osampler
     gs = _mixed_graphs()
     sd, om = _model()
@@ -81,7 +81,7 @@ def test_forward_matches_oracle(prec, algo, monkeypatch):
                 rot=_rel(rot, rot_o), tor=_rel(tor, tor_o))                  # after 4 layers the node features sit in buffer 0
     print(prec, algo, "relative errors vs fp64 oracle:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert tor.shape == tor_o.shape and tr.shape == (len(gs), 3)
-    assert all(v < 2e-5 * tol for v in errs.values()), errs
+    assert all(v < 1e-5 * tol for v in errs.values()), errs
     # side effects the reference leaves on the batch
     assert batch.graph_sigma_emb.shape == (len(gs), 20) and batch["phore"].node_sigma_emb.shape[0] == batch["phore"].pos.shape[0]
     assert n_l == batch["ligand"].node_sigma_emb.shape[0]
@@ -184,17 +184,29 @@ def _rmsd(a, b):
     return float(np.sqrt(((a - b) ** 2).sum(-1).mean()))
 
 
-def _assert_poses_or_fp32_flip(r, run_fp32_oracle, what, bound=1e-4):
-    """Every pose within `bound` of the fp64 oracle - or, for the poses that are not, the fp32 CPU oracle (run lazily, same inputs)
-    must have left the fp64 trajectory too: then the divergence is one of the reference algorithm's discontinuous decisions flipping
-    under fp32 rounding, not a property of the HIP kernels."""
+def _perturbed(gs, seed, eps=2e-6):
+    """the same start poses moved by ~fp32 resolution of a 10 A coordinate"""
+    out = copy.deepcopy(gs)
+    g_ = torch.Generator().manual_seed(seed)
+    for g in out:
+        g["ligand"].pos = g["ligand"].pos + eps * torch.randn(g["ligand"].pos.shape, generator=g_)
+    return out
+
+
+def _assert_poses_or_ill_conditioned(r, run_fp64_from, what, bound=1e-4):
+    """Every pose within `bound` of the fp64 oracle.  The reference algorithm contains discontinuous decisions (sign of an MLP output,
+    d < 5 A radius cut, d <= k thresholds, |d1| < |d2|): a trajectory that passes one within fp32 resolution lands on either side
+    depending on rounding.  A pose beyond the bound is accepted ONLY if the fp64 oracle ITSELF leaves its own trajectory by more than
+    the bound when that pose's start coordinates are moved by 2e-6 A (three seeds) - i.e. the reference is ill-conditioned there at
+    the resolution of fp32 - and never more than a quarter of the poses.  (Teacher-forced single steps agree to <= 3e-6 A everywhere:
+    tools/diag_traj.py.)"""
     bad = np.nonzero(~(r < bound))[0]
     if bad.size == 0:
         return
-    r32 = run_fp32_oracle()
-    print(what, "poses beyond the bound:", bad.tolist(), "HIP:", r[bad], "fp32 oracle:", r32[bad])
     assert np.isfinite(r).all() and bad.size <= max(1, len(r) // 4), (what, r)
-    assert all(r32[i] > bound for i in bad), (what, "HIP diverges where the fp32 CPU oracle does not", r, r32)
+    sens = np.max(np.stack([run_fp64_from(seed) for seed in (1, 2, 3)]), 0)
+    print(what, "poses beyond the bound:", bad.tolist(), "HIP:", r[bad], "fp64 oracle sensitivity to a 2e-6 A start perturbation:", sens[bad])
+    assert all(sens[i] > bound for i in bad), (what, "HIP leaves the fp64 trajectory at a pose where the reference is well conditioned", r, sens)
 
 
 @pytest.mark.parametrize("ode,prec,algo", [(False, "f32", "edge"), (True, "f32", "edge"), (False, "f32", "node"), (True, "f32", "node"),
@@ -232,11 +244,10 @@ def test_sampler_trajectory_matches_oracle(ode, prec, algo, monkeypatch):
     r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b)])
     print("per-pose RMSD (A):", r)
 
-    def fp32_oracle():
-        _, om32 = _model(torch.float32)
-        c, _ = osampler.sampling_phore(copy.deepcopy(gs), om32, S, sched, sched, sched, t_to_sigma_fn(args), args, ode=ode, batch_size=5, noise=noise)
+    def fp64_from(seed):
+        c, _ = osampler.sampling_phore(_perturbed(gs, seed), om, S, sched, sched, sched, t_to_sigma_fn(args), args, ode=ode, batch_size=5, noise=noise)
         return np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
-    _assert_poses_or_fp32_flip(r, fp32_oracle, f"6-step {prec}/{algo}")
+    _assert_poses_or_ill_conditioned(r, fp64_from, f"6-step {'ode' if ode else 'sde'} {prec}/{algo}")
 
 
 @pytest.mark.parametrize("shape", [(20, 5, 79), (80, 25, 32), (3, 0, 8)])
@@ -415,13 +426,12 @@ def test_full_schedule_20_steps_matches_oracle(monkeypatch):
                                    no_final_step_noise=True)
     cache = {}
 
-    def fp32_oracle():
-        if "r" not in cache:
-            _, om32 = _model(torch.float32)
-            c, _ = osampler.sampling_phore(copy.deepcopy(gs), om32, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=8, noise=noise,
+    def fp64_from(seed):
+        if seed not in cache:
+            c, _ = osampler.sampling_phore(_perturbed(gs, seed), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=8, noise=noise,
                                            no_final_step_noise=True)
-            cache["r"] = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
-        return cache["r"]
+            cache[seed] = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
+        return cache[seed]
     for prec, algo in (("f32", "edge"), ("f32", "node"), ("bf16x6", "edge"), ("bf16x9", "edge")):
         monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
         m = TensorProductScoreModel(device="cuda", precision=prec).load_state_dict(sd)
@@ -429,7 +439,7 @@ def test_full_schedule_20_steps_matches_oracle(monkeypatch):
                               no_final_step_noise=True)
         r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b)])
         print(prec, algo, "20-step per-pose RMSD (A):", r)
-        _assert_poses_or_fp32_flip(r, fp32_oracle, f"20-step {prec}/{algo}")
+        _assert_poses_or_ill_conditioned(r, fp64_from, f"20-step {prec}/{algo}")
 
 
 def test_random_shapes_soak():
@@ -507,10 +517,13 @@ def test_configs0_real_example_inputs(golden_dir, monkeypatch):
     sd, om = _model()
     a, _ = osampler.sampling_phore(copy.deepcopy(gs[:NO]), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=NO, noise=sub)
 
-    def fp32_oracle():
-        _, om32 = _model(torch.float32)
-        c, _ = osampler.sampling_phore(copy.deepcopy(gs[:NO]), om32, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=NO, noise=sub)
-        return np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
+    cache = {}
+
+    def fp64_from(seed):
+        if seed not in cache:
+            c, _ = osampler.sampling_phore(_perturbed(gs[:NO], seed), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=NO, noise=sub)
+            cache[seed] = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
+        return cache[seed]
     ei = g0["ligand", "ligand"].edge_index.numpy()
     d0 = np.linalg.norm(g0["ligand"].pos.numpy()[ei[0]] - g0["ligand"].pos.numpy()[ei[1]], axis=1)
     for algo in ("edge", "node"):
@@ -521,7 +534,7 @@ def test_configs0_real_example_inputs(golden_dir, monkeypatch):
         assert np.isfinite(pos).all()
         r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b[:NO])])
         print(algo, "configs[0] 20-step per-pose RMSD vs fp64 oracle (A):", r)
-        _assert_poses_or_fp32_flip(r, fp32_oracle, f"configs[0] {algo}")
+        _assert_poses_or_ill_conditioned(r, fp64_from, f"configs[0] {algo}")
         for s_ in range(N):
             np.testing.assert_allclose(np.linalg.norm(pos[s_][ei[0]] - pos[s_][ei[1]], axis=1), d0, atol=5e-4)
         assert np.abs(pos[0] - pos[1]).max() > 1e-2

@@ -1,0 +1,178 @@
+"""BASELINE configs[3] / configs[4] per-GPU workloads (diffphore_amd/workloads.py) on the device vs the fp64 oracle, and the
+multi-GPU contract on ONE GPU: two ranks (gloo rendezvous, both on cuda:0) run their LPT shards of a virtual screen with weights
+broadcast from rank 0, and reproduce the unsharded run pose for pose."""
+import copy
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffphore_amd import config, synthetic, weights, workloads  # noqa: E402
+from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn  # noqa: E402
+
+
+def _args():
+    cfg = config.ModelConfig()
+    return types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+
+
+def _rmsd(a, b):
+    return float(np.sqrt(((a - b) ** 2).sum(-1).mean()))
+
+
+def _start_and_noise(poses, keys, S):
+    """Start poses and per-step noise that depend only on a pose's global key, not on which rank / batch it lands in."""
+    from oracle import conformer
+    from scipy.spatial.transform import Rotation
+    draws, ztr, zrot, ztor = [], [], [], []
+    for g, key in zip(poses, keys):
+        rng = np.random.default_rng(key)
+        T = int(g["ligand"].edge_mask.sum())
+        draws.append(dict(tor=rng.uniform(-np.pi, np.pi, size=T), rot=Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix(),
+                          tr=torch.from_numpy(rng.normal(scale=3.0, size=(1, 3)).astype(np.float32))))
+        ztr.append(rng.normal(size=(S, 1, 3)).astype(np.float32))
+        zrot.append(rng.normal(size=(S, 1, 3)).astype(np.float32))
+        ztor.append(rng.normal(size=(S, T)).astype(np.float32))
+    conformer.randomize_position(poses, False, False, 5.0, draws=draws)
+    for g in poses:
+        g["ligand"].norm = g["ligand"].norm.reshape(-1, 33)
+    return dict(tr=torch.from_numpy(np.concatenate(ztr, 1)), rot=torch.from_numpy(np.concatenate(zrot, 1)),
+                tor=torch.from_numpy(np.concatenate(ztor, 1)))
+
+
+@pytest.mark.parametrize("cfg_id,precision,tol", [(4, "f32", 1e-4), (5, "bf16x3", 5e-3)])
+def test_config_workload_matches_oracle(cfg_id, precision, tol, monkeypatch):
+    """2 complexes x 40 samples of the configs[3] / configs[4] generators, first steps of their schedules (20 / 100 steps), HIP vs the
+    fp64 oracle on a sample of the poses; configs[4] runs BASELINE's 'bf16 mixed precision' analogue (2-way bf16 split, ~2^-17 products),
+    hence its looser bound."""
+    from diffphore_amd.sampling import sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import sampler as osampler
+    from oracle.model import OracleScoreModel
+    from oracle.tables import load_tables
+    poses, mine = workloads.build(cfg_id, 2, 0, 1)
+    assert len(poses) == 2 * workloads.SAMPLES and mine == [0, 1]
+    S_total, S = workloads.steps_of(cfg_id), 3
+    assert S_total == (20 if cfg_id == 4 else 100)
+    sched = get_t_schedule(S_total)[:S + 1]
+    args = _args()
+    noise = _start_and_noise(poses, [1000 + i for i in range(len(poses))], S)
+    sd = weights.init_state_dict()
+    m = TensorProductScoreModel(device="cuda", precision=precision).load_state_dict(sd)
+    b, _ = sampling_phore(copy.deepcopy(poses), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise)
+    assert all(np.isfinite(g["ligand"].pos.numpy()).all() for g in b)
+    pick = [0, 1, 39, 40, 41, 79]                          # samples of both complexes
+    T = [int(g["ligand"].edge_mask.sum()) for g in poses]
+    toff = np.concatenate([[0], np.cumsum(T)])
+    sub = dict(tr=noise["tr"][:, pick], rot=noise["rot"][:, pick],
+               tor=torch.cat([noise["tor"][:, toff[i]:toff[i + 1]] for i in pick], 1))
+    om = OracleScoreModel(sd, config.ModelConfig(), dtype=torch.float64, tables=load_tables())
+    a, _ = osampler.sampling_phore([copy.deepcopy(poses[i]) for i in pick], om, S, sched, sched, sched, t_to_sigma_fn(args), args,
+                                   batch_size=len(pick), noise=sub)
+    r = np.asarray([_rmsd(x["ligand"].pos.numpy(), b[i]["ligand"].pos.numpy()) for x, i in zip(a, pick)])
+    print(f"config {cfg_id} ({precision}) RMSD vs fp64 oracle (A):", r)
+    assert (r < tol).all(), r
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_worker(rank, world, port, S, q):
+    import torch.distributed as dist
+    from diffphore_amd import distributed as D
+    from diffphore_amd.sampling import sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        cplx = synthetic.synthetic_pairs(4, 6, (15, 45), (2, 12), 79, seed=synthetic.BASE_SEED + 4, shared_phore=True)
+        mine = D.shard_indices([D.pose_cost(g) for g in cplx], world)[rank]
+        NS = 3
+        poses = [cplx[i].sample_copy() for i in mine for _ in range(NS)]
+        keys = [7000 + 10 * i + s for i in mine for s in range(NS)]
+        noise = _start_and_noise(poses, keys, S)
+        # rank 0 owns the real weights; the others start from a different random model and must receive rank 0's blob
+        m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict(20250321 if rank == 0 else 99))
+        blob = m.device_model.blob.cpu()
+        D.broadcast_weights(blob, src=0)
+        m.device_model.blob.copy_(blob)
+        args = _args()
+        sched = get_t_schedule(20)[:S + 1]
+        out, _ = sampling_phore(poses, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise)
+        allpos = D.gather_positions(keys, [g["ligand"].pos for g in out], 0, dst=0) if False else None
+        payload = (keys, [g["ligand"].pos.numpy() for g in out])
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(payload, gathered, dst=0)
+        if rank == 0:
+            q.put({k: p for ks, ps in gathered for k, p in zip(ks, ps)})
+        del allpos
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_equal_the_unsharded_run():
+    import torch.multiprocessing as mp
+    from diffphore_amd.sampling import sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+    S, NS = 3, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sharded = q.get(timeout=500)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cplx = synthetic.synthetic_pairs(4, 6, (15, 45), (2, 12), 79, seed=synthetic.BASE_SEED + 4, shared_phore=True)
+    poses = [cplx[i].sample_copy() for i in range(6) for _ in range(NS)]
+    keys = [7000 + 10 * i + s for i in range(6) for s in range(NS)]
+    noise = _start_and_noise(poses, keys, S)
+    m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+    args = _args()
+    sched = get_t_schedule(20)[:S + 1]
+    out, _ = sampling_phore(poses, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise)
+    assert sorted(sharded) == sorted(keys)
+    worst = max(_rmsd(sharded[k], g["ligand"].pos.numpy()) for k, g in zip(keys, out))
+    print("worst RMSD sharded vs unsharded (A):", worst)
+    assert worst < 2e-5      # same kernels on the same poses; only the batch composition (workgroup slicing of the edge-side convs) differs
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("cfg_id,extra", [(2, ["--poses", "24"]), (4, ["--units", "1"]), (5, ["--units", "1"])])
+def test_bench_self_launches_two_ranks(cfg_id, extra):
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself (here both on the one GPU of the box, gloo rendezvous) and
+    rank 0 prints the contract's JSON line with n_gpus = 2 and the whole-job pose count."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIFFPHORE_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", str(cfg_id),
+                          "--no-cpu-baseline", "--no-alt", "--no-e2e"] + extra, capture_output=True, text=True, timeout=800, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["finite"] and d["config"]["kabsch_flagged_poses"] == 0
+    per = {2: 24, 4: 40, 5: 40}[cfg_id]
+    assert d["config"]["poses_total"] == 2 * per
+    assert f"configs[{cfg_id - 1}]" in d["config"]["workload"]
+    assert d["dtype"].startswith("bf16x3" if cfg_id == 5 else "f32")
