@@ -81,6 +81,14 @@ def radius_graph(pos: torch.Tensor, r: float, batch: torch.Tensor, max_num_neigh
     return torch.stack([row[keep], col[keep]])
 
 
+def _graph_min(val: torch.Tensor, graph: torch.Tensor, B: int) -> torch.Tensor:
+    """per-graph minimum of `val` (1e9 where a graph has no entry)"""
+    out = torch.full((B,), 1e9, dtype=torch.float64)
+    if val.numel():
+        out = out.scatter_reduce(0, graph.long().reshape(-1), val.double().reshape(-1), reduce="amin", include_self=True)
+    return out
+
+
 def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
     out = src.new_zeros(dim_size, src.shape[1]).index_add_(0, index, src)
     cnt = torch.bincount(index, minlength=dim_size).clamp_min(1).to(src.dtype)
@@ -112,6 +120,11 @@ class OracleScoreModel:
         self.tor_out = e3.parse_irreps("20x0o + 20x0e")
         self.tor_sh_irreps, _ = e3.full_tp_irreps(self.sh_irreps, e3.parse_irreps("1x2e"))
         self.debug: Dict[str, torch.Tensor] = {}
+        # decision margins (tests only): with track_margins the forward records, per graph, how close each DISCONTINUOUS decision of the
+        # reference algorithm came to flipping (relative distance from its threshold): radius cuts, d_min <= k, sign of the direction
+        # MLP, |d2| < |d1|.  A trajectory that passes one within fp32 resolution has no well-defined fp32 continuation.
+        self.track_margins = False
+        self.margins: Dict[str, torch.Tensor] = {}
 
     # ---- small modules -------------------------------------------------------------------------------------------
     def lin(self, name, x):
@@ -148,6 +161,12 @@ class OracleScoreModel:
         L.node_sigma_emb = timestep_embedding(L.node_t["tr"], self.cfg.embedding_scale, self.cfg.sigma_embed_dim)
         pos = L.pos.to(dt)
         radius_edges = radius_graph(L.pos.float(), self.cfg.lig_max_radius, L.batch)
+        if self.track_margins:      # distance of every same-graph atom pair from the 5 A cut, relative (decision: d^2 < r^2)
+            B = int(L.batch.max()) + 1
+            d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
+            same = (L.batch[:, None] == L.batch[None, :]) & ~torch.eye(pos.shape[0], dtype=torch.bool)
+            rel = (d2 / self.cfg.lig_max_radius ** 2 - 1).abs()
+            self.margins = {"lig_radius": _graph_min(rel[same], L.batch[:, None].expand_as(same)[same], B)}
         bond_ei = data["ligand", "ligand"].edge_index.long()
         edge_index = torch.cat([bond_ei, radius_edges], 1)
         edge_attr = torch.cat([data["ligand", "ligand"].edge_attr.to(dt),
@@ -221,6 +240,21 @@ class OracleScoreModel:
         edge_sh = e3.spherical_harmonics_lmax2(edge_vec)
         edge_norm_sh = e3.spherical_harmonics_lmax2(rotate_norm)
         self.debug.update(cross_dir=direction, cross_aw=atom_weight, cross_tw=total_weight)
+        if self.track_margins:
+            B = int(L.batch.max()) + 1
+            gsrc = L.batch[src]
+            # sign of the direction MLP output (:813-816): |z| relative to the magnitude of the terms it is the (cancelling) sum of,
+            # z = b3 + sum_o w3_o leaky(w0_o tw + b0_o) - the scale on which fp32 rounding of the sum acts
+            pre = "encoder.phore_direction_transition"
+            hdir = F.leaky_relu(self.lin(pre + ".0", total_weight))
+            w3, b3 = self.sd[pre + ".3.weight"], self.sd[pre + ".3.bias"]
+            zdir = F.linear(hdir, w3, b3).reshape(-1)
+            scale = (hdir * w3.reshape(1, -1)).abs().sum(-1) + b3.abs().reshape(-1)
+            self.margins["cross_sign"] = _graph_min(zdir.abs() / scale.clamp_min(1e-30), gsrc, B)
+            # |d2| < |d1| choice of the normal-vector rule (:883-887); only where it changes the result (d1 != d2, agreement present)
+            live = ((d1 - d2).abs().reshape(-1) > 0) & (agreement.sum(-1) > 0)
+            gap = (d2.abs() - d1.abs()).abs().reshape(-1)
+            self.margins["norm_choice"] = _graph_min(gap[live], gsrc[live], B)
         return torch.stack([src, dst]), edge_attr, edge_sh, edge_norm_sh
 
     def boarder_analyze(self, data):
@@ -235,6 +269,10 @@ class OracleScoreModel:
         dis_min = torch.where(m, d, torch.full_like(d, 1e9)).min(dim=1).values if ppos.shape[0] else torch.full((lpos.shape[0],), 1e9, dtype=dt)
         cut = torch.tensor(list(self.cfg.clash_cutoff), dtype=dt)
         clashed = dis_min[:, None] <= cut[None, :]
+        if self.track_margins:      # d_min <= k thresholds (:912-935)
+            B = int(L.batch.max()) + 1
+            rel = ((dis_min[:, None] - cut[None, :]).abs() / cut[None, :]).min(dim=1).values
+            self.margins["boarder"] = _graph_min(rel, L.batch, B)
         return clashed, dis_min[:, None]
 
     # ---- encoder -------------------------------------------------------------------------------------------------
@@ -323,6 +361,12 @@ class OracleScoreModel:
         bond_pos = (pos[bonds[0]] + pos[bonds[1]]) / 2
         bond_batch = L.batch[bonds[0]]
         t_ei = radius_neighbors(L.pos.float(), L.batch, bond_pos.float(), bond_batch, cfg.lig_max_radius, 32)
+        if self.track_margins:
+            B = int(L.batch.max()) + 1
+            d2 = ((bond_pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
+            same = bond_batch[:, None] == L.batch[None, :]
+            rel = (d2 / cfg.lig_max_radius ** 2 - 1).abs()
+            self.margins["tor_radius"] = _graph_min(rel[same], bond_batch[:, None].expand_as(same)[same], B)
         t_vec = pos[t_ei[1]] - bond_pos[t_ei[0]]
         t_attr = self.mlp("final_edge_embedding", gaussian_smearing(t_vec.norm(dim=-1), cfg.lig_max_radius))
         t_sh = e3.spherical_harmonics_lmax2(t_vec)

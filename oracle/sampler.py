@@ -41,7 +41,7 @@ def set_time_phore(graphs, t_tr, t_rot, t_tor, batchsize):
 
 
 def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma_fn, model_args,
-                   no_random=False, ode=False, batch_size=20, no_final_step_noise=False, noise=None, trace=None):
+                   no_random=False, ode=False, batch_size=20, no_final_step_noise=False, noise=None, trace=None, pos_trace=None, margin_trace=None):
     N = len(data_list)
     for t_idx in range(inference_steps):
         t_tr, t_rot, t_tor = tr_schedule[t_idx], rot_schedule[t_idx], tor_schedule[t_idx]
@@ -63,6 +63,8 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             tr_score, rot_score, tor_score = tr_score.float(), rot_score.float(), tor_score.float()
             if trace is not None:
                 trace.append((tr_score.clone(), rot_score.clone(), tor_score.clone()))
+            if getattr(model, "track_margins", False) and margin_trace is not None:
+                margin_trace.append((t_idx, lo, {k: v.clone() for k, v in model.margins.items()}))
             tr_g = tr_sigma * torch.sqrt(torch.tensor(2 * np.log(model_args.tr_sigma_max / model_args.tr_sigma_min)))
             rot_g = 2 * rot_sigma * torch.sqrt(torch.tensor(np.log(model_args.rot_sigma_max / model_args.rot_sigma_min)))
             zero = no_random or (no_final_step_noise and last)
@@ -103,4 +105,6 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             g0 += b
             tor0 += nT
         data_list = new_data_list
+        if pos_trace is not None:          # per-step coordinates (diagnostics: tools/diag_traj2.py)
+            pos_trace.append([g["ligand"].pos.clone() for g in data_list])
     return data_list, None

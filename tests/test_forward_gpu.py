@@ -7,8 +7,8 @@ Tolerances (fp32 device path vs fp64 oracle, identical weights / tables / noise;
     conformer update vs reference golden vectors   <= 3e-6 A  (reference itself is fp32 + fp32 SVD)
     end-to-end trajectory         EVERY pose <= 1e-4 A RMSD from the fp64 oracle, unless the reference algorithm itself is ill-conditioned
                                   at that pose: its discontinuous decisions (sign of an MLP output, d < 5 A radius cut, <= k thresholds)
-                                  flip within fp32 resolution.  A pose may exceed the bound only if the fp64 oracle leaves its OWN
-                                  trajectory by more than the bound when the start is moved by 2e-6 A (`_assert_poses_or_ill_conditioned`).
+                                  flip within fp32 resolution.  A pose may exceed the bound only if the fp64 oracle recorded, for that
+                                  pose, a decision held by a relative margin < 1e-5 (`_assert_poses_or_decision_flip`).
 """
 import copy
 import ctypes as C
@@ -184,29 +184,42 @@ def _rmsd(a, b):
     return float(np.sqrt(((a - b) ** 2).sum(-1).mean()))
 
 
-def _perturbed(gs, seed, eps=2e-6):
-    """the same start poses moved by ~fp32 resolution of a 10 A coordinate"""
-    out = copy.deepcopy(gs)
-    g_ = torch.Generator().manual_seed(seed)
-    for g in out:
-        g["ligand"].pos = g["ligand"].pos + eps * torch.randn(g["ligand"].pos.shape, generator=g_)
-    return out
+def _oracle_run_with_margins(om, gs, S, sched, args, **kw):
+    """fp64 oracle trajectory + per pose the smallest relative margin by which any discontinuous decision of the reference algorithm
+    (5 A radius cuts of the ligand / torsion graphs, d_min <= k clash thresholds, sign of the direction MLP, |d2| < |d1| angle choice)
+    held along it (oracle/model.py `track_margins`)."""
+    from diffphore_amd.diffusion import t_to_sigma_fn
+    from oracle import sampler as osampler
+    mt = []
+    om.track_margins = True
+    try:
+        a, _ = osampler.sampling_phore(copy.deepcopy(gs), om, S, sched, sched, sched, t_to_sigma_fn(args), args, margin_trace=mt, **kw)
+    finally:
+        om.track_margins = False
+    margin = np.full(len(gs), 1e9)
+    which = [""] * len(gs)
+    for t_idx, lo, mm in mt:
+        for k, v in mm.items():
+            for i, x in enumerate(v.numpy()):
+                if x < margin[lo + i]:
+                    margin[lo + i], which[lo + i] = x, f"{k}@step{t_idx}"
+    return a, margin, which
 
 
-def _assert_poses_or_ill_conditioned(r, run_fp64_from, what, bound=1e-4):
-    """Every pose within `bound` of the fp64 oracle.  The reference algorithm contains discontinuous decisions (sign of an MLP output,
-    d < 5 A radius cut, d <= k thresholds, |d1| < |d2|): a trajectory that passes one within fp32 resolution lands on either side
-    depending on rounding.  A pose beyond the bound is accepted ONLY if the fp64 oracle ITSELF leaves its own trajectory by more than
-    the bound when that pose's start coordinates are moved by 2e-6 A (three seeds) - i.e. the reference is ill-conditioned there at
-    the resolution of fp32 - and never more than a quarter of the poses.  (Teacher-forced single steps agree to <= 3e-6 A everywhere:
-    tools/diag_traj.py.)"""
+MARGIN_FP32 = 1e-5      # a decision whose relative margin is below this cannot be expected to fall the same way in fp32 and fp64
+
+
+def _assert_poses_or_decision_flip(r, margin, which, what, bound=1e-4):
+    """Every pose within `bound` of the fp64 oracle.  The reference algorithm contains discontinuous decisions; a trajectory that passes
+    one within fp32 resolution lands on either side depending on rounding.  A pose beyond the bound is accepted ONLY if the fp64 oracle
+    recorded such a near-tie for THAT pose (relative margin < 1e-5, named in the message), and never more than a quarter of the poses.
+    (Teacher-forced single steps agree to <= 3e-6 A everywhere, and both conv formulations flip identically: tools/diag_traj*.py.)"""
     bad = np.nonzero(~(r < bound))[0]
     if bad.size == 0:
         return
+    print(what, "poses beyond the bound:", bad.tolist(), "RMSD:", r[bad], "closest decision:", [(which[i], float(margin[i])) for i in bad])
     assert np.isfinite(r).all() and bad.size <= max(1, len(r) // 4), (what, r)
-    sens = np.max(np.stack([run_fp64_from(seed) for seed in (1, 2, 3)]), 0)
-    print(what, "poses beyond the bound:", bad.tolist(), "HIP:", r[bad], "fp64 oracle sensitivity to a 2e-6 A start perturbation:", sens[bad])
-    assert all(sens[i] > bound for i in bad), (what, "HIP leaves the fp64 trajectory at a pose where the reference is well conditioned", r, sens)
+    assert all(margin[i] < MARGIN_FP32 for i in bad), (what, "HIP leaves the fp64 trajectory at a pose with no near-tie decision", r, margin)
 
 
 @pytest.mark.parametrize("ode,prec,algo", [(False, "f32", "edge"), (True, "f32", "edge"), (False, "f32", "node"), (True, "f32", "node"),
@@ -236,18 +249,14 @@ def test_sampler_trajectory_matches_oracle(ode, prec, algo, monkeypatch):
     noise = dict(tr=torch.randn(S, len(gs), 3, generator=gen), rot=torch.randn(S, len(gs), 3, generator=gen),
                  tor=torch.randn(S, nT, generator=gen))
     sd, om = _model()
-    a = copy.deepcopy(gs)
-    a, _ = osampler.sampling_phore(a, om, S, sched, sched, sched, t_to_sigma_fn(args), args, ode=ode, batch_size=5, noise=noise)
+    a, margin, which = _oracle_run_with_margins(om, gs, S, sched, args, ode=ode, batch_size=5, noise=noise)
     m = TensorProductScoreModel(device="cuda", precision=prec).load_state_dict(sd)
     b = copy.deepcopy(gs)
     b, _ = sampling_phore(b, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, ode=ode, batch_size=5, noise=noise)
     r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b)])
     print("per-pose RMSD (A):", r)
 
-    def fp64_from(seed):
-        c, _ = osampler.sampling_phore(_perturbed(gs, seed), om, S, sched, sched, sched, t_to_sigma_fn(args), args, ode=ode, batch_size=5, noise=noise)
-        return np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
-    _assert_poses_or_ill_conditioned(r, fp64_from, f"6-step {'ode' if ode else 'sde'} {prec}/{algo}")
+    _assert_poses_or_decision_flip(r, margin, which, f"6-step {'ode' if ode else 'sde'} {prec}/{algo}")
 
 
 @pytest.mark.parametrize("shape", [(20, 5, 79), (80, 25, 32), (3, 0, 8)])
@@ -422,16 +431,7 @@ def test_full_schedule_20_steps_matches_oracle(monkeypatch):
     nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
     noise = dict(tr=torch.randn(S, len(gs), 3, generator=gen), rot=torch.randn(S, len(gs), 3, generator=gen), tor=torch.randn(S, nT, generator=gen))
     sd, om = _model()
-    a, _ = osampler.sampling_phore(copy.deepcopy(gs), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=8, noise=noise,
-                                   no_final_step_noise=True)
-    cache = {}
-
-    def fp64_from(seed):
-        if seed not in cache:
-            c, _ = osampler.sampling_phore(_perturbed(gs, seed), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=8, noise=noise,
-                                           no_final_step_noise=True)
-            cache[seed] = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
-        return cache[seed]
+    a, margin, which = _oracle_run_with_margins(om, gs, S, sched, args, batch_size=8, noise=noise, no_final_step_noise=True)
     for prec, algo in (("f32", "edge"), ("f32", "node"), ("bf16x6", "edge"), ("bf16x9", "edge")):
         monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
         m = TensorProductScoreModel(device="cuda", precision=prec).load_state_dict(sd)
@@ -439,7 +439,7 @@ def test_full_schedule_20_steps_matches_oracle(monkeypatch):
                               no_final_step_noise=True)
         r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b)])
         print(prec, algo, "20-step per-pose RMSD (A):", r)
-        _assert_poses_or_ill_conditioned(r, fp64_from, f"20-step {prec}/{algo}")
+        _assert_poses_or_decision_flip(r, margin, which, f"20-step {prec}/{algo}")
 
 
 def test_random_shapes_soak():
@@ -515,15 +515,8 @@ def test_configs0_real_example_inputs(golden_dir, monkeypatch):
     noise = dict(tr=torch.randn(S, N, 3, generator=gen), rot=torch.randn(S, N, 3, generator=gen), tor=torch.randn(S, N * T, generator=gen))
     sub = dict(tr=noise["tr"][:, :NO], rot=noise["rot"][:, :NO], tor=noise["tor"][:, :NO * T])
     sd, om = _model()
-    a, _ = osampler.sampling_phore(copy.deepcopy(gs[:NO]), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=NO, noise=sub)
+    a, margin, which = _oracle_run_with_margins(om, gs[:NO], S, sched, args, batch_size=NO, noise=sub)
 
-    cache = {}
-
-    def fp64_from(seed):
-        if seed not in cache:
-            c, _ = osampler.sampling_phore(_perturbed(gs[:NO], seed), om, S, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=NO, noise=sub)
-            cache[seed] = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, c)])
-        return cache[seed]
     ei = g0["ligand", "ligand"].edge_index.numpy()
     d0 = np.linalg.norm(g0["ligand"].pos.numpy()[ei[0]] - g0["ligand"].pos.numpy()[ei[1]], axis=1)
     for algo in ("edge", "node"):
@@ -534,7 +527,7 @@ def test_configs0_real_example_inputs(golden_dir, monkeypatch):
         assert np.isfinite(pos).all()
         r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b[:NO])])
         print(algo, "configs[0] 20-step per-pose RMSD vs fp64 oracle (A):", r)
-        _assert_poses_or_ill_conditioned(r, fp64_from, f"configs[0] {algo}")
+        _assert_poses_or_decision_flip(r, margin, which, f"configs[0] {algo}")
         for s_ in range(N):
             np.testing.assert_allclose(np.linalg.norm(pos[s_][ei[0]] - pos[s_][ei[1]], axis=1), d0, atol=5e-4)
         assert np.abs(pos[0] - pos[1]).max() > 1e-2
