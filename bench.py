@@ -331,6 +331,16 @@ def main():
         del copy
 
     n_x = int(pb.x_ptr[-1])
+    _ws = Engine(model, pb).ws        # one forward's lig-lig edge count (the radius graph depends on the poses)
+    edge_counts = {"x": n_x, "pp": int(pb.pp_ptr[-1])}
+    try:
+        _e = Engine(model, pb)
+        _e.forward()
+        edge_counts["ll"] = int((_e.ws.t["ll_rowend"] - _e.ws.t["ll_rowptr"]).sum().item())
+        del _e
+    except Exception:      # noqa: BLE001 - informational only
+        pass
+    del _ws
     alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
     flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * n_x
     traffic, traffic_src = measured_traffic(a.config, B, precision, algo_used) if world == 1 else (None, None)
@@ -352,7 +362,7 @@ def main():
                        "poses_per_gpu": B, "poses_total": total_poses, f"poses_per_sec_at_{S_total}_steps": total_poses * a.steps / elapsed / S_total,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
                        "kabsch_flagged_poses": bad, "finite": finite, "precision": precision, "conv_algo": algo_used,
-                       "alt_runs": alt, "e2e": e2e},
+                       "edge_counts": edge_counts, "alt_runs": alt, "e2e": e2e},
             # The dominant kernel generates the per-edge TP weights on the matrix pipe in registers (they never reach HBM), so it is
             # bound by the fp32 matrix pipe; SURVEY.md 8d asks for both views when the radial MLP is fused into the TP kernel.
             # alg_flops_per_edge is the EDGE-SIDE count of SURVEY.md 8d (radial GEMM per edge); the node-side formulation computes

@@ -1,86 +1,128 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 (rocpd sqlite) outputs into small text files under profiles/.
+"""Summarise rocprofv3 (rocpd sqlite) outputs into small text files.
 
-usage: summarize_prof.py <round-tag> <kernel-trace.db> [<pmc FETCH_SIZE .db> <pmc WRITE_SIZE .db>]
-"""
+usage: summarize_prof.py <out-prefix> <kernel-trace.db> [--fetch <pmc FETCH_SIZE .db>] [--write <pmc WRITE_SIZE .db>] [--bench <bench json>]
+
+Writes <out-prefix>_kernel_stats.csv (top kernels), <out-prefix>_conv_slots.csv (per launch slot of the fused TP conv inside one
+dp_forward: duration, and - with --bench, which carries the edge counts of the benched batch - algorithmic TFLOP/s by SURVEY.md 8d's
+edge-side count) and, with the PMC passes, <out-prefix>_conv_hbm_traffic.csv plus one JSON record for profiles/conv_hbm_traffic.json."""
+import argparse
 import collections
+import json
 import sqlite3
-import sys
 
-CONV_SLOTS = {  # launch order of the tensor-product convs inside one dp_forward, per kernel instantiation
-    "tp_conv_kernel<0>": ["lig-lig", "phore->lig", "phore->lig(norm)", "phore-phore", "lig->phore", "lig->phore(norm)"],
-    "tp_conv_kernel<1>": ["lig-lig", "phore->lig", "phore->lig(norm)", "phore-phore", "lig->phore", "lig->phore(norm)"],
-    "tp_conv_kernel<2>": ["lig-lig", "phore->lig", "phore->lig(norm)", "phore-phore", "lig->phore", "lig->phore(norm)"],
-    "tp_conv_kernel<3>": ["lig-lig", "phore->lig", "phore->lig(norm)"],
-    "tp_conv_kernel<4>": ["centre (final_conv)"],
-    "tp_conv_kernel<5>": ["torsion bonds (tor_bond_conv)"],
-}
+# launch order of the convs of one kernel instantiation inside one dp_forward (dp_graph.hip)
+EDGE_ALL = ["lig-lig", "phore->lig", "phore->lig(norm)", "phore-phore", "lig->phore", "lig->phore(norm)"]
+SLOTS = {}
+for k in range(4):
+    SLOTS[f"tp_conv_node_kernel<{k}, 4>"] = ["lig-lig"]
+    SLOTS[f"tp_conv_node_kernel<{k}, 1>"] = ["phore->lig", "phore->lig(norm)"]
+    SLOTS[f"tp_conv_node_kernel<{k}, 2>"] = ["lig->phore", "lig->phore(norm)"]
+SLOTS["tp_conv_kernel<4>"] = ["centre (final_conv)"]
+SLOTS["tp_conv_kernel<5>"] = ["torsion bonds (tor_bond_conv)"]
+FLOPS = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400}     # SURVEY.md 8d per edge-conv (edge-side count)
+EDGE_SET = {"lig-lig": "ll", "phore-phore": "pp", "phore->lig": "x", "phore->lig(norm)": "x", "lig->phore": "x", "lig->phore(norm)": "x"}
 
 
 def short(name):
-    name = name.replace("void ", "").replace("dp::", "")
+    name = name.replace("void ", "").replace("dp::", "").replace("dpn::", "")
     return name.split("(")[0][:60]
 
 
-def _has(cur, name):
-    return bool(list(cur.execute("select name from sqlite_master where name=?", (name,))))
+def slot_names(kernels_seen):
+    """edge-side layer kernels: all six slots when the node-side kernel is absent, only phore-phore (and lig-lig when that ran
+    edge-side) otherwise"""
+    s = dict(SLOTS)
+    node = any("tp_conv_node_kernel" in k for k in kernels_seen)
+    node_ll = any("tp_conv_node_kernel" in k and ", 4>" in k for k in kernels_seen)
+    for k in range(4):
+        n = f"tp_conv_kernel<{k}>"
+        if not node:
+            s[n] = EDGE_ALL if k < 3 else EDGE_ALL[:3]
+        elif node_ll:
+            s[n] = ["phore-phore"]
+        else:
+            s[n] = ["lig-lig", "phore-phore"] if k < 3 else ["lig-lig"]
+    return s
 
 
 def main():
-    tag, trace = sys.argv[1], sys.argv[2]
-    con = sqlite3.connect(trace)
-    cur = con.cursor()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("prefix")
+    ap.add_argument("trace")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--bench")
+    ap.add_argument("--command", default="")
+    a = ap.parse_args()
+    cur = sqlite3.connect(a.trace).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    out = [f"# rocprofv3 --kernel-trace --stats summary ({tag}); durations in microseconds",
-           "# command: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-alt --steps 20 --warmup 3",
-           "kernel,calls,total_us,avg_us,percent"]
-    for n, c, t, a, p in rows:
-        if p < 0.001:
-            continue
-        out.append(f"\"{short(n)}\",{c},{t:.1f},{a:.2f},{p:.3f}")
-    open(f"profiles/{tag}_kernel_stats.csv", "w").write("\n".join(out) + "\n")
+    out = [f"# rocprofv3 --kernel-trace --stats summary; durations in microseconds", f"# command: {a.command}", "kernel,calls,total_us,avg_us,percent"]
+    for n, c, t, av, p in rows:
+        if p >= 0.001:
+            out.append(f"\"{short(n)}\",{c},{t:.1f},{av:.2f},{p:.3f}")
+    open(f"{a.prefix}_kernel_stats.csv", "w").write("\n".join(out) + "\n")
 
-    cols = [d[0] for d in cur.execute("select * from kernels limit 1").description] if _has(cur, "kernels") else []
+    cols = [d[0] for d in cur.execute("select * from kernels limit 1").description]
     namecol = "name" if "name" in cols else "kernel_name"
-    disp = list(cur.execute(f"select {namecol}, start, end from kernels order by start")) if cols else []
-    lines = [f"# per-launch-slot durations of the fused TP conv ({tag}); slot = position inside one dp_forward",
-             "kernel,slot,launches,avg_us,min_us,max_us"]
+    disp = [(short(n), s, e) for n, s, e in cur.execute(f"select {namecol}, start, end from kernels order by start")]
+    slots = slot_names({n for n, _, _ in disp})
+    bench = json.load(open(a.bench)) if a.bench else None
+    edges = (bench or {}).get("config", {}).get("edge_counts", {})
     per = collections.defaultdict(list)
     for n, s, e in disp:
-        for k in CONV_SLOTS:
-            if k in n:
-                per[k].append((e - s) / 1e3)
-    for k, durs in per.items():
-        slots = CONV_SLOTS[k]
-        for i, sname in enumerate(slots):
-            d = durs[i::len(slots)]
-            if d:
-                lines.append(f"{k},{sname},{len(d)},{sum(d) / len(d):.2f},{min(d):.2f},{max(d):.2f}")
-    open(f"profiles/{tag}_conv_slots.csv", "w").write("\n".join(lines) + "\n")
+        if n in slots:
+            per[n].append((e - s) / 1e3)
+    lines = ["# per-launch-slot durations of the fused TP conv; slot = position inside one dp_forward; TFLOP/s = SURVEY.md 8d's edge-side",
+             "# algorithmic flops (2*(60*60+60*numel)+TP per edge-conv) x edges of the slot's edge set / duration - the node-side kernel executes",
+             f"# ~3.5x fewer flops for the same result (DESIGN.md 5).  edge counts of the benched batch: {edges}", f"# command: {a.command}",
+             "kernel,slot,launches,avg_us,min_us,max_us,alg_TFLOPs"]
+    for k in sorted(per):
+        names = slots[k]
+        kind = int(k.split("<")[1][0])
+        for i, sname in enumerate(names):
+            d = per[k][i::len(names)]
+            if not d:
+                continue
+            avg = sum(d) / len(d)
+            tf = ""
+            if kind in FLOPS and EDGE_SET.get(sname) in edges:
+                tf = f"{FLOPS[kind] * edges[EDGE_SET[sname]] / (avg * 1e-6) / 1e12:.1f}"
+            lines.append(f"{k},{sname},{len(d)},{avg:.2f},{min(d):.2f},{max(d):.2f},{tf}")
+    open(f"{a.prefix}_conv_slots.csv", "w").write("\n".join(lines) + "\n")
 
-    if len(sys.argv) >= 5:
+    if a.fetch and a.write:
         res = ["# HBM traffic counters per launch slot (separate --pmc passes), KiB as reported by rocprofv3",
                "# FETCH_SIZE on gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section): 'hbm_read_MiB' doubles it",
                "kernel,slot,launches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_read_MiB_corrected,hbm_write_MiB"]
         vals = {}
-        for cname, db in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
+        for cname, db in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
             c2 = sqlite3.connect(db).cursor()
-            rr = list(c2.execute("select kernel_name, start, value from counters_collection where counter_name=? order by start", (cname,)))
-            per = collections.defaultdict(list)
-            for n, s, v in rr:
-                for k in CONV_SLOTS:
-                    if k in n:
-                        per[k].append(v)
-            vals[cname] = per
-        for k in CONV_SLOTS:
-            slots = CONV_SLOTS[k]
-            for i, sname in enumerate(slots):
-                f = vals["FETCH_SIZE"].get(k, [])[i::len(slots)]
-                w = vals["WRITE_SIZE"].get(k, [])[i::len(slots)]
+            pr = collections.defaultdict(list)
+            for n, s, v in c2.execute("select kernel_name, start, value from counters_collection where counter_name=? order by start", (cname,)):
+                if short(n) in slots:
+                    pr[short(n)].append(v)
+            vals[cname] = pr
+        rec = None
+        for k in sorted(slots):
+            names = slots[k]
+            for i, sname in enumerate(names):
+                f = vals["FETCH_SIZE"].get(k, [])[i::len(names)]
+                w = vals["WRITE_SIZE"].get(k, [])[i::len(names)]
                 if f and w:
                     fa, wa = sum(f) / len(f), sum(w) / len(w)
                     res.append(f"{k},{sname},{len(f)},{fa:.1f},{wa:.1f},{2 * fa / 1024:.2f},{wa / 1024:.2f}")
-        open(f"profiles/{tag}_conv_hbm_traffic.csv", "w").write("\n".join(res) + "\n")
+                    if k.startswith(("tp_conv_node_kernel<2, 1>", "tp_conv_kernel<2>")) and sname == "phore->lig":
+                        rec = int((2 * fa + wa) * 1024)
+        open(f"{a.prefix}_conv_hbm_traffic.csv", "w").write("\n".join(res) + "\n")
+        if rec is not None and bench is not None:
+            import os
+            import sys
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+            import bench as benchmod
+            json.dump({"source_hash": benchmod.kernel_source_hash(), "config": 2, "poses": bench["config"]["poses_per_gpu"],
+                       "precision": bench["config"]["precision"], "conv_algo": bench["config"]["conv_algo"], "traffic_bytes": rec,
+                       "profile": os.path.basename(a.prefix) + "_conv_hbm_traffic.csv"}, open(f"{a.prefix}_traffic_record.json", "w"))
 
 
 if __name__ == "__main__":
