@@ -35,6 +35,11 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_EDGE = {0: 2516, 1: 4636, 2: 6756, 3: 9236}      # 4*(numel + D_in + 9) per edge-conv, fp32
 ALG_FLOPS_PER_EDGE = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400}   # radial-MLP GEMM + TP
+# node-side formulation: per EDGE 2*61*(60 + C) flop (radial layer 1 + GEMM-A over C = sum_p mul_in*d_out columns),
+# per scatter NODE 2*61*W flop (GEMM-B, W = sum_p mul_in*mul_out*d_out); no padding counted
+NODE_COLS = {0: 80, 1: 180, 2: 280, 3: 360}
+NODE_W = {0: 1000, 1: 2100, 2: 3200, 3: 4200}
+NODE_MFMA_PER_WAVE = {0: 512 + 6 * 128 + 400, 1: 512 + 13 * 128 + 840, 2: 512 + 20 * 128 + 1280, 3: 512 + 26 * 128 + 1680}   # issued per 32-edge pass
 MFMA_F32_PEAK_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 PROF_LAYER, PROF_CONV = 2, 1                                     # layer-2 phore->ligand conv: dense cross edge set
@@ -331,7 +336,7 @@ def main():
         del copy
 
     n_x = int(pb.x_ptr[-1])
-    _ws = Engine(model, pb).ws        # one forward's lig-lig edge count (the radius graph depends on the poses)
+    # one forward's lig-lig edge count (the radius graph depends on the poses)
     edge_counts = {"x": n_x, "pp": int(pb.pp_ptr[-1])}
     try:
         _e = Engine(model, pb)
@@ -340,9 +345,21 @@ def main():
         del _e
     except Exception:      # noqa: BLE001 - informational only
         pass
-    del _ws
     alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
     flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * n_x
+    if algo_used == "node":
+        n_nodes = int(pb.lig_ptr[-1])                      # scatter nodes of the phore->ligand conv = ligand atoms
+        rf_flops = n_x * 2 * 61 * (60 + NODE_COLS[PROF_LAYER]) + n_nodes * 2 * 61 * NODE_W[PROF_LAYER]
+        rf_note = ("node-side formulation: 2*61*(60+280) flop per edge (radial layer 1 + GEMM-A) + 2*61*3200 flop per scatter node (GEMM-B), "
+                   "DESIGN.md 5; the edge-side count of SURVEY.md 8d is reported beside it")
+        groups = int(sum((int(pb.nl[i]) + 15) // 16 for i in range(B)))      # workgroups: 16-node groups, one 32-edge pass each at NP <= 32
+        passes = int(sum(((int(pb.nl[i]) + 15) // 16) * ((int(pb.np_[i]) + 31) // 32) for i in range(B)))
+        issued = passes * 4 * NODE_MFMA_PER_WAVE[PROF_LAYER] * 2048.0
+        rf_issue = {"executed_flops_per_launch": issued, "achieved": issued / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
+                    "frac": issued / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None, "workgroups": groups,
+                    "note": "fp32 MFMA flops actually issued (v_mfma_f32_16x16x4_f32, padding included) / launch time = matrix-pipe occupancy"}
+    else:
+        rf_flops, rf_note, rf_issue = flops, "SURVEY.md 8d: 2*(60*60+60*numel)+TP flop per edge-conv (edge-side formulation)", None
     traffic, traffic_src = measured_traffic(a.config, B, precision, algo_used) if world == 1 else (None, None)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else float("nan")
 
@@ -368,9 +385,15 @@ def main():
             # alg_flops_per_edge is the EDGE-SIDE count of SURVEY.md 8d (radial GEMM per edge); the node-side formulation computes
             # the same result with fewer flops, so its `frac` under this count can exceed what the pipe could
             # deliver for the edge-side form - `executed_flops_per_edge` is what that launch really issues.
-            "roofline": {"bound": "mfma", "achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
+            "roofline": {"bound": "mfma", "achieved": rf_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None,
+                         "frac": rf_flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None,
+                         "alg_flops_per_launch": rf_flops, "flop_count": rf_note,
+                         "edge_side_count": {"achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
+                                             "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None,
+                                             "note": "SURVEY.md 8d's per-edge count (radial GEMM per edge) x edges / launch time: what an edge-side "
+                                                     "kernel would have to sustain for this launch time; > 1 is possible for the node-side form"},
+                         "mfma_issue": rf_issue,
                          "traffic": traffic,
                          "kernel": f"fused TP conv, layer-2 phore->ligand launch (dense cross edges), conv_algo={algo_used}, precision={precision}",
                          "kernel_ms": kern_ms, "edges_per_launch": n_x,
