@@ -51,6 +51,10 @@ typedef NProf NProfT;
 typedef int NProfT;
 #endif
 
+#ifndef DP_NABL    // ablation builds (tools/ablate_node.sh): 1 no sh factors / z arithmetic, 2 no T transpose through LDS, 3 no GEMM-B MFMAs,
+#define DP_NABL 0  // 4 no GEMM-B at all, 5 no GEMM-A MFMAs, 6 no GEMM1 MFMAs.  Results are wrong by construction; timing only.
+#endif
+
 namespace dpn {
 using namespace dp;
 
@@ -291,7 +295,7 @@ struct PathStage {
         // the MFMA / VALU interleave inside a step, sched_barrier keeps steps apart (hoisting all LDS reads together spills).
         // Lanes of the unused 16th column store into a per-wave dummy slot instead of being masked off (no exec juggling).
         const int twr = c < TCOLS ? c * (NB * 16) : TCOLS * (NB * 16);
-        if constexpr (needs_s<ZT>()) {
+        if constexpr (needs_s<ZT>() && DP_NABL != 1) {
           const char* sbase = reinterpret_cast<const char*>(sS);
           auto loadS = [&](int qs, f32x4 (&sv)[NTERM]) {
 #pragma unroll
@@ -322,9 +326,19 @@ struct PathStage {
             if (qs + 1 < 2 * NB) makeZ((qs + 1) & 1, sv_nxt, z_nxt);
             if (t2 == 0) D[nn & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) D[nn & 1] = mfma16(hid[nn][4 * t2 + rr], z_cur[rr], D[nn & 1]);
+            for (int rr = 0; rr < 4; ++rr) {
+#if DP_NABL == 5
+              asm volatile("" ::"v"(z_cur[rr]), "v"(hid[nn][4 * t2 + rr]));
+#else
+              D[nn & 1] = mfma16(hid[nn][4 * t2 + rr], z_cur[rr], D[nn & 1]);
+#endif
+            }
             // the finished tile of the PREVIOUS node is stored one step late, behind this step's MFMAs: its last MFMA has long retired
+#if DP_NABL == 2
+            if (t2 == 0 && nn > 0) asm volatile("" ::"v"(D[(nn - 1) & 1]));
+#else
             if (t2 == 0 && nn > 0) *reinterpret_cast<f32x4*>(tslot(nn - 1)) = D[(nn - 1) & 1];
+#endif
             if (qs + 2 < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, NTERM, 0);       // the prefetch reads go first
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -337,7 +351,11 @@ struct PathStage {
 #pragma unroll
             for (int t = 0; t < NTERM; ++t) sv_nxt[t] = sv_nn[t];
           }
+#if DP_NABL == 2
+          asm volatile("" ::"v"(D[(NB - 1) & 1]));
+#else
           *reinterpret_cast<f32x4*>(tslot(NB - 1)) = D[(NB - 1) & 1];
+#endif
           __builtin_amdgcn_sched_barrier(0);
         } else {
           // z is the gathered input itself (sh_0 = 1): nothing to fetch or compute per node
@@ -345,13 +363,29 @@ struct PathStage {
           for (int nn = 0; nn < NB; ++nn) {
             f32x4 D = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) D = mfma16(hid[nn][j], xa[0][j], D);
+            for (int j = 0; j < 8; ++j) {
+#if DP_NABL == 5
+              asm volatile("" ::"v"(xa[0][j]), "v"(hid[nn][j]));
+#else
+              D = mfma16(hid[nn][j], xa[0][j], D);
+#endif
+            }
+#if DP_NABL == 2
+            asm volatile("" ::"v"(D));
+#else
             *reinterpret_cast<f32x4*>(sT + twr + (c < TCOLS ? ((((nn << 2) | g) ^ (c & 7)) << 2) : (g << 2))) = D;
+#endif
             __builtin_amdgcn_sched_barrier(0);
           }
         }
         NPROF(2);
+        __builtin_amdgcn_s_setprio(1);      // a wave in its (VALU-free) GEMM-B goes first: -3.4 % measured against no priority
         // ---- GEMM-B: out[w][node] += W2[w][(u,k)] T[(u,k)][node] -------------------------------------------------------------
+#if DP_NABL == 4
+        if (ut + 1 < pc.mul_in / NU) load_x<KIND, MODE, P>(a, r, et, lane_l, ut + 1, xr);
+        else load_x<KIND, MODE, P + 1>(a, r, et, lane_l, 0, xr);
+        if (false)
+#endif
         {
           const float* wsrc = a.w2n + w2n_path_off<KIND>(P) + (size_t)(ut * MT) * w2n_tile_floats<KIND>(P) + (size_t)(q * 64 + lane_l) * STEPS;
           f32x4 wf[MT], wn[MT];
@@ -361,7 +395,11 @@ struct PathStage {
           // in-channel's fragment (L2) and the next step's T fragment (LDS) are requested before the current ones are consumed
           auto readT = [&](int st) {
             const int col = (VEC ? 5 * (st % NG) : 0) + st / NG;
+#if DP_NABL == 2
+            return f32x4{(float)col, xr[0][0], xr[0][1], xr[0][2]};
+#else
             return *reinterpret_cast<const f32x4*>(sT + (size_t)col * (NB * 16) + ((lane_slot ^ (col & 7)) << 2));
+#endif
           };
           f32x4 tv = readT(0), tn;
 #pragma unroll
@@ -381,7 +419,13 @@ struct PathStage {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) acc[AB + grp * MT + mt] = mfma16(wf[mt][rr], tv[rr], acc[AB + grp * MT + mt]);
+              for (int mt = 0; mt < MT; ++mt) {
+#if DP_NABL == 3
+                asm volatile("" ::"v"(wf[mt][rr]), "v"(tv[rr]));
+#else
+                acc[AB + grp * MT + mt] = mfma16(wf[mt][rr], tv[rr], acc[AB + grp * MT + mt]);
+#endif
+              }
             __builtin_amdgcn_sched_barrier(0);
             tv = tn;
             if (grp == NG - 1) {
@@ -390,6 +434,7 @@ struct PathStage {
             }
           }
         }
+        __builtin_amdgcn_s_setprio(0);
         NPROF(3);
       }
       PathStage<KIND, MODE, P + 1>::run(a, r, et, q, lane, hid, sT, sS, acc, xr, prof_prev);
@@ -427,6 +472,10 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
   using S = Spec<KIND>;
   __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE];              // wave-private T tiles (+ a dummy slot); reused for the final reduction
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];         // per-edge sh factors of the current pass
+#if DP_NABL == 7                                                                // one workgroup per CU (a single wave per SIMD)
+  __shared__ float s_pad[2048];
+  if (threadIdx.x == 1023) s_pad[threadIdx.x] = 0.f;
+#endif
   static_assert(4 * NB * S::D_OUT <= 4 * TSTRIDE, "reduction scratch fits in the T buffers");
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
   const Wg r = wg_of<MODE>(a);
@@ -513,14 +562,19 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
     auto gemm1 = [&](const f4u (&v4)[3], const float (&v1)[3], float one) {
       f32x4 D = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int b3 = 0; b3 < 3; ++b3) {
+      for (int b3 = 0; b3 < (DP_NABL == 6 ? 0 : 3); ++b3) {
         D = mfma16(v4[b3].x, w1[5 * b3 + 0], D);
         D = mfma16(v4[b3].y, w1[5 * b3 + 1], D);
         D = mfma16(v4[b3].z, w1[5 * b3 + 2], D);
         D = mfma16(v4[b3].w, w1[5 * b3 + 3], D);
         D = mfma16(v1[b3], w1[5 * b3 + 4], D);
       }
+#if DP_NABL == 6
+      D[0] = v1[0] + one; D[1] = v1[1]; D[2] = v1[2]; D[3] = v4[0].x;
+      return D;
+#else
       return mfma16(one, w1[15], D);
+#endif
     };
     f4u a4[3], b4[3], n4[3];
     float a1[3], b1[3], n1[3], ao, bo, no;
@@ -541,17 +595,22 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
       ao = bo; bo = no;
     }
     if constexpr (MODE == LL) {
-      // second GEMM1 over the bond edges of the same pairs (1-4 per atom): skipped per 16-pair tile when none of them is bonded
+      // second GEMM1 over the bond edges of the same pairs (1-4 per atom): skipped per 16-pair tile when none of them is bonded;
+      // the operands of step + 1 are requested before step's MFMAs
+      load_av(0, a4, a1, ao, 1);
 #pragma unroll
       for (int step = 0; step < 2 * NB; ++step) {
         const int nn = step >> 1, t2 = step & 1;
-        load_av(step, a4, a1, ao, 1);
+        if (step + 1 < 2 * NB) load_av(step + 1, n4, n1, no, 1);
         if (__builtin_amdgcn_ballot_w64(ao != 0.f) != 0) {       // lane group 0 carries the validity of the tile's 16 pairs
           const f32x4 D = gemm1(a4, a1, ao);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] += fmaxf(D[rr], 0.f);
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b3 = 0; b3 < 3; ++b3) { a4[b3] = n4[b3]; a1[b3] = n1[b3]; }
+        ao = no;
       }
     }
     NPROF(1);
