@@ -63,12 +63,12 @@ def _noisy_steps(inference_steps, ode, no_random, no_final_step_noise):
 
 
 def _host_stage(part, device, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise,
-                randomize=None):
-    """Everything that needs no device: pack the graphs, draw the start randomisation (if asked) and then the run's normals - the
-    reference's order for one complex: randomize_position(...) first, sampling_phore(...) after - and tabulate the times."""
+                randomize=None, rz=None):
+    """Everything that needs no device: pack the graphs, draw the start randomisation (if asked and not pre-drawn: `rz`) and then the
+    run's normals - the reference's order for one complex: randomize_position(...) first, sampling_phore(...) after - and tabulate the
+    times."""
     pb = PackedBatch(part, device, upload=False)
-    rz = None
-    if randomize is not None:
+    if randomize is not None and rz is None:
         rz = _randomize_draws(part, pb.nt, randomize["no_torsion"], randomize["no_random"], randomize["tr_sigma_max"],
                               randomize.get("keep_update", False), randomize.get("draws"))
     return _host_stage_noise_only(pb, len(part), inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random,
@@ -161,20 +161,41 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
         return data_list, None
     if N > max_poses and visualization_list is not None:
         raise NotImplementedError("visualization_list with more than max_poses poses")
-    # Device-batch the pose list (`max_poses` per batch).  Poses are independent, so results do not depend on the batching; with
-    # noise=None the global RNG stream is consumed batch-major instead of step-major when there is more than one batch (the
-    # reference never runs more than `--sample_per_complex` poses at once).  The host stage of batch k+1 (packing, noise) runs
+    # Device-batch the pose list (`max_poses` per batch).  Poses are independent, so results do not depend on the batching.  With more
+    # than one batch and noise=None the global generators are still consumed in the reference's order for the WHOLE list - start
+    # randomisation of every pose first, then step-major normals per `batch_size` chunk - by drawing everything before the first batch
+    # (S x N x (6 + T) floats on the host); the batches then take their slices.  The host stage of batch k+1 (packing, uploads) runs
     # while the GPU works on batch k: the step loop is enqueued without any host synchronisation.
-    parts, subs, t_off = [], [], 0
+    rz_all = None
+    if N > max_poses and noise is None:
+        nt_all = np.asarray([int(torch.as_tensor(g["ligand"].edge_mask).sum()) for g in data_list], dtype=np.int64)
+        if randomize is not None:
+            rz_all = _randomize_draws(data_list, nt_all, randomize["no_torsion"], randomize["no_random"], randomize["tr_sigma_max"],
+                                      randomize.get("keep_update", False), randomize.get("draws"))
+        steps = _noisy_steps(inference_steps, ode, no_random, no_final_step_noise)
+        if steps:
+            d = [_draw_reference_order(N, nt_all, batch_size) for _ in steps]
+            noise = {k: torch.zeros((inference_steps,) + tuple(d[0][i].shape)) for i, k in enumerate(("tr", "rot", "tor"))}
+            for t, dd in zip(steps, d):
+                for i, k in enumerate(("tr", "rot", "tor")):
+                    noise[k][t] = dd[i]
+    parts, subs, rzs, t_off = [], [], [], 0
     for lo in range(0, N, max_poses):
         part = data_list[lo:lo + max_poses]
-        nt_part = sum(int(torch.as_tensor(g["ligand"].edge_mask).sum()) for g in part) if (noise is not None and N > max_poses) else 0
+        need = N > max_poses and (noise is not None or rz_all is not None)
+        nt_part = sum(int(torch.as_tensor(g["ligand"].edge_mask).sum()) for g in part) if need else 0
         subs.append(noise if (noise is None or N <= max_poses) else
                     {"tr": noise["tr"][:, lo:lo + max_poses], "rot": noise["rot"][:, lo:lo + max_poses], "tor": noise["tor"][:, t_off:t_off + nt_part]})
+        if rz_all is not None:
+            th, rm, tr = rz_all
+            rzs.append((th[t_off:t_off + nt_part].contiguous() if (th is not None and nt_part) else None, rm[lo:lo + max_poses].contiguous(),
+                        tr[lo:lo + max_poses].contiguous() if tr is not None else None))
+        else:
+            rzs.append(None)
         parts.append(part)
         t_off += nt_part
     _t0 = _time.time()
-    stage = _host_stage(parts[0], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[0], randomize)
+    stage = _host_stage(parts[0], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[0], randomize, rzs[0])
     for k, part in enumerate(parts):
         pb, Z, T_all, rz = stage
         pb.upload()
@@ -186,7 +207,7 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             timing["pack_and_noise_s"] = _time.time() - _t0
             _t0 = _time.time()
         _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list)
-        stage = (_host_stage(parts[k + 1], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[k + 1], randomize)
+        stage = (_host_stage(parts[k + 1], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[k + 1], randomize, rzs[k + 1])
                  if k + 1 < len(parts) else None)
         if timing is not None and k == len(parts) - 1:
             torch.cuda.synchronize()

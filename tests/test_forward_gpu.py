@@ -307,6 +307,32 @@ def test_sampler_chunking_and_keep_update():
         np.testing.assert_array_equal(x.docked_poses[-1], x["ligand"].pos.numpy())
 
 
+def test_sampler_chunking_keeps_the_reference_rng_order():
+    """noise=None with more poses than max_poses: the global generators (np.random for the torsion randomisation, scipy's R.random,
+    torch for translations and step normals) are consumed in the reference's order for the whole list - randomisation of every pose,
+    then step-major normals per batch_size chunk - whatever the device batching (sampling.py:16-63, :230-243)."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+    gs = synthetic.synthetic_pairs(101, 7, (10, 18), (0, 4), (8, 16))
+    S = 3
+    sched = get_t_schedule(S)
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+    rz = dict(no_torsion=False, no_random=False, tr_sigma_max=cfg.tr_sigma_max)
+    outs = []
+    for mp in (8192, 3):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        o, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, batch_size=4,
+                              max_poses=mp, randomize=rz)
+        outs.append(o)
+    for x, y in zip(*outs):
+        assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
+
+
 def test_fit_complexes_driver_single_rank():
     """inference.py::fit's sampler-facing loop: N samples per complex, randomised start, poses returned per complex."""
     from diffphore_amd.distributed import fit_complexes
