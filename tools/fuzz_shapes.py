@@ -15,8 +15,15 @@ from oracle.tables import load_tables
 
 
 def rel(a, b):
+    """max |a - b| / max |b| over the entries where the oracle is finite; inf when the NaN patterns differ (a degenerate pose - e.g. a
+    pharmacophore of <= 6 nodes without phore-phore edges - is NaN in the reference arithmetic too: both sides must agree on it)."""
     a, b = a.double().cpu(), b.double().cpu()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    if not torch.equal(torch.isnan(a), torch.isnan(b)):
+        return float("inf")
+    ok = ~torch.isnan(b)
+    if not bool(ok.any()):
+        return 0.0
+    return float((a[ok] - b[ok]).abs().max() / b[ok].abs().max().clamp_min(1e-30))
 
 
 def main():
