@@ -63,7 +63,11 @@ def measured_traffic(config, poses, precision, conv_algo):
     except (OSError, ValueError):
         return None, None
     src = kernel_source_hash()
+    if isinstance(recs, dict):
+        recs = [recs]
     for r in recs:
+        if not isinstance(r, dict):
+            continue
         if (r.get("source_hash") == src and r.get("config") == config and r.get("poses") == poses and r.get("precision") == precision
                 and r.get("conv_algo", "edge") == conv_algo):
             return int(r["traffic_bytes"]), r.get("profile")

@@ -522,19 +522,56 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
     NPROF(0);
 
     // ---- GEMM1: hidden rows 16q..16q+15 of the 32 edges of every node of the batch ---------------------------------------------
+    // attr = [edge_emb | attr1[:20] | attr2[:20]] and two of the three blocks belong to NODES, not edges: the scatter node's block is the
+    // same for all of its edges and the gather node's block the same for every scatter node.  So the first layer is split
+    //     pre[e] = W1_emb emb[e]  +  u_s[scatter(e)]  +  u_g[gather(e)],     u_s = W1_s attr_s + b,   u_g = W1_g attr_g
+    // with u_s / u_g evaluated once per pass as three 16-row MFMA tiles (rows = nodes) and the per-edge part shrinking from 16 K-steps
+    // to 5 (+ 1 mask step).  u_g comes out of the MFMA in exactly the D-fragment layout of the edge tiles (rows = the pass's gather
+    // nodes = its edge slots), u_s is broadcast over rows through 1 KiB of the (idle) T buffer.
     float hid[NB][8];
     float w1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) w1[s] = a.w1n[(q * 16 + s) * 64 + lane];
-    // attr operands of one (node, 16-edge tile): five consecutive floats of [edge_emb | attr1[:20] | attr2[:20]] per lane group;
-    // the loads of step i + 1 are issued before the MFMAs of step i (steps = 16 nodes x 2 tiles)
-    // An edge that does not exist (e >= En, or no radius / bond edge for the pair) gets an all-zero A operand INCLUDING the bias step's
-    // 1.0: its pre-activation is 0, so its hidden vector - constant-one unit included - is exactly 0 and it drops out of T.
-    auto load_av = [&](int step, f4u (&v4)[3], float (&v1)[3], float& one, int which) {
+    constexpr int SBLK = MODE == DP_EDGES_L2P ? 2 : 1, GBLK = MODE == DP_EDGES_L2P ? 1 : 2;      // attr block of the scatter / gather node
+    const float* s_tab = MODE == DP_EDGES_L2P ? a.attr2_tab : a.attr1_tab;
+    const float* g_tab = MODE == DP_EDGES_L2P ? a.attr1_tab : a.attr2_tab;
+    const int s_stride = MODE == DP_EDGES_L2P ? a.attr2_stride : a.attr1_stride, g_stride = MODE == DP_EDGES_L2P ? a.attr1_stride : a.attr2_stride;
+    auto node_tile = [&](const float* rowp, int blk, bool bias) {
+      const f4u v4 = *reinterpret_cast<const f4u*>(rowp + 5 * g);
+      const float v1 = rowp[5 * g + 4];
+      f32x4 D = {0.f, 0.f, 0.f, 0.f};
+      D = mfma16(v4.x, w1[5 * blk + 0], D);
+      D = mfma16(v4.y, w1[5 * blk + 1], D);
+      D = mfma16(v4.z, w1[5 * blk + 2], D);
+      D = mfma16(v4.w, w1[5 * blk + 3], D);
+      D = mfma16(v1, w1[5 * blk + 4], D);
+      if (bias) D = mfma16(g == 0 ? 1.f : 0.f, w1[15], D);
+      return D;
+    };
+    f32x4 ug[2];                                               // u_g of the pass's 32 edge slots: register rr <-> slot 16 t2 + 4 g + rr
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int e0 = 32 * et + 16 * t2 + c;
+      const int grow = (MODE == DP_EDGES_P2L ? r.p0 : r.l0) + (e0 < r.En ? e0 : 0);
+      ug[t2] = node_tile(g_tab + (size_t)grow * g_stride, GBLK, false);
+    }
+    {
+      const int srow = r.n_lo + (c < r.n_loc ? c : 0);
+      const f32x4 us = node_tile(s_tab + (size_t)srow * s_stride, SBLK, true);            // + fc.0 bias (and the constant-one unit)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) sT[(4 * g + rr) * 16 + c] = us[rr];                   // [node][k]: read back as a broadcast over rows
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // edge part: five consecutive floats of edge_emb per lane group; the loads of step i + 2 are issued before the MFMAs of step i
+    // (steps = 16 nodes x 2 tiles).  An edge that does not exist (e >= En, or no radius / bond edge for the pair) gets -1e30 added to
+    // every pre-activation by the mask step (A = -1e30 in lane group 0, B = ones): its hidden vector - constant-one unit included -
+    // is exactly 0 and it drops out of T.
+    const float bone = g == 0 ? 1.f : 0.f;
+    auto load_av = [&](int step, f4u& v4, float& v1, float& msk, int which) {
       int nn_o = step >> 1;                          // opaque copy: keeps the 16 nodes' row pointers from being hoisted out of the pass loop (spills)
       asm volatile("" : "+s"(nn_o));
       const int node = r.n_lo + (nn_o < r.n_loc ? nn_o : 0);
-      const int e0 = 32 * et + 16 * (step & 1) + c;  // GEMM1 view: lane (g, c) feeds attr[edge c][group g]
+      const int e0 = 32 * et + 16 * (step & 1) + c;  // GEMM1 view: lane (g, c) feeds emb[edge c][group g]
       bool ok = e0 < r.En;
       const int e = ok ? e0 : 0;
       int frow;
@@ -546,71 +583,63 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
         frow = feat_row<MODE>(r, node, e);
       }
       const float* pe = a.edge_emb + (size_t)frow * 20 + 5 * g;
-      const int r1 = MODE == DP_EDGES_L2P ? r.l0 + e : node, r2 = MODE == DP_EDGES_P2L ? r.p0 + e : (MODE == LL ? r.l0 + e : node);
-      const float* p1 = a.attr1_tab + (size_t)r1 * a.attr1_stride + 5 * g;
-      const float* p2 = a.attr2_tab + (size_t)r2 * a.attr2_stride + 5 * g;
-      const f4u z4 = {0.f, 0.f, 0.f, 0.f};
-      v4[0] = *reinterpret_cast<const f4u*>(pe); v1[0] = pe[4];
-      v4[1] = *reinterpret_cast<const f4u*>(p1); v1[1] = p1[4];
-      v4[2] = *reinterpret_cast<const f4u*>(p2); v1[2] = p2[4];
-      if (!ok) {
-#pragma unroll
-        for (int b3 = 0; b3 < 3; ++b3) { v4[b3] = z4; v1[b3] = 0.f; }
-      }
-      one = (ok && g == 0) ? 1.f : 0.f;
+      v4 = *reinterpret_cast<const f4u*>(pe);
+      v1 = pe[4];
+      msk = (!ok && g == 0) ? -1e30f : 0.f;
     };
-    auto gemm1 = [&](const f4u (&v4)[3], const float (&v1)[3], float one) {
-      f32x4 D = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int b3 = 0; b3 < (DP_NABL == 6 ? 0 : 3); ++b3) {
-        D = mfma16(v4[b3].x, w1[5 * b3 + 0], D);
-        D = mfma16(v4[b3].y, w1[5 * b3 + 1], D);
-        D = mfma16(v4[b3].z, w1[5 * b3 + 2], D);
-        D = mfma16(v4[b3].w, w1[5 * b3 + 3], D);
-        D = mfma16(v1[b3], w1[5 * b3 + 4], D);
-      }
-#if DP_NABL == 6
-      D[0] = v1[0] + one; D[1] = v1[1]; D[2] = v1[2]; D[3] = v4[0].x;
-      return D;
+    auto gemm1 = [&](const f4u& v4, float v1, float msk, float usn, const f32x4& ugt) {
+      f32x4 D = {usn + ugt[0], usn + ugt[1], usn + ugt[2], usn + ugt[3]};
+#if DP_NABL != 6
+      D = mfma16(v4.x, w1[0], D);
+      D = mfma16(v4.y, w1[1], D);
+      D = mfma16(v4.z, w1[2], D);
+      D = mfma16(v4.w, w1[3], D);
+      D = mfma16(v1, w1[4], D);
+      D = mfma16(msk, bone, D);
 #else
-      return mfma16(one, w1[15], D);
+      D[0] += v4.x + msk; D[1] += v4.y; D[2] += v4.z; D[3] += v4.w + v1;
 #endif
+      return D;
     };
-    f4u a4[3], b4[3], n4[3];
-    float a1[3], b1[3], n1[3], ao, bo, no;
-    load_av(0, a4, a1, ao, 0);
-    load_av(1, b4, b1, bo, 0);
+    f4u a4, b4, n4;
+    float a1, b1, n1, am, bm, nm;
+    load_av(0, a4, a1, am, 0);
+    load_av(1, b4, b1, bm, 0);
     float xr0[3][8];
+    float us_cur = sT[c], us_nxt = 0.f;
 #pragma unroll
     for (int step = 0; step < 2 * NB; ++step) {
       const int nn = step >> 1, t2 = step & 1;
-      if (step + 2 < 2 * NB) load_av(step + 2, n4, n1, no, 0);   // two steps (32 MFMAs) ahead
-      if (step == 2 * NB - 3) load_x<KIND, MODE, 0>(a, r, et, lane, 0, xr0);   // first column tile's operands: behind the last attr request
-      const f32x4 D = gemm1(a4, a1, ao);
+      if (step + 2 < 2 * NB) load_av(step + 2, n4, n1, nm, 0);   // two steps ahead
+      if (t2 == 0 && nn + 1 < NB) us_nxt = sT[(nn + 1) * 16 + c];
+      if (step == 2 * NB - 3) load_x<KIND, MODE, 0>(a, r, et, lane, 0, xr0);   // first column tile's operands: behind the last emb request
+      const f32x4 D = gemm1(a4, a1, am, us_cur, ug[t2]);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] = fmaxf(D[rr], 0.f);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b3 = 0; b3 < 3; ++b3) { a4[b3] = b4[b3]; a1[b3] = b1[b3]; b4[b3] = n4[b3]; b1[b3] = n1[b3]; }
-      ao = bo; bo = no;
+      a4 = b4; a1 = b1; am = bm;
+      b4 = n4; b1 = n1; bm = nm;
+      if (t2 == 1) us_cur = us_nxt;
     }
     if constexpr (MODE == LL) {
       // second GEMM1 over the bond edges of the same pairs (1-4 per atom): skipped per 16-pair tile when none of them is bonded;
       // the operands of step + 1 are requested before step's MFMAs
-      load_av(0, a4, a1, ao, 1);
+      load_av(0, a4, a1, am, 1);
+      us_cur = sT[c];
 #pragma unroll
       for (int step = 0; step < 2 * NB; ++step) {
         const int nn = step >> 1, t2 = step & 1;
-        if (step + 1 < 2 * NB) load_av(step + 1, n4, n1, no, 1);
-        if (__builtin_amdgcn_ballot_w64(ao != 0.f) != 0) {       // lane group 0 carries the validity of the tile's 16 pairs
-          const f32x4 D = gemm1(a4, a1, ao);
+        if (step + 1 < 2 * NB) load_av(step + 1, n4, n1, nm, 1);
+        if (t2 == 0 && nn + 1 < NB) us_nxt = sT[(nn + 1) * 16 + c];
+        // lane group 0 carries the validity of the tile's 16 pairs (msk == 0 <=> bonded)
+        if (__builtin_amdgcn_ballot_w64(g == 0 && am == 0.f) != 0) {
+          const f32x4 D = gemm1(a4, a1, am, us_cur, ug[t2]);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] += fmaxf(D[rr], 0.f);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b3 = 0; b3 < 3; ++b3) { a4[b3] = n4[b3]; a1[b3] = n1[b3]; }
-        ao = no;
+        a4 = n4; a1 = n1; am = nm;
+        if (t2 == 1) us_cur = us_nxt;
       }
     }
     NPROF(1);

@@ -163,3 +163,20 @@ def test_batch_keeps_graph_level_tensors_and_fingerprint_tracks_static_content()
     b3["ligand"].x = b3["ligand"].x.clone()
     b3["ligand"].x[0, 1] = (b3["ligand"].x[0, 1] + 1) % 4          # an in-place edit of a static field changes the key
     assert fp(b3) != k1
+
+
+def test_bench_traffic_record_lookup_is_robust(tmp_path, monkeypatch):
+    """bench.py reads roofline.traffic from profiles/conv_hbm_traffic.json: the committed file must parse, and neither a bare record, a
+    list with junk entries nor a missing file may take the bench line down with them."""
+    import json
+    import bench
+    assert isinstance(bench.measured_traffic(2, 512, "f32", "node"), tuple)           # the committed file
+    rec = dict(source_hash=bench.kernel_source_hash(), config=2, poses=512, precision="f32", conv_algo="node", traffic_bytes=123, profile="x.csv")
+    for payload in (rec, [rec], ["junk", 5, rec]):
+        f = tmp_path / "t.json"
+        f.write_text(json.dumps(payload))
+        monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
+        assert bench.measured_traffic(2, 512, "f32", "node") == (123, "x.csv")
+        assert bench.measured_traffic(2, 512, "f32", "edge") == (None, None)
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(tmp_path / "absent.json"))
+    assert bench.measured_traffic(2, 512, "f32", "node") == (None, None)

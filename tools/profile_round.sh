@@ -15,4 +15,5 @@ T=$(find /tmp/prof_$tag/trace -name '*.db' | head -1); F=$(find /tmp/prof_$tag/f
 echo "dbs: $T $F $W"
 python tools/summarize_prof.py gpurun_out/$tag "$T" --fetch "$F" --write "$W" --bench gpurun_out/${tag}_bench.json --command "rocprofv3 --kernel-trace --stats -- $CMD (PMC passes: --steps 8 --warmup 2)"
 tail -1 /tmp/prof_$tag/trace.out | cut -c1-300
-head -30 gpurun_out/${tag}_conv_slots.csv; cat gpurun_out/${tag}_traffic_record.json; head -14 gpurun_out/${tag}_kernel_stats.csv
+python -c "import json,sys; r=json.load(open(sys.argv[1])); json.dump(r if isinstance(r,list) else [r], open(sys.argv[2],'w'), indent=1)" gpurun_out/${tag}_traffic_record.json gpurun_out/conv_hbm_traffic.json
+head -30 gpurun_out/${tag}_conv_slots.csv; cat gpurun_out/conv_hbm_traffic.json; head -14 gpurun_out/${tag}_kernel_stats.csv
