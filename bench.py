@@ -35,11 +35,13 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_EDGE = {0: 2516, 1: 4636, 2: 6756, 3: 9236}      # 4*(numel + D_in + 9) per edge-conv, fp32
 ALG_FLOPS_PER_EDGE = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400}   # radial-MLP GEMM + TP
-# node-side formulation: per EDGE 2*61*(60 + C) flop (radial layer 1 + GEMM-A over C = sum_p mul_in*d_out columns),
-# per scatter NODE 2*61*W flop (GEMM-B, W = sum_p mul_in*mul_out*d_out); no padding counted
+# node-side formulation: per EDGE 2*61*(20 + C) flop (edge part of radial layer 1 + GEMM-A over C = sum_p mul_in*d_out
+# columns), per scatter NODE 2*61*(21 + W) flop (its block of radial layer 1 incl. bias + GEMM-B, W = sum_p mul_in*mul_out*d_out), per
+# gather NODE 2*61*20 flop (its block of radial layer 1, counted once per launch); no padding, no per-workgroup recomputation counted
 NODE_COLS = {0: 80, 1: 180, 2: 280, 3: 360}
 NODE_W = {0: 1000, 1: 2100, 2: 3200, 3: 4200}
-NODE_MFMA_PER_WAVE = {0: 512 + 6 * 128 + 400, 1: 512 + 13 * 128 + 840, 2: 512 + 20 * 128 + 1280, 3: 512 + 26 * 128 + 1680}   # issued per 32-edge pass
+# MFMAs issued per wave per 32-edge pass: radial layer 1 (32 edge tiles x 6 + three node tiles = 16) + GEMM-A (128 per column tile) + GEMM-B
+NODE_MFMA_PER_WAVE = {0: 208 + 6 * 128 + 400, 1: 208 + 13 * 128 + 840, 2: 208 + 20 * 128 + 1280, 3: 208 + 26 * 128 + 1680}
 MFMA_F32_PEAK_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 PROF_LAYER, PROF_CONV = 2, 1                                     # layer-2 phore->ligand conv: dense cross edge set
@@ -353,9 +355,10 @@ def main():
     flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * n_x
     if algo_used == "node":
         n_nodes = int(pb.lig_ptr[-1])                      # scatter nodes of the phore->ligand conv = ligand atoms
-        rf_flops = n_x * 2 * 61 * (60 + NODE_COLS[PROF_LAYER]) + n_nodes * 2 * 61 * NODE_W[PROF_LAYER]
-        rf_note = ("node-side formulation: 2*61*(60+280) flop per edge (radial layer 1 + GEMM-A) + 2*61*3200 flop per scatter node (GEMM-B), "
-                   "DESIGN.md 5; the edge-side count of SURVEY.md 8d is reported beside it")
+        n_gather = int(pb.ph_ptr[-1])                      # gather nodes = pharmacophore nodes
+        rf_flops = (n_x * 2 * 61 * (20 + NODE_COLS[PROF_LAYER]) + n_nodes * 2 * 61 * (21 + NODE_W[PROF_LAYER]) + n_gather * 2 * 61 * 20)
+        rf_note = ("node-side formulation: 2*61*(20+280) flop per edge (edge part of radial layer 1 + GEMM-A) + 2*61*(21+3200) flop per scatter "
+                   "node (its layer-1 block + GEMM-B) + 2*61*20 per gather node, DESIGN.md 5.1; the edge-side count of SURVEY.md 8d is reported beside it")
         groups = int(sum((int(pb.nl[i]) + 15) // 16 for i in range(B)))      # workgroups: 16-node groups, one 32-edge pass each at NP <= 32
         passes = int(sum(((int(pb.nl[i]) + 15) // 16) * ((int(pb.np_[i]) + 31) // 32) for i in range(B)))
         issued = passes * 4 * NODE_MFMA_PER_WAVE[PROF_LAYER] * 2048.0
