@@ -34,7 +34,7 @@ class DpConvArgs(C.Structure):
         ("w1p", VOIDP), ("w2p", VOIDP), ("bn_scale", VOIDP), ("bn_shift", VOIDP),
         ("out", VOIDP), ("out_stride", c_i32), ("accumulate", c_i32),
         ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32), ("phase_split", c_i32),
-        ("w1n", VOIDP), ("w2n", VOIDP), ("algo", c_i32),
+        ("w1n", VOIDP), ("w2n", VOIDP), ("algo", c_i32), ("path_split", c_i32),
         ("pair_a", VOIDP), ("pair_b", VOIDP), ("pair_ptr", VOIDP),
     ]
 

@@ -29,7 +29,7 @@
 #define DP_ABLATE 0
 #endif
 #ifndef DP_NODE_AUTO_MIN_POSES          // DP_ALGO_AUTO picks the node-side kernel from this batch size on
-#define DP_NODE_AUTO_MIN_POSES 48        // profiles/r2_batch_sweep.csv: node-side wins from ~48 poses (2 workgroups per pose)
+#define DP_NODE_AUTO_MIN_POSES 20        // profiles/r2_batch_sweep.csv: with the path split the node-side kernel wins from 20 poses
 #endif
 #ifdef DP_PROF   // cycle-stamp breakdown of the bf16 kernel (ablation builds only; tools/bench_conv.py --prof)
 __device__ unsigned long long dp_prof[16];

@@ -1,0 +1,205 @@
+// dp_conv_node_body.h - the body of the node-side conv kernel (dp_conv_node.hip), textually included twice:
+//   * directly into tp_conv_node_kernel<KIND, MODE>            (SIDE = -1: one workgroup per node group computes every path)
+//   * into a generic lambda of tp_conv_node_split_kernel        (SIDE = 0 / 1: the paths of one half of the out slots)
+// Why an include and not a function: the same text wrapped in a (force-inlined) device function or lambda compiles to measurably worse
+// code with this toolchain (hipcc 7.2: 183 instead of 55 spilled registers for layer 3, +6 % launch time) although nothing is left of
+// the call after inlining; the unsplit kernel carries 94 % of a large batch's step, so it keeps the direct form.
+// Expects in scope: template parameters KIND, MODE; `constexpr int SIDE`; `const DpConvArgs a` (or a reference); `int bid`; the
+// __shared__ arrays s_T, s_S.  `return` leaves the kernel or the lambda respectively.
+  using S = Spec<KIND>;
+  static_assert(4 * NB * S::D_OUT <= 4 * TSTRIDE, "reduction scratch fits in the T buffers");
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
+  const Wg r = wg_of<MODE>(a, bid);
+  if (r.n_loc <= 0) return;
+  float* sT = s_T + q * TSTRIDE;
+  constexpr int P0 = next_owned<KIND, SIDE>(-1);                               // first path this workgroup computes
+
+  f32x4 acc[n_acc4<KIND>()];
+#pragma unroll
+  for (int i = 0; i < n_acc4<KIND>(); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n_et = (r.En + 31) >> 5;
+  NProfT prof_prev{};
+  (void)prof_prev;
+  NPROF(-1);
+#pragma unroll 1
+  for (int et = 0; et < n_et; ++et) {
+    __syncthreads();                               // readers of the previous pass's factors are done
+    for (int idx = tid; idx < NB * 32; idx += 256) {
+      const int nn = idx >> 5, el = idx & 31, e = 32 * et + el;
+      bool ok = nn < r.n_loc && e < r.En;
+      int frow = 0;
+      if (ok) {
+        if constexpr (MODE == LL) {
+          const int sa = pair_slot<0>(a, r, r.n_lo + nn, e), sb = pair_slot<1>(a, r, r.n_lo + nn, e);
+          frow = sa >= 0 ? sa : sb;
+          ok = frow >= 0;
+        } else {
+          frow = feat_row<MODE>(r, r.n_lo + nn, e);
+        }
+      }
+      float v[SCOMP];
+#pragma unroll
+      for (int i = 0; i < SCOMP; ++i) v[i] = 0.f;
+      if (ok) {
+        const float* ps = a.edge_sh + (size_t)frow * a.sh_stride;
+        const float cc = 0.57735026918962576451f * ps[6];
+        v[0] = ps[1]; v[1] = ps[2]; v[2] = ps[3];
+        v[3] = -cc - ps[8]; v[4] = ps[5]; v[5] = ps[4]; v[6] = 2.f * cc; v[7] = ps[7]; v[8] = -cc + ps[8];
+      }
+#pragma unroll
+      for (int i = 0; i < SCOMP; ++i) s_S[((nn * 2 + (el >> 4)) * SCOMP + i) * 16 + (el & 15)] = v[i];
+    }
+    __syncthreads();
+    NPROF(0);
+
+    // ---- GEMM1: hidden rows 16q..16q+15 of the 32 edges of every node of the batch ---------------------------------------------
+    // attr = [edge_emb | attr1[:20] | attr2[:20]] and two of the three blocks belong to NODES, not edges: the scatter node's block is the
+    // same for all of its edges and the gather node's block the same for every scatter node.  So the first layer is split
+    //     pre[e] = W1_emb emb[e]  +  u_s[scatter(e)]  +  u_g[gather(e)],     u_s = W1_s attr_s + b,   u_g = W1_g attr_g
+    // with u_s / u_g evaluated once per pass as three 16-row MFMA tiles (rows = nodes) and the per-edge part shrinking from 16 K-steps
+    // to 5 (+ 1 mask step).  u_g comes out of the MFMA in exactly the D-fragment layout of the edge tiles (rows = the pass's gather
+    // nodes = its edge slots), u_s is broadcast over rows through 1 KiB of the (idle) T buffer.
+    float hid[NB][8];
+    float w1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w1[s] = a.w1n[(q * 16 + s) * 64 + lane];
+    constexpr int SBLK = MODE == DP_EDGES_L2P ? 2 : 1, GBLK = MODE == DP_EDGES_L2P ? 1 : 2;      // attr block of the scatter / gather node
+    const float* s_tab = MODE == DP_EDGES_L2P ? a.attr2_tab : a.attr1_tab;
+    const float* g_tab = MODE == DP_EDGES_L2P ? a.attr1_tab : a.attr2_tab;
+    const int s_stride = MODE == DP_EDGES_L2P ? a.attr2_stride : a.attr1_stride, g_stride = MODE == DP_EDGES_L2P ? a.attr1_stride : a.attr2_stride;
+    auto node_tile = [&](const float* rowp, int blk, bool bias) {
+      const f4u v4 = *reinterpret_cast<const f4u*>(rowp + 5 * g);
+      const float v1 = rowp[5 * g + 4];
+      f32x4 D = {0.f, 0.f, 0.f, 0.f};
+      D = mfma16(v4.x, w1[5 * blk + 0], D);
+      D = mfma16(v4.y, w1[5 * blk + 1], D);
+      D = mfma16(v4.z, w1[5 * blk + 2], D);
+      D = mfma16(v4.w, w1[5 * blk + 3], D);
+      D = mfma16(v1, w1[5 * blk + 4], D);
+      if (bias) D = mfma16(g == 0 ? 1.f : 0.f, w1[15], D);
+      return D;
+    };
+    f32x4 ug[2];                                               // u_g of the pass's 32 edge slots: register rr <-> slot 16 t2 + 4 g + rr
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int e0 = 32 * et + 16 * t2 + c;
+      const int grow = (MODE == DP_EDGES_P2L ? r.p0 : r.l0) + (e0 < r.En ? e0 : 0);
+      ug[t2] = node_tile(g_tab + (size_t)grow * g_stride, GBLK, false);
+    }
+    {
+      const int srow = r.n_lo + (c < r.n_loc ? c : 0);
+      const f32x4 us = node_tile(s_tab + (size_t)srow * s_stride, SBLK, true);            // + fc.0 bias (and the constant-one unit)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) sT[(4 * g + rr) * 16 + c] = us[rr];                   // [node][k]: read back as a broadcast over rows
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // edge part: five consecutive floats of edge_emb per lane group; the loads of step i + 2 are issued before the MFMAs of step i
+    // (steps = 16 nodes x 2 tiles).  An edge that does not exist (e >= En, or no radius / bond edge for the pair) gets -1e30 added to
+    // every pre-activation by the mask step (A = -1e30 in lane group 0, B = ones): its hidden vector - constant-one unit included -
+    // is exactly 0 and it drops out of T.
+    const float bone = g == 0 ? 1.f : 0.f;
+    auto load_av = [&](int step, f4u& v4, float& v1, float& msk, int which) {
+      int nn_o = step >> 1;                          // opaque copy: keeps the 16 nodes' row pointers from being hoisted out of the pass loop (spills)
+      asm volatile("" : "+s"(nn_o));
+      const int node = r.n_lo + (nn_o < r.n_loc ? nn_o : 0);
+      const int e0 = 32 * et + 16 * (step & 1) + c;  // GEMM1 view: lane (g, c) feeds emb[edge c][group g]
+      bool ok = e0 < r.En;
+      const int e = ok ? e0 : 0;
+      int frow;
+      if constexpr (MODE == LL) {
+        frow = which == 0 ? pair_slot<0>(a, r, node, e) : pair_slot<1>(a, r, node, e);
+        ok = ok && frow >= 0;
+        frow = frow >= 0 ? frow : 0;
+      } else {
+        frow = feat_row<MODE>(r, node, e);
+      }
+      const float* pe = a.edge_emb + (size_t)frow * 20 + 5 * g;
+      v4 = *reinterpret_cast<const f4u*>(pe);
+      v1 = pe[4];
+      msk = (!ok && g == 0) ? -1e30f : 0.f;
+    };
+    auto gemm1 = [&](const f4u& v4, float v1, float msk, float usn, const f32x4& ugt) {
+      f32x4 D = {usn + ugt[0], usn + ugt[1], usn + ugt[2], usn + ugt[3]};
+#if DP_NABL != 6
+      D = mfma16(v4.x, w1[0], D);
+      D = mfma16(v4.y, w1[1], D);
+      D = mfma16(v4.z, w1[2], D);
+      D = mfma16(v4.w, w1[3], D);
+      D = mfma16(v1, w1[4], D);
+      D = mfma16(msk, bone, D);
+#else
+      D[0] += v4.x + msk; D[1] += v4.y; D[2] += v4.z; D[3] += v4.w + v1;
+#endif
+      return D;
+    };
+    f4u a4, b4, n4;
+    float a1, b1, n1, am, bm, nm;
+    load_av(0, a4, a1, am, 0);
+    load_av(1, b4, b1, bm, 0);
+    float xr0[3][8];
+    float us_cur = sT[c], us_nxt = 0.f;
+#pragma unroll
+    for (int step = 0; step < 2 * NB; ++step) {
+      const int nn = step >> 1, t2 = step & 1;
+      if (step + 2 < 2 * NB) load_av(step + 2, n4, n1, nm, 0);   // two steps ahead
+      if (t2 == 0 && nn + 1 < NB) us_nxt = sT[(nn + 1) * 16 + c];
+      if (step == 2 * NB - 3) load_x<KIND, MODE, P0>(a, r, et, lane, 0, xr0);   // first column tile's operands: behind the last emb request
+      const f32x4 D = gemm1(a4, a1, am, us_cur, ug[t2]);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] = fmaxf(D[rr], 0.f);
+      __builtin_amdgcn_sched_barrier(0);
+      a4 = b4; a1 = b1; am = bm;
+      b4 = n4; b1 = n1; bm = nm;
+      if (t2 == 1) us_cur = us_nxt;
+    }
+    if constexpr (MODE == LL) {
+      // second GEMM1 over the bond edges of the same pairs (1-4 per atom): skipped per 16-pair tile when none of them is bonded;
+      // the operands of step + 1 are requested before step's MFMAs
+      load_av(0, a4, a1, am, 1);
+      us_cur = sT[c];
+#pragma unroll
+      for (int step = 0; step < 2 * NB; ++step) {
+        const int nn = step >> 1, t2 = step & 1;
+        if (step + 1 < 2 * NB) load_av(step + 1, n4, n1, nm, 1);
+        if (t2 == 0 && nn + 1 < NB) us_nxt = sT[(nn + 1) * 16 + c];
+        // lane group 0 carries the validity of the tile's 16 pairs (msk == 0 <=> bonded)
+        if (__builtin_amdgcn_ballot_w64(g == 0 && am == 0.f) != 0) {
+          const f32x4 D = gemm1(a4, a1, am, us_cur, ug[t2]);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] += fmaxf(D[rr], 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a4 = n4; a1 = n1; am = nm;
+        if (t2 == 1) us_cur = us_nxt;
+      }
+    }
+    NPROF(1);
+    PathStage<KIND, MODE, SIDE, P0>::run(a, r, et, q, lane, hid, sT, s_S, acc, xr0, prof_prev);
+  }
+
+  // ---- sum the four k-partials, mean, BatchNorm affine, residual stream ------------------------------------------------------------
+  __syncthreads();
+  AccStore<KIND, 0>::run(acc, s_T + q * (NB * S::D_OUT), lane);
+  __syncthreads();
+  for (int i = tid; i < r.n_loc * S::D_OUT; i += 256) {
+    const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
+    if (SIDE >= 0 && kChanOwner<KIND>.v[ch] != SIDE) continue;
+    const int node = r.n_lo + n;
+    const int deg = MODE == LL ? a.rowend[node] - a.rowptr[node] : r.En;       // scatter MEAN over the node's edges (torch_scatter: / max(count, 1))
+    float v = ((s_T[i] + s_T[NB * S::D_OUT + i]) + s_T[2 * NB * S::D_OUT + i]) + s_T[3 * NB * S::D_OUT + i];
+    v = v / (float)max(deg, 1);
+    v = v * a.bn_scale[ch] + a.bn_shift[ch];
+    float* o = a.out + (size_t)node * a.out_stride + ch;
+    if (a.accumulate) {
+      *o += v;
+    } else {
+      if (a.resid != nullptr && ch < a.resid_width) v += a.resid[(size_t)node * a.resid_stride + ch];
+      *o = v;
+    }
+  }
+  NPROF(4);
+#ifdef DP_PROF
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&dpn_prof[i], prof_prev.acc[i]);
+#endif

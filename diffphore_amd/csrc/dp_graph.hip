@@ -569,6 +569,9 @@ __global__ void tor_head_kernel(DpBatch b, DpWeights w, DpWork k, float* __restr
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" {
 
+// node-side convs: two workgroups per node group (DpConvArgs.path_split) while one per group leaves half of the 256 CUs x 2 slots idle
+static int node_path_split(int B, int slices) { return (long long)B * slices <= 256 ? 1 : 0; }
+
 static int dp_check_batch(const DpBatch* b) {
   if (!b || b->B <= 0) return DP_E_BADARG;
   if (b->max_nl > dp::MAXN_L || b->max_np > dp::MAXN_P || b->max_t > dp::MAXT) return DP_E_TOOLARGE;
@@ -651,6 +654,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.out = hl2; c.accumulate = 0; c.resid = hl; c.resid_width = din;
       if (node_ll) {
         c.algo = DP_ALGO_NODE; c.mode = DP_EDGES_LLPAIR; c.w1n = w->lig_conv[l].w1n; c.w2n = w->lig_conv[l].w2n; c.slices = slices_pl; c.phase_split = 0;
+        c.path_split = node_path_split(B, slices_pl);
         c.pair_a = k->ll_pair_rad; c.pair_b = k->ll_pair_bond; c.pair_ptr = b->llp_ptr;
       }
       if ((rc = timed(c, l, 0, st))) return rc;
@@ -662,7 +666,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
-      if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; }
+      if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); }
       if ((rc = timed(c, l, 1 + nv, st))) return rc;
     }
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
@@ -681,7 +685,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
-        if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; }
+        if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); }
         if ((rc = timed(c, l, 4 + nv, sp_))) return rc;
       }
     }

@@ -118,6 +118,8 @@ typedef struct DpConvArgs {
   const float* w1n;
   const float* w2n;
   int32_t algo;              /* DpConvAlgo; AUTO / EDGE -> the edge-side kernel */
+  int32_t path_split;        /* node-side only. 1: two workgroups per node group, each owning half of the output irrep slots - halves a conv's
+                                latency when B*slices cannot fill the chip (both repeat the cheap radial layer 1); bit-identical results */
   /* DP_EDGES_LLPAIR: per pose a [N_l x N_l] table at pair_ptr[pose]; entry (i, j) = edge slot (row of edge_emb / edge_sh, CSR order)
    * of the radius edge scatter i <- gather j (pair_a) / of the bond edge (pair_b), -1 if absent.  rowptr / rowend give the degree. */
   const int32_t *pair_a, *pair_b, *pair_ptr;

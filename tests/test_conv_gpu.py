@@ -241,6 +241,11 @@ def test_conv_node_side_dense_cross(kind, mode):
     base.update(algo=_lib.ALGO_NODE, out=out3, slices=(mx + nb - 1) // nb)
     _run(base, keep)
     assert torch.equal(out3.cpu().double(), got)
+    # path split (two workgroups per node group, each owning half of the out slots): every channel is computed as before
+    out4 = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    base.update(out=out4, path_split=1)
+    _run(base, keep)
+    assert torch.equal(out4.cpu().double(), got)
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3])
@@ -313,6 +318,9 @@ def test_conv_node_side_ligand_pairs(kind):
     _run(dict(common, mode=_lib.EDGES_CSR, algo=_lib.ALGO_EDGE, slices=2, out=out2), keep)
     err = (out2.cpu().double() - got).abs().max().item() / scale
     assert err < TOL["f32"], err
+    out3 = torch.full((N, dims["d_out"]), float("nan")).cuda()
+    _run(dict(common, mode=_lib.EDGES_LLPAIR, algo=_lib.ALGO_NODE, slices=(max(NL) + nb - 1) // nb, out=out3, path_split=1), keep)
+    assert torch.equal(out3.cpu().double(), got)               # path split: bit-identical
 
 
 @pytest.mark.parametrize("prec", PRECS)
