@@ -537,11 +537,14 @@ template <int KIND, int MODE>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_split_kernel(DpConvArgs a) {
   __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE];
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];
-  auto conv_body = [a]<int SIDE>(std::integral_constant<int, SIDE>, int bid) {
+  const int bid = (int)(blockIdx.x >> 1);
+  if (blockIdx.x & 1u) {
+    constexpr int SIDE = 1;
 #include "dp_conv_node_body.h"
-  };
-  if (blockIdx.x & 1u) conv_body(std::integral_constant<int, 1>{}, (int)(blockIdx.x >> 1));
-  else conv_body(std::integral_constant<int, 0>{}, (int)(blockIdx.x >> 1));
+  } else {
+    constexpr int SIDE = 0;
+#include "dp_conv_node_body.h"
+  }
 }
 
 template <int KIND> int launch(const DpConvArgs& a, hipStream_t st) {

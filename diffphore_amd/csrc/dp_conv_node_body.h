@@ -1,11 +1,11 @@
 // dp_conv_node_body.h - the body of the node-side conv kernel (dp_conv_node.hip), textually included twice:
 //   * directly into tp_conv_node_kernel<KIND, MODE>            (SIDE = -1: one workgroup per node group computes every path)
-//   * into a generic lambda of tp_conv_node_split_kernel        (SIDE = 0 / 1: the paths of one half of the out slots)
+//   * into the two branches of tp_conv_node_split_kernel        (SIDE = 0 / 1: the paths of one half of the out slots)
 // Why an include and not a function: the same text wrapped in a (force-inlined) device function or lambda compiles to measurably worse
 // code with this toolchain (hipcc 7.2: 183 instead of 55 spilled registers for layer 3, +6 % launch time) although nothing is left of
 // the call after inlining; the unsplit kernel carries 94 % of a large batch's step, so it keeps the direct form.
 // Expects in scope: template parameters KIND, MODE; `constexpr int SIDE`; `const DpConvArgs a` (or a reference); `int bid`; the
-// __shared__ arrays s_T, s_S.  `return` leaves the kernel or the lambda respectively.
+// __shared__ arrays s_T, s_S.  `return` leaves the kernel.
   using S = Spec<KIND>;
   static_assert(4 * NB * S::D_OUT <= 4 * TSTRIDE, "reduction scratch fits in the T buffers");
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
