@@ -24,7 +24,8 @@ from . import _lib
 from .engine import DpStepParams, Engine, PackedBatch, _declare, _stream
 
 
-GRAPH_MAX_POSES = 128      # batches up to this size replay the captured loop
+GRAPH_MAX_POSES = 0        # `auto` never captures: the loop is GPU-bound down to 8 poses, a replay gains <= 0.5 % and the capture of a
+                           # run's ~760 launches costs ~2 ms per call (40 poses: 35.4 vs 32.4 ms end to end); DIFFPHORE_GRAPH=1 forces it
 
 
 def _step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero_noise) -> DpStepParams:
@@ -91,8 +92,8 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
         zero = no_random or (no_final_step_noise and last)
         sps.append(_step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero))
     if not keep_update and visualization_list is None and os.environ.get("DIFFPHORE_WHOLE_LOOP", "1") != "0":
-        # the whole loop in one library call (dp_sample): times and noise are device tables indexed by the step; small batches replay
-        # it from a hipGraph (launch-gap bound), large ones enqueue it eagerly (GPU bound either way)
+        # the whole loop in one library call (dp_sample): times and noise are device tables indexed by the step.  Enqueued eagerly; the
+        # hipGraph form (capture once, replay) is for callers that rerun the same engine many times (dp_sample_graph_*)
         g = os.environ.get("DIFFPHORE_GRAPH", "auto")
         use_graph = g == "1" or (g == "auto" and pb.B <= GRAPH_MAX_POSES)
         z_tor = Z["tor"] if (Z is not None and not no_torsion and Z["tor"].numel()) else None
