@@ -14,8 +14,10 @@
 // Mapping to CDNA4 (v_mfma_f32_16x16x4_f32 everywhere, 32 cycles each)
 //   * a workgroup = 4 waves = one group of <= 16 scatter nodes of one pose; wave q owns hidden rows 16q..16q+15 (k-split), so each
 //     wave's whole pipeline GEMM1 -> GEMM-A -> LDS transpose -> GEMM-B is wave-private: no workgroup barrier inside a batch.
-//   * GEMM1  hid^T[16 edges x 16 k] = attr[16 x 64] W1^T: its D registers ARE GEMM-A's A operand (edge order of GEMM-A's K steps is
-//     chosen to be the D-fragment row order), kept in registers for the 16 nodes of the batch (128 VGPRs).
+//   * GEMM1  hid^T[16 edges x 16 k]: the radial MLP's first layer is split into per-node terms (the scatter node's and the gather node's
+//     attr blocks, three 16-row node tiles per pass) and a per-edge part over edge_emb (5 K-steps + 1 mask step instead of 16); its D
+//     registers ARE GEMM-A's A operand (edge order of GEMM-A's K steps is chosen to be the D-fragment row order), kept in registers
+//     for the 16 nodes of the batch (128 VGPRs).
 //   * GEMM-A per (column tile, node): 8 MFMAs; B operand z generated on the VALU from the gathered input (registers, loaded once per
 //     tile: in the dense modes a lane's gathered rows are the same for every node) and sh-derived factors staged in LDS per batch.
 //   * the 16x16 T tile goes through a wave-private, XOR-swizzled LDS buffer (one ds_write_b128 per node, ds_read_b128 back):
@@ -23,6 +25,8 @@
 //   * GEMM-B per column tile: A = packed W2 slice (dwordx4 loads from L2, shared by the three m components), B = T, N = 16 nodes,
 //     accumulating into <= 40 persistent registers; the four waves' k-partial outputs are summed through LDS at the end.
 //   Nodes with more than 32 edges run several 32-edge passes that accumulate into the same GEMM-B accumulators (GEMM-B is linear).
+//   Batches too small to fill the chip launch two workgroups per node group, each owning half of the output irrep slots (path split).
+// The kernel body is dp_conv_node_body.h (included into the unsplit kernel and into both branches of the split kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -63,7 +67,8 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byt
 
 constexpr int NB = 16;        // nodes per workgroup = N of the GEMM-B MFMAs
 constexpr int TCOLS = 15;     // columns of a T tile that are stored (3 m-groups x 5 in-channels, or 10 in-channels of a scalar-output path)
-constexpr int TSTRIDE = TCOLS * NB * 16 + 16;   // floats per wave: 15 column rows of 1 KiB + the dummy 16-byte slots of lanes c == 15
+constexpr int TSTRIDE = TCOLS * NB * 16;        // floats per wave: 15 column rows of 1 KiB
+constexpr int TDUMMY = NB * 16;                 // one more KiB shared by all waves: where the lanes of the unused 16th column store
 constexpr int SCOMP = 9;      // per-edge factors staged in LDS: sh1[0..2], M00, M01, M02, M11, M12, M22
 constexpr int HIDN = 60;      // hidden units of the radial MLP (kinds 0-3); unit 60 is the constant one
 
@@ -344,7 +349,12 @@ struct PathStage {
         // so neither the LDS latency nor the z arithmetic sits between two MFMA groups of the same wave.  sched_group_barrier pins
         // the MFMA / VALU interleave inside a step, sched_barrier keeps steps apart (hoisting all LDS reads together spills).
         // Lanes of the unused 16th column store into a per-wave dummy slot instead of being masked off (no exec juggling).
-        const int twr = c < TCOLS ? c * (NB * 16) : TCOLS * (NB * 16);
+        // store address of node nn's tile: [col][((nn << 2) | g) ^ (c & 7)][4] = two lane constants (even / odd nn) + an immediate nn * 64 B
+        // (the swizzle flips bit 0 of nn for the lanes with c & 4), so a store costs no VALU; lanes c == 15 aim at the shared dummy row
+        const int tb = (c >> 2) & 1;
+        float* const tw_base = c < TCOLS ? sT + c * (NB * 16) + ((g ^ (c & 3)) << 2) : sT + (4 - q) * TSTRIDE + (g << 2);
+        float* const tw_even = c < TCOLS ? tw_base + tb * 16 : tw_base;
+        float* const tw_odd = c < TCOLS ? tw_base - tb * 16 : tw_base;
         if constexpr (needs_s<ZT>() && DP_NABL != 1) {
           const char* sbase = reinterpret_cast<const char*>(sS);
           auto loadS = [&](int qs, f32x4 (&sv)[NTERM]) {
@@ -360,30 +370,39 @@ struct PathStage {
               z[rr] = zz;
             }
           };
-          f32x4 sv_nxt[NTERM], sv_nn[NTERM];
-          float z_cur[4], z_nxt[4];
-          loadS(0, sv_nn);
-          loadS(1, sv_nxt);
-          makeZ(0, sv_nn, z_cur);
+          // explicit ring buffers, no register copies between steps: the factors of step qs live in sv[qs % 3], its z in z[qs & 1]
+          // (with a two-name rotation the allocator reused the registers a step's VALU still reads for that step's prefetch, which
+          // forbids "reads first" and collapsed every second step's interleave into MFMA x4 followed by all of the VALU)
+          auto makeZ1 = [&](int t2, int rr, const f32x4 (&sv)[NTERM]) {
+            float zz = xa[0][4 * t2 + rr] * sv[0][rr];
+#pragma unroll
+            for (int t = 1; t < NTERM; ++t) zz = fmaf(xa[t][4 * t2 + rr], sv[t][rr], zz);
+            return zz;
+          };
+          f32x4 sv[3][NTERM];
+          float z[2][4];
+          loadS(0, sv[0]);
+          loadS(1, sv[1]);
+          makeZ(0, sv[0], z[0]);
           __builtin_amdgcn_sched_barrier(0);
           f32x4 D[2];
-          const int twl = c < TCOLS ? 0 : 1;
-          auto tslot = [&](int nn) { return sT + twr + (twl ? (g << 2) : ((((nn << 2) | g) ^ (c & 7)) << 2)); };
+          auto tslot = [&](int nn) { return ((nn & 1) ? tw_odd : tw_even) + nn * 16; };
 #pragma unroll
           for (int qs = 0; qs < 2 * NB; ++qs) {
             const int nn = qs >> 1, t2 = qs & 1;
-            if (qs + 2 < 2 * NB) loadS(qs + 2, sv_nn);
-            if (qs + 1 < 2 * NB) makeZ((qs + 1) & 1, sv_nxt, z_nxt);
+            if (qs + 2 < 2 * NB) loadS(qs + 2, sv[(qs + 2) % 3]);
             if (t2 == 0) D[nn & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // source order = issue order wanted: MFMA rr, then the z value of the next step's K-step rr (one mul / fma chain)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
 #if DP_NABL == 5
-              asm volatile("" ::"v"(z_cur[rr]), "v"(hid[nn][4 * t2 + rr]));
+              asm volatile("" ::"v"(z[qs & 1][rr]), "v"(hid[nn][4 * t2 + rr]));
 #else
-              D[nn & 1] = mfma16(hid[nn][4 * t2 + rr], z_cur[rr], D[nn & 1]);
+              D[nn & 1] = mfma16(hid[nn][4 * t2 + rr], z[qs & 1][rr], D[nn & 1]);
 #endif
+              if (qs + 1 < 2 * NB) z[(qs + 1) & 1][rr] = makeZ1((qs + 1) & 1, rr, sv[(qs + 1) % 3]);
             }
-            // the finished tile of the PREVIOUS node is stored one step late, behind this step's MFMAs: its last MFMA has long retired
+            // the finished tile of the PREVIOUS node is stored one step late, behind this step's first MFMA: its last MFMA has long retired
 #if DP_NABL == 2
             if (t2 == 0 && nn > 0) asm volatile("" ::"v"(D[(nn - 1) & 1]));
 #else
@@ -393,13 +412,10 @@ struct PathStage {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // one MFMA ...
+              if (rr == 0 && t2 == 0 && nn > 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // (the previous node's tile store)
               if (qs + 1 < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x002, NTERM, 0);     // ... then one z value's mul / fma chain
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) z_cur[rr] = z_nxt[rr];
-#pragma unroll
-            for (int t = 0; t < NTERM; ++t) sv_nxt[t] = sv_nn[t];
           }
 #if DP_NABL == 2
           asm volatile("" ::"v"(D[(NB - 1) & 1]));
@@ -423,7 +439,7 @@ struct PathStage {
 #if DP_NABL == 2
             asm volatile("" ::"v"(D));
 #else
-            *reinterpret_cast<f32x4*>(sT + twr + (c < TCOLS ? ((((nn << 2) | g) ^ (c & 7)) << 2) : (g << 2))) = D;
+            *reinterpret_cast<f32x4*>(((nn & 1) ? tw_odd : tw_even) + nn * 16) = D;
 #endif
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -519,7 +535,7 @@ struct AccStore {
 
 template <int KIND, int MODE>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE];              // wave-private T tiles (+ a dummy slot); reused for the final reduction
+  __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE + TDUMMY];     // wave-private T tiles + the shared dummy row; reused for the final reduction
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];         // per-edge sh factors of the current pass
 #if DP_NABL == 7                                                                // one workgroup per CU (a single wave per SIMD)
   __shared__ float s_pad[2048];
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(DpConvArgs a) {
 // workgroup per node group; every output channel is computed exactly as in the unsplit launch (bit-identical).
 template <int KIND, int MODE>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_split_kernel(DpConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE];
+  __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE + TDUMMY];
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];
   const int bid = (int)(blockIdx.x >> 1);
   if (blockIdx.x & 1u) {
