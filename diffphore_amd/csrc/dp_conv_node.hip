@@ -137,6 +137,14 @@ template <int KIND, int SIDE> constexpr int next_owned(int p) {          // firs
   while (n < Spec<KIND>::NPATH && !owns<KIND, SIDE>(n)) ++n;
   return n;
 }
+template <int KIND> constexpr bool split_is_sound() {                   // both sides own something; paths of one out slot stay together
+  if (next_owned<KIND, 0>(-1) >= Spec<KIND>::NPATH || next_owned<KIND, 1>(-1) >= Spec<KIND>::NPATH) return false;
+  for (int i = 0; i < Spec<KIND>::NPATH; ++i)
+    for (int j = 0; j < Spec<KIND>::NPATH; ++j)
+      if (Spec<KIND>::P[i].out_off == Spec<KIND>::P[j].out_off && split_owner<KIND>(i) != split_owner<KIND>(j)) return false;
+  return true;
+}
+static_assert(split_is_sound<0>() && split_is_sound<1>() && split_is_sound<2>() && split_is_sound<3>(), "path split partitions the out slots");
 template <int KIND> constexpr int chan_owner(int ch) {
   for (int i = 0; i < Spec<KIND>::NPATH; ++i) {
     const PathC& pc = Spec<KIND>::P[i];
