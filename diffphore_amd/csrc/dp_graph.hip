@@ -11,7 +11,7 @@
 #include "dp_dev.h"
 
 #ifndef DP_NODE_LL_MAX_ATOMS
-#define DP_NODE_LL_MAX_ATOMS 64      // above this the pair-dense lig-lig passes cost more than the edge-side kernel
+#define DP_NODE_LL_MAX_ATOMS 96      // three 32-slot passes still beat the edge-side kernel (80 atoms: 10.5 vs 12.4 ms/step at 256 poses); beyond: untested
 #endif
 
 namespace dp {
@@ -615,19 +615,21 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
                        b->max_nl <= DP_NODE_LL_MAX_ATOMS;
   // optional second stream: phore-side convs of a layer (and the torsion head) run beside the ligand-side ones
   hipStream_t aux = (k->aux_stream && k->ev_fork && k->ev_join) ? (hipStream_t)k->aux_stream : nullptr;
+  int ev_rc = 0;                                   // first failing event / stream call (reported at the end: launches are asynchronous anyway)
+  auto note = [&](hipError_t e) { if (e != hipSuccess && ev_rc == 0) ev_rc = (int)e; };
   auto fork = [&]() {
-    if (aux) { hipEventRecord((hipEvent_t)k->ev_fork, st); hipStreamWaitEvent(aux, (hipEvent_t)k->ev_fork, 0); }
+    if (aux) { note(hipEventRecord((hipEvent_t)k->ev_fork, st)); note(hipStreamWaitEvent(aux, (hipEvent_t)k->ev_fork, 0)); }
   };
   auto join = [&]() {
-    if (aux) { hipEventRecord((hipEvent_t)k->ev_join, aux); hipStreamWaitEvent(st, (hipEvent_t)k->ev_join, 0); }
+    if (aux) { note(hipEventRecord((hipEvent_t)k->ev_join, aux)); note(hipStreamWaitEvent(st, (hipEvent_t)k->ev_join, 0)); }
   };
   int cur = 0;
   static const int D[5] = {20, 50, 80, 100, 100};
   auto timed = [&](const DpConvArgs& c, int layer, int which, hipStream_t s_) -> int {
     const bool prof = k->prof_start && k->prof_stop && k->prof_layer == layer && k->prof_conv == which;
-    if (prof) hipEventRecord((hipEvent_t)k->prof_start, s_);
+    if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
     const int r = dp_tp_conv(&c, s_);
-    if (prof) hipEventRecord((hipEvent_t)k->prof_stop, s_);
+    if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
     return r;
   };
   for (int l = 0; l < 4; ++l) {
@@ -726,7 +728,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     hipLaunchKernelGGL(dp::tor_head_kernel, dim3((b->n_tor + 63) / 64), dim3(64), 0, s2, *b, *w, *k, tor);
     if (tor_aux) join();
   }
-  return (int)hipGetLastError();
+  return ev_rc ? ev_rc : (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -302,8 +302,8 @@ int dp_sample_graph_create(const DpBatch* b, const DpWeights* w, DpWork* k, cons
   }
   hipGraphExec_t ge = nullptr;
   if (rc == 0) rc = (int)hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-  if (g) hipGraphDestroy(g);
-  hipStreamDestroy(cs);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipStreamDestroy(cs);
   if (rc == 0) *graph_exec = ge;
   return rc;
 }
