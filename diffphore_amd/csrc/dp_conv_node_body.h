@@ -12,6 +12,8 @@
   const Wg r = wg_of<MODE>(a, bid);
   if (r.n_loc <= 0) return;
   float* sT = s_T + q * TSTRIDE;
+  int* const s_pair = reinterpret_cast<int*>(s_T + TSTRIDE - 2 * NB * 32);     // LL mode: [2][NB][32] edge slots of the pass's pairs
+  (void)s_pair;
   constexpr int P0 = next_owned<KIND, SIDE>(-1);                               // first path this workgroup computes
 
   f32x4 acc[n_acc4<KIND>()];
@@ -29,14 +31,17 @@
       const int nn = idx >> 5, el = idx & 31, e = 32 * et + el;
       bool ok = nn < r.n_loc && e < r.En;
       int frow = 0;
-      if (ok) {
-        if constexpr (MODE == LL) {
-          const int sa = pair_slot<0>(a, r, r.n_lo + nn, e), sb = pair_slot<1>(a, r, r.n_lo + nn, e);
-          frow = sa >= 0 ? sa : sb;
-          ok = frow >= 0;
-        } else {
-          frow = feat_row<MODE>(r, r.n_lo + nn, e);
-        }
+      if constexpr (MODE == LL) {
+        // the pass's pair -> edge-slot entries are parked in LDS (tail of wave 0's idle T buffer) for GEMM1: its row gathers then hang
+        // on an LDS read instead of on a second dependent global load
+        int sa = -1, sb = -1;
+        if (ok) { sa = pair_slot<0>(a, r, r.n_lo + nn, e); sb = pair_slot<1>(a, r, r.n_lo + nn, e); }
+        s_pair[idx] = sa;
+        s_pair[NB * 32 + idx] = sb;
+        frow = sa >= 0 ? sa : sb;
+        ok = frow >= 0;
+      } else if (ok) {
+        frow = feat_row<MODE>(r, r.n_lo + nn, e);
       }
       float v[SCOMP];
 #pragma unroll
@@ -108,9 +113,9 @@
       const int e = ok ? e0 : 0;
       int frow;
       if constexpr (MODE == LL) {
-        frow = which == 0 ? pair_slot<0>(a, r, node, e) : pair_slot<1>(a, r, node, e);
-        ok = ok && frow >= 0;
-        frow = frow >= 0 ? frow : 0;
+        frow = s_pair[which * (NB * 32) + nn_o * 32 + 16 * (step & 1) + c];        // -1: no such node / pair / edge of this kind
+        ok = frow >= 0;
+        frow = ok ? frow : 0;
       } else {
         frow = feat_row<MODE>(r, node, e);
       }
@@ -174,6 +179,7 @@
         if (t2 == 1) us_cur = us_nxt;
       }
     }
+    if constexpr (MODE == LL) __syncthreads();     // s_pair lives in wave 0's T buffer: every wave is done reading it before T tiles land there
     NPROF(1);
     PathStage<KIND, MODE, SIDE, P0>::run(a, r, et, q, lane, hid, sT, s_S, acc, xr0, prof_prev);
   }
