@@ -27,7 +27,32 @@
 #pragma unroll 1
   for (int et = 0; et < n_et; ++et) {
     __syncthreads();                               // readers of the previous pass's factors are done
-    for (int idx = tid; idx < NB * 32; idx += 256) {
+    // operands of the pass's three node tiles (see GEMM1 below) and the packed first layer: requested now, consumed after the staging
+    float w1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w1[s] = a.w1n[(q * 16 + s) * 64 + lane];
+    constexpr int SBLK = MODE == DP_EDGES_L2P ? 2 : 1, GBLK = MODE == DP_EDGES_L2P ? 1 : 2;      // attr block of the scatter / gather node
+    f4u nt4[3];
+    float nt1[3];
+    {
+      const float* s_tab = MODE == DP_EDGES_L2P ? a.attr2_tab : a.attr1_tab;
+      const float* g_tab = MODE == DP_EDGES_L2P ? a.attr1_tab : a.attr2_tab;
+      const int s_stride = MODE == DP_EDGES_L2P ? a.attr2_stride : a.attr1_stride, g_stride = MODE == DP_EDGES_L2P ? a.attr1_stride : a.attr2_stride;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int e0 = 32 * et + 16 * t2 + c;
+        const int grow = (MODE == DP_EDGES_P2L ? r.p0 : r.l0) + (e0 < r.En ? e0 : 0);
+        const float* rowp = g_tab + (size_t)grow * g_stride + 5 * g;
+        nt4[t2] = *reinterpret_cast<const f4u*>(rowp);
+        nt1[t2] = rowp[4];
+      }
+      const int srow = r.n_lo + (c < r.n_loc ? c : 0);
+      const float* rowp = s_tab + (size_t)srow * s_stride + 5 * g;
+      nt4[2] = *reinterpret_cast<const f4u*>(rowp);
+      nt1[2] = rowp[4];
+    }
+#pragma unroll
+    for (int idx = tid; idx < NB * 32; idx += 256) {          // two rounds, unrolled: both rounds' row loads travel together
       const int nn = idx >> 5, el = idx & 31, e = 32 * et + el;
       bool ok = nn < r.n_loc && e < r.En;
       int frow = 0;
@@ -66,16 +91,7 @@
     // to 5 (+ 1 mask step).  u_g comes out of the MFMA in exactly the D-fragment layout of the edge tiles (rows = the pass's gather
     // nodes = its edge slots), u_s is broadcast over rows through 1 KiB of the (idle) T buffer.
     float hid[NB][8];
-    float w1[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) w1[s] = a.w1n[(q * 16 + s) * 64 + lane];
-    constexpr int SBLK = MODE == DP_EDGES_L2P ? 2 : 1, GBLK = MODE == DP_EDGES_L2P ? 1 : 2;      // attr block of the scatter / gather node
-    const float* s_tab = MODE == DP_EDGES_L2P ? a.attr2_tab : a.attr1_tab;
-    const float* g_tab = MODE == DP_EDGES_L2P ? a.attr1_tab : a.attr2_tab;
-    const int s_stride = MODE == DP_EDGES_L2P ? a.attr2_stride : a.attr1_stride, g_stride = MODE == DP_EDGES_L2P ? a.attr1_stride : a.attr2_stride;
-    auto node_tile = [&](const float* rowp, int blk, bool bias) {
-      const f4u v4 = *reinterpret_cast<const f4u*>(rowp + 5 * g);
-      const float v1 = rowp[5 * g + 4];
+    auto node_tile = [&](const f4u& v4, float v1, int blk, bool bias) {
       f32x4 D = {0.f, 0.f, 0.f, 0.f};
       D = mfma16(v4.x, w1[5 * blk + 0], D);
       D = mfma16(v4.y, w1[5 * blk + 1], D);
@@ -86,21 +102,8 @@
       return D;
     };
     f32x4 ug[2];                                               // u_g of the pass's 32 edge slots: register rr <-> slot 16 t2 + 4 g + rr
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      const int e0 = 32 * et + 16 * t2 + c;
-      const int grow = (MODE == DP_EDGES_P2L ? r.p0 : r.l0) + (e0 < r.En ? e0 : 0);
-      ug[t2] = node_tile(g_tab + (size_t)grow * g_stride, GBLK, false);
-    }
-    {
-      const int srow = r.n_lo + (c < r.n_loc ? c : 0);
-      const f32x4 us = node_tile(s_tab + (size_t)srow * s_stride, SBLK, true);            // + fc.0 bias (and the constant-one unit)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) sT[(4 * g + rr) * 16 + c] = us[rr];                   // [node][k]: read back as a broadcast over rows
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // edge part: five consecutive floats of edge_emb per lane group; the loads of step i + 2 are issued before the MFMAs of step i
-    // (steps = 16 nodes x 2 tiles).  An edge that does not exist (e >= En, or no radius / bond edge for the pair) gets -1e30 added to
+    // edge part: five consecutive floats of edge_emb per lane group; the loads of step i + PF are issued before the MFMAs of step i
+    // (steps = 16 nodes x 2 tiles; a step is only 6 MFMAs, so the requests have to run several steps ahead of an L2 / HBM round trip).  An edge that does not exist (e >= En, or no radius / bond edge for the pair) gets -1e30 added to
     // every pre-activation by the mask step (A = -1e30 in lane group 0, B = ones): its hidden vector - constant-one unit included -
     // is exactly 0 and it drops out of T.
     const float bone = g == 0 ? 1.f : 0.f;
@@ -138,44 +141,52 @@
 #endif
       return D;
     };
-    f4u a4, b4, n4;
-    float a1, b1, n1, am, bm, nm;
-    load_av(0, a4, a1, am, 0);
-    load_av(1, b4, b1, bm, 0);
+    constexpr int PF = 4;                                      // steps the edge operands are requested ahead (ring of PF + 1 register sets)
+    f4u e4[PF + 1];
+    float e1[PF + 1], em[PF + 1];
+#pragma unroll
+    for (int s0 = 0; s0 < PF; ++s0) load_av(s0, e4[s0], e1[s0], em[s0], 0);
+    // the three node tiles, while those requests travel
+    ug[0] = node_tile(nt4[0], nt1[0], GBLK, false);
+    ug[1] = node_tile(nt4[1], nt1[1], GBLK, false);
+    {
+      const f32x4 us = node_tile(nt4[2], nt1[2], SBLK, true);                              // + fc.0 bias (and the constant-one unit)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) sT[(4 * g + rr) * 16 + c] = us[rr];                   // [node][k]: read back as a broadcast over rows
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float xr0[3][8];
     float us_cur = sT[c], us_nxt = 0.f;
 #pragma unroll
     for (int step = 0; step < 2 * NB; ++step) {
       const int nn = step >> 1, t2 = step & 1;
-      if (step + 2 < 2 * NB) load_av(step + 2, n4, n1, nm, 0);   // two steps ahead
+      if (step + PF < 2 * NB) load_av(step + PF, e4[(step + PF) % (PF + 1)], e1[(step + PF) % (PF + 1)], em[(step + PF) % (PF + 1)], 0);
       if (t2 == 0 && nn + 1 < NB) us_nxt = sT[(nn + 1) * 16 + c];
       if (step == 2 * NB - 3) load_x<KIND, MODE, P0>(a, r, et, lane, 0, xr0);   // first column tile's operands: behind the last emb request
-      const f32x4 D = gemm1(a4, a1, am, us_cur, ug[t2]);
+      const f32x4 D = gemm1(e4[step % (PF + 1)], e1[step % (PF + 1)], em[step % (PF + 1)], us_cur, ug[t2]);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] = fmaxf(D[rr], 0.f);
       __builtin_amdgcn_sched_barrier(0);
-      a4 = b4; a1 = b1; am = bm;
-      b4 = n4; b1 = n1; bm = nm;
       if (t2 == 1) us_cur = us_nxt;
     }
     if constexpr (MODE == LL) {
       // second GEMM1 over the bond edges of the same pairs (1-4 per atom): skipped per 16-pair tile when none of them is bonded;
-      // the operands of step + 1 are requested before step's MFMAs
-      load_av(0, a4, a1, am, 1);
+      // same operand ring
+#pragma unroll
+      for (int s0 = 0; s0 < PF; ++s0) load_av(s0, e4[s0], e1[s0], em[s0], 1);
       us_cur = sT[c];
 #pragma unroll
       for (int step = 0; step < 2 * NB; ++step) {
         const int nn = step >> 1, t2 = step & 1;
-        if (step + 1 < 2 * NB) load_av(step + 1, n4, n1, nm, 1);
+        if (step + PF < 2 * NB) load_av(step + PF, e4[(step + PF) % (PF + 1)], e1[(step + PF) % (PF + 1)], em[(step + PF) % (PF + 1)], 1);
         if (t2 == 0 && nn + 1 < NB) us_nxt = sT[(nn + 1) * 16 + c];
         // lane group 0 carries the validity of the tile's 16 pairs (msk == 0 <=> bonded)
-        if (__builtin_amdgcn_ballot_w64(g == 0 && am == 0.f) != 0) {
-          const f32x4 D = gemm1(a4, a1, am, us_cur, ug[t2]);
+        if (__builtin_amdgcn_ballot_w64(g == 0 && em[step % (PF + 1)] == 0.f) != 0) {
+          const f32x4 D = gemm1(e4[step % (PF + 1)], e1[step % (PF + 1)], em[step % (PF + 1)], us_cur, ug[t2]);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) hid[nn][4 * t2 + rr] += fmaxf(D[rr], 0.f);
         }
         __builtin_amdgcn_sched_barrier(0);
-        a4 = n4; a1 = n1; am = nm;
         if (t2 == 1) us_cur = us_nxt;
       }
     }
@@ -188,21 +199,35 @@
   __syncthreads();
   AccStore<KIND, 0>::run(acc, s_T + q * (NB * S::D_OUT), lane);
   __syncthreads();
-  for (int i = tid; i < r.n_loc * S::D_OUT; i += 256) {
+  // fixed trip count, unrolled: the rounds' table / residual loads are independent and travel together (a rolled loop waits a full global
+  // round trip per round)
+  constexpr int EP_ROUNDS = (NB * S::D_OUT + 255) / 256;
+  float ev[EP_ROUNDS], er[EP_ROUNDS], es[EP_ROUNDS], eb[EP_ROUNDS];
+  int edeg[EP_ROUNDS];
+#pragma unroll
+  for (int it = 0; it < EP_ROUNDS; ++it) {
+    const int i = tid + 256 * it;
+    const bool live = i < r.n_loc * S::D_OUT;
     const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
-    if (SIDE >= 0 && kChanOwner<KIND>.v[ch] != SIDE) continue;
-    const int node = r.n_lo + n;
-    const int deg = MODE == LL ? a.rowend[node] - a.rowptr[node] : r.En;       // scatter MEAN over the node's edges (torch_scatter: / max(count, 1))
-    float v = ((s_T[i] + s_T[NB * S::D_OUT + i]) + s_T[2 * NB * S::D_OUT + i]) + s_T[3 * NB * S::D_OUT + i];
-    v = v / (float)max(deg, 1);
-    v = v * a.bn_scale[ch] + a.bn_shift[ch];
-    float* o = a.out + (size_t)node * a.out_stride + ch;
-    if (a.accumulate) {
-      *o += v;
-    } else {
-      if (a.resid != nullptr && ch < a.resid_width) v += a.resid[(size_t)node * a.resid_stride + ch];
-      *o = v;
-    }
+    const bool mine = live && (SIDE < 0 || kChanOwner<KIND>.v[live ? ch : 0] == SIDE);
+    const int node = r.n_lo + (live ? n : 0);
+    edeg[it] = MODE == LL ? a.rowend[node] - a.rowptr[node] : r.En;          // scatter MEAN over the node's edges (torch_scatter: / max(count, 1))
+    es[it] = a.bn_scale[live ? ch : 0];
+    eb[it] = a.bn_shift[live ? ch : 0];
+    const float* src = a.accumulate ? a.out + (size_t)node * a.out_stride + (live ? ch : 0)
+                                    : (a.resid != nullptr && live && ch < a.resid_width ? a.resid + (size_t)node * a.resid_stride + ch : nullptr);
+    er[it] = (mine && src != nullptr) ? *src : 0.f;
+    ev[it] = live ? ((s_T[i] + s_T[NB * S::D_OUT + i]) + s_T[2 * NB * S::D_OUT + i]) + s_T[3 * NB * S::D_OUT + i] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < EP_ROUNDS; ++it) {
+    const int i = tid + 256 * it;
+    const bool live = i < r.n_loc * S::D_OUT;
+    const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
+    if (!live || (SIDE >= 0 && kChanOwner<KIND>.v[ch] != SIDE)) continue;
+    float v = ev[it] / (float)max(edeg[it], 1);
+    v = v * es[it] + eb[it];
+    a.out[(size_t)(r.n_lo + n) * a.out_stride + ch] = er[it] + v;
   }
   NPROF(4);
 #ifdef DP_PROF
