@@ -51,6 +51,34 @@
       nt4[2] = *reinterpret_cast<const f4u*>(rowp);
       nt1[2] = rowp[4];
     }
+    const float bone = g == 0 ? 1.f : 0.f;
+    auto load_av = [&](int step, f4u& v4, float& v1, float& msk, int which) {
+      int nn_o = step >> 1;                          // opaque copy: keeps the 16 nodes' row pointers from being hoisted out of the pass loop (spills)
+      asm volatile("" : "+s"(nn_o));
+      const int node = r.n_lo + (nn_o < r.n_loc ? nn_o : 0);
+      const int e0 = 32 * et + 16 * (step & 1) + c;  // GEMM1 view: lane (g, c) feeds emb[edge c][group g]
+      bool ok = e0 < r.En;
+      const int e = ok ? e0 : 0;
+      int frow;
+      if constexpr (MODE == LL) {
+        frow = s_pair[which * (NB * 32) + nn_o * 32 + 16 * (step & 1) + c];        // -1: no such node / pair / edge of this kind
+        ok = frow >= 0;
+        frow = ok ? frow : 0;
+      } else {
+        frow = feat_row<MODE>(r, node, e);
+      }
+      const float* pe = a.edge_emb + (size_t)frow * 20 + 5 * g;
+      v4 = *reinterpret_cast<const f4u*>(pe);
+      v1 = pe[4];
+      msk = (!ok && g == 0) ? -1e30f : 0.f;
+    };
+    constexpr int PF = 4;                                      // steps the edge operands are requested ahead (ring of PF + 1 register sets)
+    f4u e4[PF + 1];
+    float e1[PF + 1], em[PF + 1];
+    if constexpr (MODE != LL) {                                // dense modes: edge rows are arithmetic, the first requests can leave now
+#pragma unroll
+      for (int s0 = 0; s0 < PF; ++s0) load_av(s0, e4[s0], e1[s0], em[s0], 0);
+    }
 #pragma unroll
     for (int idx = tid; idx < NB * 32; idx += 256) {          // two rounds, unrolled: both rounds' row loads travel together
       const int nn = idx >> 5, el = idx & 31, e = 32 * et + el;
@@ -106,27 +134,6 @@
     // (steps = 16 nodes x 2 tiles; a step is only 6 MFMAs, so the requests have to run several steps ahead of an L2 / HBM round trip).  An edge that does not exist (e >= En, or no radius / bond edge for the pair) gets -1e30 added to
     // every pre-activation by the mask step (A = -1e30 in lane group 0, B = ones): its hidden vector - constant-one unit included -
     // is exactly 0 and it drops out of T.
-    const float bone = g == 0 ? 1.f : 0.f;
-    auto load_av = [&](int step, f4u& v4, float& v1, float& msk, int which) {
-      int nn_o = step >> 1;                          // opaque copy: keeps the 16 nodes' row pointers from being hoisted out of the pass loop (spills)
-      asm volatile("" : "+s"(nn_o));
-      const int node = r.n_lo + (nn_o < r.n_loc ? nn_o : 0);
-      const int e0 = 32 * et + 16 * (step & 1) + c;  // GEMM1 view: lane (g, c) feeds emb[edge c][group g]
-      bool ok = e0 < r.En;
-      const int e = ok ? e0 : 0;
-      int frow;
-      if constexpr (MODE == LL) {
-        frow = s_pair[which * (NB * 32) + nn_o * 32 + 16 * (step & 1) + c];        // -1: no such node / pair / edge of this kind
-        ok = frow >= 0;
-        frow = ok ? frow : 0;
-      } else {
-        frow = feat_row<MODE>(r, node, e);
-      }
-      const float* pe = a.edge_emb + (size_t)frow * 20 + 5 * g;
-      v4 = *reinterpret_cast<const f4u*>(pe);
-      v1 = pe[4];
-      msk = (!ok && g == 0) ? -1e30f : 0.f;
-    };
     auto gemm1 = [&](const f4u& v4, float v1, float msk, float usn, const f32x4& ugt) {
       f32x4 D = {usn + ugt[0], usn + ugt[1], usn + ugt[2], usn + ugt[3]};
 #if DP_NABL != 6
@@ -141,11 +148,10 @@
 #endif
       return D;
     };
-    constexpr int PF = 4;                                      // steps the edge operands are requested ahead (ring of PF + 1 register sets)
-    f4u e4[PF + 1];
-    float e1[PF + 1], em[PF + 1];
+    if constexpr (MODE == LL) {                                // (the dense modes' first requests left before the staging)
 #pragma unroll
-    for (int s0 = 0; s0 < PF; ++s0) load_av(s0, e4[s0], e1[s0], em[s0], 0);
+      for (int s0 = 0; s0 < PF; ++s0) load_av(s0, e4[s0], e1[s0], em[s0], 0);
+    }
     // the three node tiles, while those requests travel
     ug[0] = node_tile(nt4[0], nt1[0], GBLK, false);
     ug[1] = node_tile(nt4[1], nt1[1], GBLK, false);
@@ -196,13 +202,10 @@
   }
 
   // ---- sum the four k-partials, mean, BatchNorm affine, residual stream ------------------------------------------------------------
-  __syncthreads();
-  AccStore<KIND, 0>::run(acc, s_T + q * (NB * S::D_OUT), lane);
-  __syncthreads();
-  // fixed trip count, unrolled: the rounds' table / residual loads are independent and travel together (a rolled loop waits a full global
-  // round trip per round)
+  // epilogue operands (degree, BatchNorm affine, residual / previous output): fixed trip count, unrolled and requested BEFORE the partial
+  // sums go through LDS, so the rounds' loads travel together and behind the reduction
   constexpr int EP_ROUNDS = (NB * S::D_OUT + 255) / 256;
-  float ev[EP_ROUNDS], er[EP_ROUNDS], es[EP_ROUNDS], eb[EP_ROUNDS];
+  float er[EP_ROUNDS], es[EP_ROUNDS], eb[EP_ROUNDS];
   int edeg[EP_ROUNDS];
 #pragma unroll
   for (int it = 0; it < EP_ROUNDS; ++it) {
@@ -217,15 +220,18 @@
     const float* src = a.accumulate ? a.out + (size_t)node * a.out_stride + (live ? ch : 0)
                                     : (a.resid != nullptr && live && ch < a.resid_width ? a.resid + (size_t)node * a.resid_stride + ch : nullptr);
     er[it] = (mine && src != nullptr) ? *src : 0.f;
-    ev[it] = live ? ((s_T[i] + s_T[NB * S::D_OUT + i]) + s_T[2 * NB * S::D_OUT + i]) + s_T[3 * NB * S::D_OUT + i] : 0.f;
   }
+  __syncthreads();
+  AccStore<KIND, 0>::run(acc, s_T + q * (NB * S::D_OUT), lane);
+  __syncthreads();
 #pragma unroll
   for (int it = 0; it < EP_ROUNDS; ++it) {
     const int i = tid + 256 * it;
     const bool live = i < r.n_loc * S::D_OUT;
     const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
     if (!live || (SIDE >= 0 && kChanOwner<KIND>.v[ch] != SIDE)) continue;
-    float v = ev[it] / (float)max(edeg[it], 1);
+    const float part = ((s_T[i] + s_T[NB * S::D_OUT + i]) + s_T[2 * NB * S::D_OUT + i]) + s_T[3 * NB * S::D_OUT + i];
+    float v = part / (float)max(edeg[it], 1);
     v = v * es[it] + eb[it];
     a.out[(size_t)(r.n_lo + n) * a.out_stride + ch] = er[it] + v;
   }
