@@ -86,8 +86,12 @@ def main():
         L.dp_tp_conv(C.byref(args), st)
         torch.cuda.synchronize()
         L.dp_debug_prof_node(buf, 0)
-        tot = sum(buf[:5]) or 1
-        for n, v in zip(["sh staging+barriers", "GEMM1", "GEMM-A (+operand fetch)", "GEMM-B", "reduce+epilogue"], buf[:5]):
+        tot = sum(buf[:11]) or 1
+        names = ["staging: 2nd barrier (or whole staging)", "GEMM1", "GEMM-A (+operand fetch)", "GEMM-B", "reduce (or whole epilogue)",
+                 "pass top: barrier", "pass top: operand requests", "staging loop", "epilogue: operand requests + barrier", "AccStore", "epilogue: 2nd barrier"]
+        for n, v in zip(names, buf[:11]):
+            if v == 0:
+                continue
             print(f"  {n:24s} {v:14d} ticks  {100.0 * v / tot:5.1f} %")
     elif a.prof:
         buf = (C.c_ulonglong * 16)()
