@@ -55,14 +55,22 @@ def main():
         if a.only >= 0 and bi != a.only:
             continue
         osampler.set_time_phore(batch, t, t, t, batch.num_graphs)
+        om.track_margins, om.margins = True, {}            # per pose: how close its discontinuous decisions are to a tie
         tr_o, rot_o, tor_o = om(batch)
+        om.track_margins = False
+        margin = np.min(np.stack([np.asarray(v, dtype=np.float64) for v in om.margins.values()]), axis=0)
         tr, rot, tor = m(batch)
         e = dict(tr=rel(tr, tr_o), rot=rel(rot, rot_o), tor=rel(tor, tor_o) if tor_o.numel() else 0.0)
         shapes = [(int(g["ligand"].pos.shape[0]), int(g["ligand"].edge_mask.sum()), int(g["phore"].pos.shape[0])) for g in gs]
-        flag = "" if max(e.values()) < 3e-4 and np.isfinite(list(e.values())).all() else "   <<<<<<"
+        bad = not (max(e.values()) < 3e-4 and np.isfinite(list(e.values())).all())
+        # a deviation is a finding only if no pose of the batch sits on a tie (margin within fp32 rounding of the decision, the tests'
+        # MARGIN_FP32): there the fp32 arithmetic may legitimately take the other branch (tests/test_forward_gpu.py)
+        tie = bool((margin < 1e-5).any())
+        flag = "" if not bad else ("   (tie: decision margin %.1e)" % margin.min() if tie else "   <<<<<<")
         print(f"batch {bi:3d} t={t:.2f} shapes={shapes} err tr {e['tr']:.1e} rot {e['rot']:.1e} tor {e['tor']:.1e}{flag}", flush=True)
-        for k in worst:
-            worst[k] = max(worst[k], e[k])
+        if not (bad and tie):
+            for k in worst:
+                worst[k] = max(worst[k], e[k])
         if a.only >= 0:
             om32 = OracleScoreModel(sd, config.ModelConfig(), dtype=torch.float32, tables=load_tables())
             b2 = Batch.from_data_list(gs)
@@ -72,6 +80,15 @@ def main():
             print("per-pose |rot - rot_oracle64|:", (rot.cpu().double() - rot_o).abs().max(1).values.numpy(), " oracle32 vs 64:", (rot32.double() - rot_o).abs().max(1).values.numpy())
             print("tr_o:", tr_o.numpy(), "\nrot_o:", rot_o.numpy())
             print("nan in oracle:", bool(torch.isnan(tr_o).any()), " nan in hip:", bool(torch.isnan(tr).any()))
+            # how close each pose's discontinuous decisions are to a tie (oracle/model.py::track_margins): a pose that deviates although
+            # the fp32 oracle does not is expected to show a margin within fp32 rounding (~1e-6 relative) here
+            om.track_margins, om.margins = True, {}
+            b3 = Batch.from_data_list(gs)
+            osampler.set_time_phore(b3, t, t, t, b3.num_graphs)
+            om(b3)
+            for name, v in om.margins.items():
+                print(f"margin {name:12s}", np.asarray(v, dtype=np.float64))
+            om.track_margins = False
     print("worst:", worst)
 
 
