@@ -558,3 +558,20 @@ def test_configs0_real_example_inputs(golden_dir, monkeypatch):
         for s_ in range(N):
             np.testing.assert_allclose(np.linalg.norm(pos[s_][ei[0]] - pos[s_][ei[1]], axis=1), d0, atol=5e-4)
         assert np.abs(pos[0] - pos[1]).max() > 1e-2
+
+
+@pytest.mark.parametrize("algo", ["node", "edge"])
+def test_random_shapes_soak(algo, monkeypatch):
+    """tools/fuzz_shapes.py as a test: random ragged batches (ligands of 2-70 atoms = up to three ligand-ligand passes of the node-side
+    kernel, pharmacophores of 7-110 nodes = up to four cross passes) through the HIP forward vs the fp64 oracle.  A batch may deviate
+    only if the oracle recorded a decision margin within fp32 rounding for one of its poses (a tie: either branch is legitimate)."""
+    import importlib.util
+    import os
+    import types
+    spec = importlib.util.spec_from_file_location("fuzz_shapes", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_shapes.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
+    worst, findings = fz.run(types.SimpleNamespace(batches=8, seed=1234, precision="f32", only=-1))
+    assert not findings, findings
+    assert max(worst.values()) < 3e-4, worst

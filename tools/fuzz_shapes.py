@@ -33,6 +33,12 @@ def main():
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--only", type=int, default=-1, help="evaluate only this batch index (same random sequence), with per-pose detail")
     a = ap.parse_args()
+    run(a)
+
+
+def run(a):
+    """-> (worst relative errors over batches without a decision tie, list of findings = deviating batches without a tie)."""
+    findings = []
     rng = np.random.default_rng(a.seed)
     sd = weights.init_state_dict()
     om = OracleScoreModel(sd, config.ModelConfig(), dtype=torch.float64, tables=load_tables())
@@ -67,6 +73,8 @@ def main():
         # MARGIN_FP32): there the fp32 arithmetic may legitimately take the other branch (tests/test_forward_gpu.py)
         tie = bool((margin < 1e-5).any())
         flag = "" if not bad else ("   (tie: decision margin %.1e)" % margin.min() if tie else "   <<<<<<")
+        if bad and not tie:
+            findings.append((bi, shapes, e))
         print(f"batch {bi:3d} t={t:.2f} shapes={shapes} err tr {e['tr']:.1e} rot {e['rot']:.1e} tor {e['tor']:.1e}{flag}", flush=True)
         if not (bad and tie):
             for k in worst:
@@ -90,6 +98,7 @@ def main():
                 print(f"margin {name:12s}", np.asarray(v, dtype=np.float64))
             om.track_margins = False
     print("worst:", worst)
+    return worst, findings
 
 
 if __name__ == "__main__":
