@@ -378,7 +378,7 @@ struct PathStage {
               z[rr] = zz;
             }
           };
-          // explicit ring buffers, no register copies between steps: the factors of step qs live in sv[qs % 3], its z in z[qs & 1]
+          // explicit ring buffers, no register copies between steps: the factors of step qs live in sv[qs % RD], its z in z[qs & 1]
           // (with a two-name rotation the allocator reused the registers a step's VALU still reads for that step's prefetch, which
           // forbids "reads first" and collapsed every second step's interleave into MFMA x4 followed by all of the VALU)
           auto makeZ1 = [&](int t2, int rr, const f32x4 (&sv)[NTERM]) {
@@ -387,10 +387,13 @@ struct PathStage {
             for (int t = 1; t < NTERM; ++t) zz = fmaf(xa[t][4 * t2 + rr], sv[t][rr], zz);
             return zz;
           };
-          f32x4 sv[3][NTERM];
+          // ring depth / prefetch distance of the factor reads: two steps ahead, one for the three-term paths (12 fewer live registers
+          // where the pressure peaks: fewer accumulator spills across path turns, ~1 % on the layer-3 launch)
+          constexpr int RD = NTERM == 3 ? 2 : 3, PD = RD - 1;
+          f32x4 sv[RD][NTERM];
           float z[2][4];
           loadS(0, sv[0]);
-          loadS(1, sv[1]);
+          if (PD > 1) loadS(1, sv[1]);
           makeZ(0, sv[0], z[0]);
           __builtin_amdgcn_sched_barrier(0);
           f32x4 D[2];
@@ -398,7 +401,7 @@ struct PathStage {
 #pragma unroll
           for (int qs = 0; qs < 2 * NB; ++qs) {
             const int nn = qs >> 1, t2 = qs & 1;
-            if (qs + 2 < 2 * NB) loadS(qs + 2, sv[(qs + 2) % 3]);
+            if (qs + PD < 2 * NB) loadS(qs + PD, sv[(qs + PD) % RD]);
             if (t2 == 0) D[nn & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
             // source order = issue order wanted: MFMA rr, then the z value of the next step's K-step rr (one mul / fma chain)
 #pragma unroll
@@ -408,7 +411,7 @@ struct PathStage {
 #else
               D[nn & 1] = mfma16(hid[nn][4 * t2 + rr], z[qs & 1][rr], D[nn & 1]);
 #endif
-              if (qs + 1 < 2 * NB) z[(qs + 1) & 1][rr] = makeZ1((qs + 1) & 1, rr, sv[(qs + 1) % 3]);
+              if (qs + 1 < 2 * NB) z[(qs + 1) & 1][rr] = makeZ1((qs + 1) & 1, rr, sv[(qs + 1) % RD]);
             }
             // the finished tile of the PREVIOUS node is stored one step late, behind this step's first MFMA: its last MFMA has long retired
 #if DP_NABL == 2
@@ -416,7 +419,7 @@ struct PathStage {
 #else
             if (t2 == 0 && nn > 0) *reinterpret_cast<f32x4*>(tslot(nn - 1)) = D[(nn - 1) & 1];
 #endif
-            if (qs + 2 < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, NTERM, 0);       // the prefetch reads go first
+            if (qs + PD < 2 * NB) __builtin_amdgcn_sched_group_barrier(0x100, NTERM, 0);      // the prefetch reads go first
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // one MFMA ...
