@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--conv-algo", default=None, choices=["edge", "node"], help="fused conv formulation (default: library default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the informational passes at other precisions / formulations")
     ap.add_argument("--no-e2e", action="store_true", help="skip the drop-in sampling_phore() end-to-end pass")
+    ap.add_argument("--no-other", action="store_true", help="skip the short passes over the other BASELINE configs (default run only)")
     ap.add_argument("--cpu-poses", type=int, default=20)
     ap.add_argument("--cpu-steps", type=int, default=4)
     a = ap.parse_args()
@@ -220,77 +221,102 @@ def main():
                                                                   "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
     units = (a.poses if a.config in (1, 2, 3) else a.units) or workloads.DEFAULT_UNITS[a.config]
     precision = a.precision or ("bf16x3" if a.config == 5 else "f32")
-    graphs, _mine = workloads.build(a.config, units, rank, world)
-    S_total = workloads.steps_of(a.config)
     sd = weights.init_state_dict()
-    model = DeviceModel(sd, cfg, dev, precision=precision)
-    if world > 1:
-        # the only collective of the job: weights from rank 0 to every GPU over xGMI
-        dist.broadcast(model.blob, src=0)
-        torch.cuda.synchronize()
-    # initial state: randomize_position on the device (same call the sampler's callers make, inference.py:185)
-    np.random.seed(607201 + rank)
-    torch.manual_seed(607201 + rank)
-    randomize_position(graphs, False, False, cfg.tr_sigma_max, device=dev)
-    pb0 = PackedBatch(graphs, dev)
-    pos0, norm0 = pb0.pos.clone(), pb0.norm.clone()
-    sched = get_t_schedule(S_total)
+    models = {}
+
+    def model_for(prec):
+        if prec not in models:
+            models[prec] = DeviceModel(sd, cfg, dev, precision=prec)
+            if world > 1:
+                # the only collective of the job: weights from rank 0 to every GPU over xGMI
+                dist.broadcast(models[prec].blob, src=0)
+                torch.cuda.synchronize()
+        return models[prec]
+
+    class Workload:
+        """One BASELINE config on this rank: poses packed on the device, randomised start state, schedule, pre-drawn noise."""
+
+        def __init__(self, config, n_units):
+            self.config, self.units = config, n_units
+            self.graphs, _mine = workloads.build(config, n_units, rank, world)
+            self.S_total = workloads.steps_of(config)
+            # initial state: randomize_position on the device (same call the sampler's callers make, inference.py:185)
+            np.random.seed(607201 + rank)
+            torch.manual_seed(607201 + rank)
+            randomize_position(self.graphs, False, False, cfg.tr_sigma_max, device=dev)
+            self.pb = PackedBatch(self.graphs, dev)
+            self.pos0, self.norm0 = self.pb.pos.clone(), self.pb.norm.clone()
+            self.sched = get_t_schedule(self.S_total)
+            gen = torch.Generator(device=dev).manual_seed(607201 + rank)
+            self.B, self.nT = self.pb.B, int(self.pb.tor_ptr[-1])
+            B, nT, S = self.B, self.nT, self.S_total
+            # pre-drawn noise resident in HBM (the reference draws it on the host inside the loop, sampling.py:230-243); one set per step
+            self.zs = [(torch.randn(B, 3, device=dev, generator=gen), torch.randn(B, 3, device=dev, generator=gen),
+                        torch.randn(max(nT, 1), device=dev, generator=gen)) for _ in range(S)]
+            self.sps = [_step_params(t, S, self.sched, self.sched, self.sched, t2s, margs, False, False) for t in range(S)]
+            self.T_dev = torch.tensor([[float(self.sched[t])] * 3 for t in range(S)], dtype=torch.float32, device=dev)   # diffusion times, resident
+
+        def timed_run(self, mdl, conv_algo, steps, warmup, prof=True):
+            pb, B, S_total, zs, sps, nT = self.pb, self.B, self.S_total, self.zs, self.sps, self.nT
+            eng = Engine(mdl, pb, conv_algo=conv_algo)
+            ev = HipEvents(steps if prof else 0)
+
+            def reset():
+                pb.pos.copy_(self.pos0)
+                pb.norm.copy_(self.norm0)
+                eng.ws.t["status"].zero_()
+
+            def step(i, prof_idx=None):
+                t_idx = i % S_total
+                if t_idx == 0:
+                    reset()
+                pb.t.copy_(self.T_dev[t_idx].expand(B, 3))
+                w = eng.ws.struct
+                if prof_idx is None:
+                    w.prof_start, w.prof_stop = None, None
+                else:
+                    s0, s1 = ev.pair(prof_idx)
+                    w.prof_start, w.prof_stop, w.prof_layer, w.prof_conv = s0, s1, PROF_LAYER, PROF_CONV
+                z = zs[t_idx]
+                eng.sample_step(sps[t_idx], z[0], z[1], z[2] if nT else None)
+
+            for i in range(warmup):
+                step(i)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i, prof_idx=i if prof else None)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                te = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                el = float(te.item())
+            nbad = int((eng.ws.t["status"] != 0).sum().item())
+            fin = bool(torch.isfinite(pb.pos).all().item())
+            kms = float(np.nanmean([ev.ms(i) for i in range(steps)])) if prof else float("nan")
+            ev.destroy()
+            # edge counts of the last forward (the radius graphs depend on the poses): per-slot TF/s in profiles/*_conv_slots.csv
+            t = eng.ws.t
+            self.edge_counts = {"x": int(pb.x_ptr[-1]), "pp": int(pb.pp_ptr[-1]), "center": int(pb.lig_ptr[-1]),
+                                "ll": int((t["ll_rowend"] - t["ll_rowptr"]).sum().item()),
+                                "tor": int((t["t_rowend"] - t["t_rowptr"])[:max(nT, 0)].sum().item()) if nT else 0}
+            return el, kms, nbad, fin, eng.conv_algo
+
     t2s = t_to_sigma_fn(margs)
-    gen = torch.Generator(device=dev).manual_seed(607201 + rank)
-    B, nT = pb0.B, int(pb0.tor_ptr[-1])
-    # pre-drawn noise resident in HBM (the reference draws it on the host inside the loop, sampling.py:230-243); one set per schedule step
-    zs = [(torch.randn(B, 3, device=dev, generator=gen), torch.randn(B, 3, device=dev, generator=gen),
-           torch.randn(max(nT, 1), device=dev, generator=gen)) for _ in range(S_total)]
-    sps = [_step_params(t, S_total, sched, sched, sched, t2s, margs, False, False) for t in range(S_total)]
-    T_dev = torch.tensor([[float(sched[t])] * 3 for t in range(S_total)], dtype=torch.float32, device=dev)   # diffusion times, resident
+    wl = Workload(a.config, units)
+    graphs, S_total, pb0, B, nT = wl.graphs, wl.S_total, wl.pb, wl.B, wl.nT
+    sched = wl.sched
+    model = model_for(precision)
 
     def timed_run(mdl, conv_algo=None):
-        pb = pb0
-        eng = Engine(mdl, pb, conv_algo=conv_algo)
-        ev = HipEvents(a.steps)
-
-        def reset():
-            pb.pos.copy_(pos0)
-            pb.norm.copy_(norm0)
-            eng.ws.t["status"].zero_()
-
-        def step(i, prof_idx=None):
-            t_idx = i % S_total
-            if t_idx == 0:
-                reset()
-            pb.t.copy_(T_dev[t_idx].expand(B, 3))
-            w = eng.ws.struct
-            if prof_idx is None:
-                w.prof_start, w.prof_stop = None, None
-            else:
-                s0, s1 = ev.pair(prof_idx)
-                w.prof_start, w.prof_stop, w.prof_layer, w.prof_conv = s0, s1, PROF_LAYER, PROF_CONV
-            z = zs[t_idx]
-            eng.sample_step(sps[t_idx], z[0], z[1], z[2] if nT else None)
-
-        for i in range(a.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            step(i, prof_idx=i)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            te = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            el = float(te.item())
-        nbad = int((eng.ws.t["status"] != 0).sum().item())
-        fin = bool(torch.isfinite(pb.pos).all().item())
-        kms = float(np.nanmean([ev.ms(i) for i in range(a.steps)]))
-        ev.destroy()
-        return el, kms, nbad, fin, eng.conv_algo
+        return wl.timed_run(mdl, conv_algo, a.steps, a.warmup)
 
     elapsed, kern_ms, bad, finite, algo_used = timed_run(model, a.conv_algo)
     pb = pb0
@@ -308,10 +334,7 @@ def main():
                 ("bf16x9", None, "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
                 ("bf16x6", None, "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances")):
             try:
-                alt_model = model if prec == precision else DeviceModel(sd, cfg, dev, precision=prec)
-                if world > 1 and alt_model is not model:
-                    dist.broadcast(alt_model.blob, src=0)
-                el2, k2, bad2, fin2, algo2 = timed_run(alt_model, algo)
+                el2, k2, bad2, fin2, algo2 = timed_run(model_for(prec), algo)
             except Exception as e:      # noqa: BLE001 - an informational pass must never sink the headline line
                 alt.append({"precision": prec, "conv_algo": algo, "error": str(e)[:200]})
                 continue
@@ -319,7 +342,7 @@ def main():
                         "ms_per_step": el2 / a.steps * 1e3, "kernel_ms": k2, "finite": fin2, "kabsch_flagged_poses": bad2})
 
     e2e = None
-    if not a.no_e2e and world == 1 and a.config in (1, 2, 3):
+    if not a.no_e2e and world == 1:
         # secondary figure: the whole drop-in call sampling_phore(data_list, ...) - host packing of the HeteroData list, noise
         # draw + upload, device loop, write-back over PCIe - on the same poses (never `value`: that is HBM-resident)
         import copy
@@ -342,15 +365,32 @@ def main():
         del copy
 
     n_x = int(pb.x_ptr[-1])
-    # one forward's lig-lig edge count (the radius graph depends on the poses)
-    edge_counts = {"x": n_x, "pp": int(pb.pp_ptr[-1])}
-    try:
-        _e = Engine(model, pb)
-        _e.forward()
-        edge_counts["ll"] = int((_e.ws.t["ll_rowend"] - _e.ws.t["ll_rowptr"]).sum().item())
-        del _e
-    except Exception:      # noqa: BLE001 - informational only
-        pass
+    edge_counts = dict(wl.edge_counts)
+
+    other = None
+    if not a.no_other and a.config == 2 and a.precision is None and a.conv_algo is None and a.poses is None:
+        # every other BASELINE config in the same driver-run line (never the headline `value`): one short pass each at its default
+        # per-GPU size, library-default conv formulation, the config's own precision; one schedule wrap (config 5: the first 20 steps of
+        # its 100-step schedule), 3 warm-up steps
+        other = []
+        for c in (1, 3, 4, 5):
+            try:
+                t_b = time.perf_counter()
+                w2 = Workload(c, workloads.DEFAULT_UNITS[c])
+                prec_c = "bf16x3" if c == 5 else "f32"
+                n_steps = min(w2.S_total, 20)
+                el2, _k, bad2, fin2, algo2 = w2.timed_run(model_for(prec_c), None, n_steps, 3, prof=False)
+                tot = torch.tensor([w2.B], device=dev, dtype=torch.float64)
+                if dist is not None:
+                    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                other.append({"config": f"configs[{c - 1}]", "workload": workloads.describe(c, w2.units), "poses_per_gpu": w2.B,
+                              "poses_total": int(tot.item()), "precision": prec_c, "conv_algo": algo2, "steps": n_steps,
+                              "ms_per_step": el2 / n_steps * 1e3, "value": float(tot.item()) * n_steps / el2, "unit": "pose-steps/s",
+                              "finite": fin2, "kabsch_flagged_poses": bad2, "edge_counts": w2.edge_counts,
+                              "build_and_run_s": round(time.perf_counter() - t_b, 2)})
+                del w2
+            except Exception as e:      # noqa: BLE001 - an informational pass must never sink the headline line
+                other.append({"config": f"configs[{c - 1}]", "error": str(e)[:200]})
     alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
     flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * n_x
     if algo_used == "node":
@@ -386,7 +426,7 @@ def main():
                        "poses_per_gpu": B, "poses_total": total_poses, f"poses_per_sec_at_{S_total}_steps": total_poses * a.steps / elapsed / S_total,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
                        "kabsch_flagged_poses": bad, "finite": finite, "precision": precision, "conv_algo": algo_used,
-                       "edge_counts": edge_counts, "alt_runs": alt, "e2e": e2e},
+                       "edge_counts": edge_counts, "alt_runs": alt, "e2e": e2e, "other_configs": other},
             # The dominant kernel generates the per-edge TP weights on the matrix pipe in registers (they never reach HBM), so it is
             # bound by the fp32 matrix pipe; SURVEY.md 8d asks for both views when the radial MLP is fused into the TP kernel.
             # alg_flops_per_edge is the EDGE-SIDE count of SURVEY.md 8d (radial GEMM per edge); the node-side formulation computes

@@ -595,8 +595,18 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   if (!w || !k || !tr || !rot || (b->n_tor > 0 && !tor)) return DP_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int B = b->B;
+  // dense cross convs: node-side formulation when asked for (or chosen by AUTO) and the weights were packed for it
+  const bool node_side = dp_resolve_conv_algo(k->conv_algo, w->precision, B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
+  // lig-lig conv on the node-side kernel too (pair-dense form): pays while a pose's atoms fit a few 32-slot passes
+  const bool node_ll = node_side && w->lig_conv[0].w2n != nullptr && b->llp_ptr != nullptr && k->ll_pair_rad != nullptr &&
+                       k->ll_pair_bond != nullptr && b->max_nl <= DP_NODE_LL_MAX_ATOMS;
   hipLaunchKernelGGL(dp::time_params_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, b->t, *w, k->tparams);
-  hipLaunchKernelGGL(dp::lig_graph_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  {
+    // the N x N pair tables are filled (and verified: status bit 1) only when the node-side ligand-ligand conv will read them
+    DpWork kg = *k;
+    if (!node_ll) kg.ll_pair_rad = kg.ll_pair_bond = nullptr;
+    hipLaunchKernelGGL(dp::lig_graph_kernel, dim3(B), dim3(256), 0, st, *b, *w, kg);
+  }
   hipLaunchKernelGGL(dp::node_embed_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
   hipLaunchKernelGGL(dp::cross_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
   // workgroups per pose: keep <= 48 scatter nodes per workgroup and >= ~2 workgroups per CU in flight
@@ -606,23 +616,23 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while ((mx + slices - 1) / slices > dp_conv_max_nodes(w->precision)) ++slices;
     while (B * slices < 512 && slices < 8) ++slices;
   }
-  // dense cross convs: node-side formulation when asked for (or chosen by AUTO) and the weights were packed for it
-  const bool node_side = dp_resolve_conv_algo(k->conv_algo, w->precision, B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
   const int nb = dp_conv_node_max_nodes();
   const int slices_pl = (b->max_nl + nb - 1) / nb, slices_lp = (b->max_np + nb - 1) / nb;
-  // lig-lig conv on the node-side kernel too (pair-dense form): pays while a pose's atoms fit a few 32-slot passes
-  const bool node_ll = node_side && w->lig_conv[0].w2n != nullptr && b->llp_ptr != nullptr && k->ll_pair_rad != nullptr &&
-                       b->max_nl <= DP_NODE_LL_MAX_ATOMS;
   // optional second stream: phore-side convs of a layer (and the torsion head) run beside the ligand-side ones
   hipStream_t aux = (k->aux_stream && k->ev_fork && k->ev_join) ? (hipStream_t)k->aux_stream : nullptr;
   int ev_rc = 0;                                   // first failing event / stream call (reported at the end: launches are asynchronous anyway)
   auto note = [&](hipError_t e) { if (e != hipSuccess && ev_rc == 0) ev_rc = (int)e; };
+  bool aux_forked = false;
   auto fork = [&]() {
-    if (aux) { note(hipEventRecord((hipEvent_t)k->ev_fork, st)); note(hipStreamWaitEvent(aux, (hipEvent_t)k->ev_fork, 0)); }
+    if (aux) { note(hipEventRecord((hipEvent_t)k->ev_fork, st)); note(hipStreamWaitEvent(aux, (hipEvent_t)k->ev_fork, 0)); aux_forked = true; }
   };
   auto join = [&]() {
     if (aux) { note(hipEventRecord((hipEvent_t)k->ev_join, aux)); note(hipStreamWaitEvent(st, (hipEvent_t)k->ev_join, 0)); }
+    aux_forked = false;
   };
+  // error exit: never leave the aux stream forked (eager: later work on `st` must stay ordered after it; capture: an unjoined stream
+  // turns the caller's hipStreamEndCapture into an error that masks `rc`)
+  auto fail = [&](int rc_) { if (aux_forked) join(); return rc_; };
   int cur = 0;
   static const int D[5] = {20, 50, 80, 100, 100};
   auto timed = [&](const DpConvArgs& c, int layer, int which, hipStream_t s_) -> int {
@@ -659,7 +669,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.path_split = node_path_split(B, slices_pl);
         c.pair_a = k->ll_pair_rad; c.pair_b = k->ll_pair_bond; c.pair_ptr = b->llp_ptr;
       }
-      if ((rc = timed(c, l, 0, st))) return rc;
+      if ((rc = timed(c, l, 0, st))) return fail(rc);
     }
     for (int nv = 0; nv < 2; ++nv) {
       DpConvArgs c = a;
@@ -669,7 +679,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
       if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); }
-      if ((rc = timed(c, l, 1 + nv, st))) return rc;
+      if ((rc = timed(c, l, 1 + nv, st))) return fail(rc);
     }
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
       {
@@ -678,7 +688,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_scat = b->pp_src; c.gather_tab = hp; c.attr1_tab = hp; c.attr2_tab = hp; c.edge_emb = k->pp_emb; c.edge_sh = k->pp_sh;
         c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
-        if ((rc = timed(c, l, 3, sp_))) return rc;
+        if ((rc = timed(c, l, 3, sp_))) return fail(rc);
       }
       for (int nv = 0; nv < 2; ++nv) {
         DpConvArgs c = a;
@@ -688,7 +698,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
         if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); }
-        if ((rc = timed(c, l, 4 + nv, sp_))) return rc;
+        if ((rc = timed(c, l, 4 + nv, sp_))) return fail(rc);
       }
     }
     if (two) join();
@@ -707,7 +717,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.edge_emb = k->c_emb; c.edge_sh = k->c_sh; c.sh_stride = 9;
     c.w1p = w->final_conv.w1p; c.w2p = w->final_conv.w2p; c.bn_scale = w->final_conv.bn_scale; c.bn_shift = w->final_conv.bn_shift;
     c.out = k->gpred; c.out_stride = 12;
-    if ((rc = dp_tp_conv(&c, st))) return rc;
+    if ((rc = dp_tp_conv(&c, st))) return fail(rc);
   }
   hipLaunchKernelGGL(dp::trrot_head_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, *w, *k, tr, rot);
   // torsion head
@@ -724,7 +734,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.attr_swap = 1; c.edge_emb = k->t_emb; c.edge_sh = k->t_sh; c.sh_stride = 7;
     c.w1p = w->tor_conv.w1p; c.w2p = w->tor_conv.w2p; c.bn_scale = w->tor_conv.bn_scale; c.bn_shift = w->tor_conv.bn_shift;
     c.out = k->t_q; c.out_stride = 40;
-    if ((rc = dp_tp_conv(&c, s2))) return rc;
+    if ((rc = dp_tp_conv(&c, s2))) return fail(rc);
     hipLaunchKernelGGL(dp::tor_head_kernel, dim3((b->n_tor + 63) / 64), dim3(64), 0, s2, *b, *w, *k, tor);
     if (tor_aux) join();
   }

@@ -308,6 +308,34 @@ int dp_sample_graph_create(const DpBatch* b, const DpWeights* w, DpWork* k, cons
   return rc;
 }
 
+// second stream + fork / join events for DpWork.aux_stream / ev_fork / ev_join, created by THIS library's HIP runtime (a host binding
+// that dlopens its own libamdhip64 could hand over handles of a different runtime)
+int dp_aux_create(void** aux_stream, void** ev_fork, void** ev_join) {
+  if (!aux_stream || !ev_fork || !ev_join) return DP_E_BADARG;
+  *aux_stream = *ev_fork = *ev_join = nullptr;
+  hipStream_t s = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  int rc = (int)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (rc == 0) rc = (int)hipEventCreateWithFlags(&a, hipEventDisableTiming);
+  if (rc == 0) rc = (int)hipEventCreateWithFlags(&b, hipEventDisableTiming);
+  if (rc != 0) {
+    if (b) (void)hipEventDestroy(b);
+    if (a) (void)hipEventDestroy(a);
+    if (s) (void)hipStreamDestroy(s);
+    return rc;
+  }
+  *aux_stream = s; *ev_fork = a; *ev_join = b;
+  return DP_OK;
+}
+
+int dp_aux_destroy(void* aux_stream, void* ev_fork, void* ev_join) {
+  int rc = 0;
+  if (ev_fork) { const int r = (int)hipEventDestroy((hipEvent_t)ev_fork); if (r && !rc) rc = r; }
+  if (ev_join) { const int r = (int)hipEventDestroy((hipEvent_t)ev_join); if (r && !rc) rc = r; }
+  if (aux_stream) { const int r = (int)hipStreamDestroy((hipStream_t)aux_stream); if (r && !rc) rc = r; }
+  return rc;
+}
+
 int dp_sample_graph_launch(void* graph_exec, void* stream) {
   if (!graph_exec) return DP_E_BADARG;
   return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);

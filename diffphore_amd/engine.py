@@ -120,6 +120,10 @@ def _declare():
     L.dp_sample_graph_destroy.restype = C.c_int
     L.dp_resolve_conv_algo.argtypes = [c_i32, c_i32, c_i32]
     L.dp_resolve_conv_algo.restype = C.c_int
+    L.dp_aux_create.argtypes = [C.POINTER(VOIDP)] * 3
+    L.dp_aux_create.restype = C.c_int
+    L.dp_aux_destroy.argtypes = [VOIDP] * 3
+    L.dp_aux_destroy.restype = C.c_int
     L._dp_engine_declared = True
     return L
 
@@ -301,6 +305,11 @@ class PackedBatch:
         H["lig_x"] = cat([l.x for l in L], np.int32)
         ei_all = cat([g["ligand", "ligand"].edge_index for g in graphs], np.int64, axis=1) + np.repeat(self.lig_ptr[:-1], nb)[None, :]
         H["bond_src"], H["bond_dst"] = ei_all[0].astype(np.int32), ei_all[1].astype(np.int32)
+        # A ligand graph that lists the same ordered bond twice (a multigraph the reference would simply process) does not fit the
+        # N x N pair tables of the node-side ligand-ligand conv: such a batch carries no tables (DpBatch.llp_ptr = NULL) and dp_forward
+        # keeps its ligand-ligand convs on the edge-side CSR kernel.  Global atom ids are unique per pose, so one key covers the batch.
+        key = ei_all[0] * (int(self.lig_ptr[-1]) + 1) + ei_all[1]
+        self.ll_pairs_ok = bool(np.unique(key).size == key.size)
         ea = cat([g["ligand", "ligand"].edge_attr for g in graphs], np.float32).reshape(-1, 4)
         if ea.size and not np.all((ea.sum(1) == 1) & (ea.max(1) == 1)):
             raise ValueError("ligand bond edge_attr must be one-hot over 4 bond types")
@@ -359,10 +368,12 @@ class PackedBatch:
         s.B = B
         s.n_lig, s.n_ph, s.n_bond, s.n_tor = int(self.lig_ptr[-1]), n_ph, int(self.bond_ptr[-1]), int(self.tor_ptr[-1])
         s.n_pp, s.n_x, s.ll_cap = int(self.pp_ptr[-1]), int(self.x_ptr[-1]), int(self.ll_ptr[-1])
-        s.n_llp = int(self.llp_ptr[-1])
+        s.n_llp = int(self.llp_ptr[-1]) if self.ll_pairs_ok else 0
         s.max_nl, s.max_np, s.max_t = int(nl.max()), int(npn.max()), int(nt.max())
         for k, v in self.static.items():
             setattr(s, k, v.data_ptr())
+        if not self.ll_pairs_ok:
+            s.llp_ptr = None
         s.pos, s.norm, s.t = self.pos.data_ptr(), self.norm.data_ptr(), self.t.data_ptr()
         self.struct = s
         return self
@@ -422,25 +433,27 @@ class Workspace:
 
 
 class _HipHandles:
-    """A second stream + two events for dp_forward's optional fork/join (HIP runtime through ctypes; torch owns no handle here)."""
+    """A second stream + two events for dp_forward's optional fork/join, created and destroyed by the C library itself (dp_aux_create /
+    dp_aux_destroy): they come from the same HIP runtime the kernels are launched with.  Cached per device: engines are created per
+    device batch, the handles live as long as the process."""
+    _cache: Dict[int, "_HipHandles"] = {}
 
     def __init__(self):
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(VOIDP), C.c_uint]
-        hip.hipEventCreateWithFlags.argtypes = [C.POINTER(VOIDP), C.c_uint]
-        hip.hipStreamDestroy.argtypes = [VOIDP]
-        hip.hipEventDestroy.argtypes = [VOIDP]
-        self.hip = hip
+        L = _declare()
+        self.L = L
         self.stream, self.ev_fork, self.ev_join = VOIDP(), VOIDP(), VOIDP()
-        assert hip.hipStreamCreateWithFlags(C.byref(self.stream), 1) == 0          # hipStreamNonBlocking
-        assert hip.hipEventCreateWithFlags(C.byref(self.ev_fork), 2) == 0          # hipEventDisableTiming
-        assert hip.hipEventCreateWithFlags(C.byref(self.ev_join), 2) == 0
+        _lib.check(L.dp_aux_create(C.byref(self.stream), C.byref(self.ev_fork), C.byref(self.ev_join)), "dp_aux_create")
+
+    @classmethod
+    def for_device(cls, index: int) -> "_HipHandles":
+        h = cls._cache.get(index)
+        if h is None:
+            h = cls._cache[index] = cls()
+        return h
 
     def __del__(self):
         try:
-            self.hip.hipEventDestroy(self.ev_fork)
-            self.hip.hipEventDestroy(self.ev_join)
-            self.hip.hipStreamDestroy(self.stream)
+            self.L.dp_aux_destroy(self.stream, self.ev_fork, self.ev_join)
         except Exception:      # noqa: BLE001 - interpreter shutdown
             pass
 
@@ -468,15 +481,21 @@ class Engine:
         self._handles = None
         self._graph = None
         two = os.environ.get("DIFFPHORE_TWO_STREAMS", "auto")
-        if two == "1" or (two == "auto" and pb.B < TWO_STREAM_MAX_POSES):
+        if two == "1":
             self.enable_two_streams()
+        elif two == "auto" and pb.B < TWO_STREAM_MAX_POSES:
+            try:
+                self.enable_two_streams()
+            except _lib.DiffPhoreLibraryError:          # an optimisation only: a single stream computes the same result
+                self._handles = None
         _lib.check(self.L.dp_prepare(C.byref(pb.struct), C.byref(model.struct), C.byref(self.ws.struct), _stream()), "dp_prepare")
 
     def enable_two_streams(self):
         """dp_forward then runs the phore-side convs of a layer and the torsion head on a second stream (bit-identical results;
         pays when the batch is too small to fill the chip with one conv at a time)."""
         if self._handles is None:
-            self._handles = _HipHandles()
+            dev = self.pb.device
+            self._handles = _HipHandles.for_device(dev.index if dev.index is not None else torch.cuda.current_device())
             w = self.ws.struct
             w.aux_stream, w.ev_fork, w.ev_join = self._handles.stream, self._handles.ev_fork, self._handles.ev_join
 

@@ -55,7 +55,7 @@ enum DpEdgeMode {
 
 /* arithmetic of the radial-MLP second layer (the 60 x numel contraction that dominates the path) */
 enum DpPrecision {
-  DP_PREC_F32 = 0,      /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+  DP_PREC_F32 = 0,      /* exact fp32 MFMA (edge-side kernel: v_mfma_f32_32x32x2_f32; node-side kernel: v_mfma_f32_16x16x4_f32) */
   DP_PREC_BF16X6 = 3,   /* 3-way bf16 operand split, 6 cross products, fp32 accumulate: ~2^-24 relative, fp32-grade */
   DP_PREC_BF16X3 = 2,   /* 2-way bf16 split, 3 cross products: ~2^-17 relative */
   DP_PREC_BF16X9 = 4    /* 3-way split, all 9 cross products: every fp32 x fp32 product exact (3 x 8 significand bits), fp32 accumulate */
@@ -114,7 +114,12 @@ typedef struct DpConvArgs {
                                 conv's latency when B*slices cannot fill the chip; results are bit-identical.  fp32-MFMA kernel only
                                 (ignored otherwise and for kinds with a single phase) */
   /* node-side formulation (DP_ALGO_NODE): weights in the layout of dp_pack_conv_weights_node; `slices` = node groups per pose with
-   * ceil(max_scatter / slices) <= dp_conv_node_max_nodes().  Kinds 0-3, modes P2L / L2P, DP_PREC_F32 only. */
+   * ceil(max_scatter / slices) <= dp_conv_node_max_nodes().  Kinds 0-3, DP_PREC_F32 only; modes P2L / L2P (dense cross edges) and
+   * LLPAIR (ligand-ligand edges through the per-pose pair tables below).
+   * PRECONDITION on edge_sh: component 0 of every row is exactly 1.0 - true for e3nn's 'component'-normalised spherical harmonics
+   * (Y_0 = 1, score_model_phore.py:737,754,891-894), which is all dp_forward ever passes.  The node-side kernel never reads sh[0]:
+   * the l=0 paths use the gathered input itself as the GEMM-A operand.  A caller of dp_tp_conv with other edge_sh[:,0] values must
+   * use DP_ALGO_EDGE (the edge-side kernel multiplies by sh[0]). */
   const float* w1n;
   const float* w2n;
   int32_t algo;              /* DpConvAlgo; AUTO / EDGE -> the edge-side kernel */
@@ -236,7 +241,9 @@ typedef struct DpWork {
   int32_t *t_rowptr, *t_rowend, *t_nbr, *t_src;   /* [n_tor], [n_tor], [n_tor*32], [n_tor*32] */
   float *t_emb, *t_sh, *t_hb, *t_q;               /* [n_tor*32,20], [n_tor*32,7], [n_tor,20], [n_tor,40] */
   int32_t* status;                  /* [B] 0 ok, bit0 Kabsch degenerate / non-finite, bit1 ligand graph with a repeated (bond or radius) edge
-                                       between the same ordered atom pair (not representable in the pair tables of the node-side lig-lig conv) */
+                                       between the same ordered atom pair (not representable in the pair tables of the node-side lig-lig
+                                       conv; only raised when that conv runs: pass DpBatch.llp_ptr = NULL for such ligands and the
+                                       ligand-ligand convs use the edge-side CSR kernel, which handles multigraphs) */
   /* optional timing hook: if prof_start/prof_stop are hipEvent_t handles, dp_forward records them on the launch stream
    * immediately before / after the tensor-product conv (prof_layer, prof_conv); prof_conv: 0 lig-lig, 1 phore->lig,
    * 2 phore->lig (normals), 3 phore-phore, 4 lig->phore, 5 lig->phore (normals). */
@@ -323,6 +330,11 @@ int dp_sample_graph_create(const DpBatch* b, const DpWeights* w, DpWork* k, cons
                            void** graph_exec);
 int dp_sample_graph_launch(void* graph_exec, void* stream);
 int dp_sample_graph_destroy(void* graph_exec);
+
+/* the optional second stream + fork / join events of DpWork (aux_stream, ev_fork, ev_join), created / destroyed by the library's own HIP
+ * runtime; the caller keeps them alive while any DpWork that names them is in use */
+int dp_aux_create(void** aux_stream, void** ev_fork, void** ev_join);
+int dp_aux_destroy(void* aux_stream, void* ev_fork, void* ev_join);
 
 /* sizeof() of DpConvArgs, DpBatch, DpWeights, DpWork, DpStepParams, DpMlp (binding self-check) */
 int dp_struct_sizes(int32_t* out, int32_t n);

@@ -422,10 +422,10 @@ def test_sampler_without_any_torsion_and_no_torsion_flag():
         gen = torch.Generator().manual_seed(5)
         nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
         noise = dict(tr=torch.randn(S, len(gs), 3, generator=gen), rot=torch.randn(S, len(gs), 3, generator=gen), tor=torch.randn(S, nT, generator=gen))
-        a, _ = osampler.sampling_phore(copy.deepcopy(gs), om, S, sched, sched, sched, t_to_sigma_fn(args), args, noise=noise)
+        a, margin, which = _oracle_run_with_margins(om, gs, S, sched, args, noise=noise)
         b, _ = sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise)
         r = np.asarray([_rmsd(x["ligand"].pos.numpy(), y["ligand"].pos.numpy()) for x, y in zip(a, b)])
-        assert np.isfinite(r).all() and np.median(r) < 1e-4, r
+        _assert_poses_or_decision_flip(r, margin, which, f"3-step no-torsion case (no_torsion={no_tor})")
         # without torsion updates the ligand moves rigidly: all pair distances are preserved
         for g0, g1 in zip(gs, b):
             d0 = torch.cdist(g0["ligand"].pos, g0["ligand"].pos)
@@ -469,7 +469,7 @@ def test_full_schedule_20_steps_matches_oracle(monkeypatch):
         _assert_poses_or_decision_flip(r, margin, which, f"20-step {prec}/{algo}")
 
 
-def test_random_shapes_soak():
+def test_random_shapes_small_phores_and_nan_coincidence():
     """Random ligand / pharmacophore sizes mixed in random batches (2..70 atoms, 0..14 torsions, 2..110 phore nodes - including
     pharmacophores without exclusion spheres, where the reference itself overflows to NaN, score_model_phore.py:912): the HIP forward
     tracks the fp64 oracle to ~1e-6 of each output's magnitude, and is NaN exactly where the oracle is.  One batch may exceed the
@@ -561,7 +561,7 @@ def test_configs0_real_example_inputs(golden_dir, monkeypatch):
 
 
 @pytest.mark.parametrize("algo", ["node", "edge"])
-def test_random_shapes_soak(algo, monkeypatch):
+def test_fuzz_shapes_soak(algo, monkeypatch):
     """tools/fuzz_shapes.py as a test: random ragged batches (ligands of 2-70 atoms = up to three ligand-ligand passes of the node-side
     kernel, pharmacophores of 7-110 nodes = up to four cross passes) through the HIP forward vs the fp64 oracle.  A batch may deviate
     only if the oracle recorded a decision margin within fp32 rounding for one of its poses (a tie: either branch is legitimate)."""

@@ -180,3 +180,40 @@ def test_bench_traffic_record_lookup_is_robust(tmp_path, monkeypatch):
         assert bench.measured_traffic(2, 512, "f32", "edge") == (None, None)
     monkeypatch.setattr(bench, "TRAFFIC_FILE", str(tmp_path / "absent.json"))
     assert bench.measured_traffic(2, 512, "f32", "node") == (None, None)
+
+
+def test_fingerprint_is_cached_on_the_batch_object_and_invalidated_by_edits():
+    """the content hash is computed once per batch object; later calls compare O(1) identity / version keys only, and an
+    in-place edit or a replaced static tensor recomputes it."""
+    from diffphore_amd.score_model import TensorProductScoreModel
+    gs = synthetic.synthetic_pairs(3, 3, (8, 12), (1, 3), (6, 9))
+    m = TensorProductScoreModel.__new__(TensorProductScoreModel)
+    calls = []
+    real = TensorProductScoreModel._fingerprint
+    m._fingerprint = lambda d: (calls.append(1), real(d))[1]
+    b = Batch.from_data_list(gs)
+    k1 = m._fingerprint_cached(b)
+    b["ligand"].pos = b["ligand"].pos + 1.0                        # diffusion state: no recomputation
+    assert m._fingerprint_cached(b) == k1 and len(calls) == 1
+    b["ligand"].x[0, 1] = (b["ligand"].x[0, 1] + 1) % 4            # in-place edit of a static tensor bumps its version
+    k2 = m._fingerprint_cached(b)
+    assert k2 != k1 and len(calls) == 2
+    b["phore"].pos = b["phore"].pos.clone()                        # replaced (equal content): rehashed, same key
+    assert m._fingerprint_cached(b) == k2 and len(calls) == 3
+    assert m._fingerprint_cached(Batch.from_data_list(gs)) == k1 and len(calls) == 4      # a new object never inherits a cache entry
+
+
+def test_repeated_ordered_bond_drops_the_pair_tables():
+    from diffphore_amd.engine import PackedBatch
+    """A ligand graph that lists the same ordered bond twice cannot be held in the node-side conv's N x N pair tables: the packed batch
+    then carries no tables (llp_ptr NULL, n_llp 0), which keeps dp_forward's ligand-ligand convs on the edge-side CSR kernel."""
+    gs = synthetic.synthetic_pairs(5, 2, 10, 2, 8)
+    pb = PackedBatch(gs, "cpu", upload=False)
+    assert pb.ll_pairs_ok
+    g = gs[1]
+    ei, ea = g["ligand", "ligand"].edge_index, g["ligand", "ligand"].edge_attr
+    g["ligand", "ligand"].edge_index = torch.cat([ei, ei[:, :1]], 1)
+    g["ligand", "ligand"].edge_attr = torch.cat([ea, ea[:1]], 0)
+    g["ligand"].edge_mask = torch.cat([torch.as_tensor(g["ligand"].edge_mask), torch.zeros(1, dtype=torch.bool)])
+    pb2 = PackedBatch(gs, "cpu", upload=False)
+    assert not pb2.ll_pairs_ok

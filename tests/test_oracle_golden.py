@@ -129,3 +129,15 @@ def test_table_lookups_match_reference(golden_dir):
     P = np.load(os.path.join(golden_dir, "ref_tables_probe.npz"))
     np.testing.assert_array_equal(tables.so3_score_norm(P["so3_eps"]), P["so3_score_norm"])
     np.testing.assert_array_equal(tables.torus_score_norm(P["torus_sigma"]), P["torus_score_norm"])
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_modify_conformer_many_torsions(golden_dir, case):
+    """BASELINE configs[2]'s shape (80 atoms x 25 torsions), the kernel-limit shape (128 x 40) and a 45 x 12 tree: the oracle's
+    modify_conformer against the reference's own outputs (tests/golden/make_torsion25_golden.py)."""
+    G25 = np.load(os.path.join(golden_dir, "ref_torsion25.npz"))
+    pre = f"c{case}_"
+    g = _graph(G25, pre)
+    conformer.modify_conformer(g, torch.from_numpy(G25[pre + "mc_tr"]), torch.from_numpy(G25[pre + "mc_rot"]), G25[pre + "theta"])
+    np.testing.assert_allclose(g["ligand"].pos.numpy(), G25[pre + "mc_pos_out"], atol=4e-6)
+    np.testing.assert_allclose(g["ligand"].norm.numpy(), G25[pre + "mc_norm_out"], atol=8e-6)

@@ -20,8 +20,11 @@ for k in range(4):
     SLOTS[f"tp_conv_node_kernel<{k}, 2>"] = ["lig->phore", "lig->phore(norm)"]
 SLOTS["tp_conv_kernel<4>"] = ["centre (final_conv)"]
 SLOTS["tp_conv_kernel<5>"] = ["torsion bonds (tor_bond_conv)"]
-FLOPS = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400}     # SURVEY.md 8d per edge-conv (edge-side count)
-EDGE_SET = {"lig-lig": "ll", "phore-phore": "pp", "phore->lig": "x", "phore->lig(norm)": "x", "lig->phore": "x", "lig->phore(norm)": "x"}
+# SURVEY.md 8d per edge-conv (edge-side count): 2*(n_attr*hid + hid*numel) + 2*sum_paths mul_in*mul_out*(2 l_out + 1); kinds 4 / 5 = the
+# centre head (fc 40->40->200, out 2x1o+2x1e) and the torsion head (fc 60->60->1600, scalar outputs)
+FLOPS = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400, 4: 19200 + 1200, 5: 199200 + 3200}
+EDGE_SET = {"lig-lig": "ll", "phore-phore": "pp", "phore->lig": "x", "phore->lig(norm)": "x", "lig->phore": "x", "lig->phore(norm)": "x",
+            "centre (final_conv)": "center", "torsion bonds (tor_bond_conv)": "tor"}
 
 
 def short(name):
