@@ -12,9 +12,9 @@ BASELINE configs (diffphore_amd/workloads.py).  Poses are independent: with --gp
 Timed region: W warm-up steps (untimed), state reset to the randomised start poses, then EXACTLY K steps walking the
 schedule 0..S-1 (state reset at every wrap), bracketed by barrier + synchronize; MAX over ranks.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused TP conv, layer-2 phore->ligand launch):
-algorithmic flops / bytes of SURVEY.md 8d per launch / mean launch duration measured with HIP events recorded inside
-dp_forward on the launch stream during the timed steps.  `cpu_baseline` = this repo's CPU oracle (reference-style
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused TP conv, the layer-2 ligand-side launch: node-side it
+carries ligand-ligand + phore->ligand + phore->ligand(normals) in one launch): algorithmic flops / bytes per launch (summed over
+its convs) / mean launch duration measured with HIP events recorded inside dp_forward on the launch stream during the timed steps.  `cpu_baseline` = this repo's CPU oracle (reference-style
 torch-CPU restatement, fp32) on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
@@ -307,6 +307,7 @@ def main():
             self.edge_counts = {"x": int(pb.x_ptr[-1]), "pp": int(pb.pp_ptr[-1]), "center": int(pb.lig_ptr[-1]),
                                 "ll": int((t["ll_rowend"] - t["ll_rowptr"]).sum().item()),
                                 "tor": int((t["t_rowend"] - t["t_rowptr"])[:max(nT, 0)].sum().item()) if nT else 0}
+            self.prof_launch = eng.launch_of(PROF_LAYER, PROF_CONV)      # (first conv, count, node-side) of the launch the events bracket
             return el, kms, nbad, fin, eng.conv_algo
 
     t2s = t_to_sigma_fn(margs)
@@ -319,6 +320,7 @@ def main():
         return wl.timed_run(mdl, conv_algo, a.steps, a.warmup)
 
     elapsed, kern_ms, bad, finite, algo_used = timed_run(model, a.conv_algo)
+    prof_launch, edge_counts = wl.prof_launch, dict(wl.edge_counts)
     pb = pb0
     totals = torch.tensor([B, int(pb.x_ptr[-1])], device=dev, dtype=torch.float64)
     if dist is not None:
@@ -365,7 +367,6 @@ def main():
         del copy
 
     n_x = int(pb.x_ptr[-1])
-    edge_counts = dict(wl.edge_counts)
 
     other = None
     if not a.no_other and a.config == 2 and a.precision is None and a.conv_algo is None and a.poses is None:
@@ -391,20 +392,40 @@ def main():
                 del w2
             except Exception as e:      # noqa: BLE001 - an informational pass must never sink the headline line
                 other.append({"config": f"configs[{c - 1}]", "error": str(e)[:200]})
-    alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * n_x
-    flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * n_x
-    if algo_used == "node":
-        n_nodes = int(pb.lig_ptr[-1])                      # scatter nodes of the phore->ligand conv = ligand atoms
-        n_gather = int(pb.ph_ptr[-1])                      # gather nodes = pharmacophore nodes
-        rf_flops = (n_x * 2 * 61 * (20 + NODE_COLS[PROF_LAYER]) + n_nodes * 2 * 61 * (21 + NODE_W[PROF_LAYER]) + n_gather * 2 * 61 * 20)
-        rf_note = ("node-side formulation: 2*61*(20+280) flop per edge (edge part of radial layer 1 + GEMM-A) + 2*61*(21+3200) flop per scatter "
-                   "node (its layer-1 block + GEMM-B) + 2*61*20 per gather node, DESIGN.md 5.1; the edge-side count of SURVEY.md 8d is reported beside it")
-        groups = int(sum((int(pb.nl[i]) + 15) // 16 for i in range(B)))      # workgroups: 16-node groups, one 32-edge pass each at NP <= 32
-        passes = int(sum(((int(pb.nl[i]) + 15) // 16) * ((int(pb.np_[i]) + 31) // 32) for i in range(B)))
+    # The profiled launch: the one that carries layer-2 phore->ligand.  Node-side it is a FUSED launch (dp_tp_conv_node_fused): the
+    # ligand-ligand conv + phore->ligand + phore->ligand(normals) of the layer back to back into one set of accumulators, so the
+    # algorithmic work of the launch is the sum over its convs.  Edge-side it is the single conv.
+    first, count, launch_node = prof_launch
+    convs = list(range(first, first + count))
+    n_ll = edge_counts["ll"]
+    conv_edges = {0: n_ll, 1: n_x, 2: n_x}
+    launch_edges = sum(conv_edges[c] for c in convs)
+    alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * launch_edges
+    flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * launch_edges
+    conv_names = {0: "ligand-ligand", 1: "phore->ligand", 2: "phore->ligand(normals)"}
+    kernel_name = (f"layer-2 ligand-side launch = {' + '.join(conv_names[c] for c in convs)}"
+                   + (" fused into one node-side launch" if count > 1 else "") + f", conv_algo={algo_used}, precision={precision}")
+    if launch_node:
+        n_nodes = int(pb.lig_ptr[-1])                      # scatter nodes of every conv of the launch = ligand atoms
+        n_gather = {0: int(pb.lig_ptr[-1]), 1: int(pb.ph_ptr[-1]), 2: int(pb.ph_ptr[-1])}      # gather nodes: atoms (lig-lig) / pharmacophore nodes
+        rf_flops = sum(conv_edges[c] * 2 * 61 * (20 + NODE_COLS[PROF_LAYER]) + n_nodes * 2 * 61 * (21 + NODE_W[PROF_LAYER])
+                       + n_gather[c] * 2 * 61 * 20 for c in convs)
+        rf_note = (f"node-side formulation, summed over the {count} conv(s) of the launch: 2*61*(20+280) flop per edge (edge part of radial layer 1 + "
+                   "GEMM-A) + 2*61*(21+3200) flop per scatter node (its layer-1 block + GEMM-B) + 2*61*20 per gather node, DESIGN.md 5.1; "
+                   "the edge-side count of SURVEY.md 8d is reported beside it")
+        nl_, np__ = [int(x) for x in pb.nl], [int(x) for x in pb.np_]
+        groups = int(sum((n + 15) // 16 for n in nl_))       # workgroups: 16-node groups
+
+        def pass_units(n_slots):                             # 32-slot passes of a node, a last pass of <= 16 slots counted as half a pass
+            full, rem = divmod(n_slots, 32)
+            return full + (0 if rem == 0 else (0.5 if rem <= 16 else 1.0))
+        slots = {0: nl_, 1: np__, 2: np__}                   # edge slots per scatter node: pair-dense lig-lig = atoms of the pose
+        passes = sum(((nl_[i] + 15) // 16) * pass_units(slots[c][i]) for c in convs for i in range(B))
         issued = passes * 4 * NODE_MFMA_PER_WAVE[PROF_LAYER] * 2048.0
         rf_issue = {"executed_flops_per_launch": issued, "achieved": issued / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
                     "frac": issued / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None, "workgroups": groups,
-                    "note": "fp32 MFMA flops actually issued (v_mfma_f32_16x16x4_f32, padding included) / launch time = matrix-pipe occupancy"}
+                    "note": "fp32 MFMA flops actually issued (v_mfma_f32_16x16x4_f32, padding included; a half pass counted as half of a "
+                            "32-slot pass, the lig-lig conv's second layer-1 sweep over bond edges not counted) / launch time = matrix-pipe occupancy"}
     else:
         rf_flops, rf_note, rf_issue = flops, "SURVEY.md 8d: 2*(60*60+60*numel)+TP flop per edge-conv (edge-side formulation)", None
     traffic, traffic_src = measured_traffic(a.config, B, precision, algo_used) if world == 1 else (None, None)
@@ -442,8 +463,8 @@ def main():
                                                      "kernel would have to sustain for this launch time; > 1 is possible for the node-side form"},
                          "mfma_issue": rf_issue,
                          "traffic": traffic,
-                         "kernel": f"fused TP conv, layer-2 phore->ligand launch (dense cross edges), conv_algo={algo_used}, precision={precision}",
-                         "kernel_ms": kern_ms, "edges_per_launch": n_x,
+                         "kernel": "fused TP conv, " + kernel_name,
+                         "kernel_ms": kern_ms, "edges_per_launch": launch_edges, "convs_in_launch": [conv_names[c] for c in convs],
                          "alg_flops_per_edge": ALG_FLOPS_PER_EDGE[PROF_LAYER], "alg_bytes_per_edge": ALG_BYTES_PER_EDGE[PROF_LAYER],
                          "hbm_equivalent": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                                             "note": "algorithmic bytes of the e3nn operator boundary (per-edge weights counted as "

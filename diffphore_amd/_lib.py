@@ -12,7 +12,7 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 3
+DP_ABI_VERSION = 4
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
@@ -75,12 +75,14 @@ def _declare(L):
     L.dp_pack_conv_weights.argtypes = [c_i32, c_i32, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP]
     L.dp_pack_conv_weights.restype = C.c_int
     L.dp_tp_conv_node.argtypes = [C.POINTER(DpConvArgs), VOIDP]
+    L.dp_tp_conv_node_fused.argtypes = [C.POINTER(DpConvArgs), c_i32, VOIDP]
+    L.dp_tp_conv_node_fused.restype = C.c_int
     L.dp_tp_conv_node.restype = C.c_int
     L.dp_conv_w1n_floats.argtypes = [c_i32]
     L.dp_conv_w1n_floats.restype = C.c_int
     L.dp_conv_w2n_floats.argtypes = [c_i32]
     L.dp_conv_w2n_floats.restype = C.c_int
-    L.dp_pack_conv_weights_node.argtypes = [c_i32] + [VOIDP] * 6
+    L.dp_pack_conv_weights_node.argtypes = [c_i32] + [VOIDP] * 7
     L.dp_pack_conv_weights_node.restype = C.c_int
     L.dp_conv_node_max_nodes.restype = C.c_int
 

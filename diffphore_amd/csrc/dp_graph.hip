@@ -589,6 +589,34 @@ int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream) {
   return (int)hipGetLastError();
 }
 
+// which formulation the convs of a forward take (shared by dp_forward and dp_forward_launch_of)
+static bool plan_node_side(const DpBatch* b, const DpWeights* w, const DpWork* k) {
+  return dp_resolve_conv_algo(k->conv_algo, w->precision, b->B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
+}
+static bool plan_node_ll(const DpBatch* b, const DpWeights* w, const DpWork* k) {
+  return plan_node_side(b, w, k) && w->lig_conv[0].w2n != nullptr && b->llp_ptr != nullptr && k->ll_pair_rad != nullptr &&
+         k->ll_pair_bond != nullptr && b->max_nl <= DP_NODE_LL_MAX_ATOMS;
+}
+
+int dp_forward_launch_of(const DpBatch* b, const DpWeights* w, const DpWork* k, int32_t layer, int32_t conv, int32_t* first, int32_t* count,
+                         int32_t* node_side_out) {
+  if (!b || !w || !k || !first || !count || layer < 0 || layer > 3 || conv < 0 || conv > 5 || (layer == 3 && conv > 2)) return DP_E_BADARG;
+  const bool node_side = plan_node_side(b, w, k), node_ll = plan_node_ll(b, w, k), fuse = k->conv_fuse != 1;
+  int f = conv, n = 1;
+  bool ns = false;
+  if (conv <= 2) {                                  // ligand side: lig_conv, phore_to_lig, phore_to_lig_norm
+    if (node_side && fuse && node_ll) { f = 0; n = 3; }
+    else if (node_side && fuse && conv >= 1) { f = 1; n = 2; }
+    ns = conv == 0 ? node_ll : node_side;
+  } else if (conv >= 4) {                           // pharmacophore side: lig_to_phore, lig_to_phore_norm (conv 3 = phore_conv, edge-side)
+    if (node_side && fuse) { f = 4; n = 2; }
+    ns = node_side;
+  }
+  *first = f; *count = n;
+  if (node_side_out) *node_side_out = ns ? 1 : 0;
+  return DP_OK;
+}
+
 int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float* rot, float* tor, void* stream) {
   int rc = dp_check_batch(b);
   if (rc) return rc;
@@ -596,10 +624,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   hipStream_t st = (hipStream_t)stream;
   const int B = b->B;
   // dense cross convs: node-side formulation when asked for (or chosen by AUTO) and the weights were packed for it
-  const bool node_side = dp_resolve_conv_algo(k->conv_algo, w->precision, B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
+  const bool node_side = plan_node_side(b, w, k);
   // lig-lig conv on the node-side kernel too (pair-dense form): pays while a pose's atoms fit a few 32-slot passes
-  const bool node_ll = node_side && w->lig_conv[0].w2n != nullptr && b->llp_ptr != nullptr && k->ll_pair_rad != nullptr &&
-                       k->ll_pair_bond != nullptr && b->max_nl <= DP_NODE_LL_MAX_ATOMS;
+  const bool node_ll = plan_node_ll(b, w, k);
   hipLaunchKernelGGL(dp::time_params_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, b->t, *w, k->tparams);
   {
     // the N x N pair tables are filled (and verified: status bit 1) only when the node-side ligand-ligand conv will read them
@@ -616,6 +643,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while ((mx + slices - 1) / slices > dp_conv_max_nodes(w->precision)) ++slices;
     while (B * slices < 512 && slices < 8) ++slices;
   }
+  const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
   const int nb = dp_conv_node_max_nodes();
   const int slices_pl = (b->max_nl + nb - 1) / nb, slices_lp = (b->max_np + nb - 1) / nb;
   // optional second stream: phore-side convs of a layer (and the torsion head) run beside the ligand-side ones
@@ -658,8 +686,18 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     const bool two = aux != nullptr && l != 3;
     hipStream_t sp_ = two ? aux : st;           // stream of the phore-side convs
     if (two) fork();
+    // timing hook around the launch that contains conv `which` (a fused launch answers for each of its convs)
+    auto timed_fused = [&](const DpConvArgs* cs, int n, int which_lo, int which_hi, hipStream_t s_) -> int {
+      const bool prof = k->prof_start && k->prof_stop && k->prof_layer == l && k->prof_conv >= which_lo && k->prof_conv <= which_hi;
+      if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
+      const int r = dp_tp_conv_node_fused(cs, n, s_);
+      if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
+      return r;
+    };
+    DpConvArgs ligc[3];                          // ligand side: lig_conv, phore_to_lig, phore_to_lig_norm
     {
-      DpConvArgs c = a;
+      DpConvArgs& c = ligc[0];
+      c = a;
       c.mode = DP_EDGES_CSR; c.scat_ptr = b->lig_ptr; c.max_scatter = b->max_nl; c.rowptr = k->ll_rowptr; c.rowend = k->ll_rowend; c.nbr = k->ll_nbr;
       c.edge_scat = k->ll_src; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hl; c.edge_emb = k->ll_emb; c.edge_sh = k->ll_sh;
       c.w1p = w->lig_conv[l].w1p; c.w2p = w->lig_conv[l].w2p; c.bn_scale = w->lig_conv[l].bn_scale; c.bn_shift = w->lig_conv[l].bn_shift;
@@ -669,17 +707,29 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.path_split = node_path_split(B, slices_pl);
         c.pair_a = k->ll_pair_rad; c.pair_b = k->ll_pair_bond; c.pair_ptr = b->llp_ptr;
       }
-      if ((rc = timed(c, l, 0, st))) return fail(rc);
     }
     for (int nv = 0; nv < 2; ++nv) {
-      DpConvArgs c = a;
+      DpConvArgs& c = ligc[1 + nv];
+      c = a;
       const DpConvW& cw = nv ? w->p2l_norm_conv[l] : w->p2l_conv[l];
       c.mode = DP_EDGES_P2L; c.scat_ptr = b->lig_ptr; c.max_scatter = b->max_nl; c.gather_tab = hp; c.attr1_tab = hl; c.attr2_tab = hp;
       c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
       if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); }
-      if ((rc = timed(c, l, 1 + nv, st))) return fail(rc);
+    }
+    if (node_side && fuse && node_ll) {
+      // one launch: the three convs scatter onto the same atoms and their outputs add up (:703-706)
+      ligc[1].accumulate = ligc[2].accumulate = 0;
+      if ((rc = timed_fused(ligc, 3, 0, 2, st))) return fail(rc);
+    } else {
+      if ((rc = timed(ligc[0], l, 0, st))) return fail(rc);
+      if (node_side && fuse) {
+        if ((rc = timed_fused(ligc + 1, 2, 1, 2, st))) return fail(rc);
+      } else {
+        for (int nv = 0; nv < 2; ++nv)
+          if ((rc = timed(ligc[1 + nv], l, 1 + nv, st))) return fail(rc);
+      }
     }
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
       {
@@ -690,15 +740,22 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
         if ((rc = timed(c, l, 3, sp_))) return fail(rc);
       }
+      DpConvArgs phc[2];
       for (int nv = 0; nv < 2; ++nv) {
-        DpConvArgs c = a;
+        DpConvArgs& c = phc[nv];
+        c = a;
         const DpConvW& cw = nv ? w->l2p_norm_conv[l] : w->l2p_conv[l];
         c.mode = DP_EDGES_L2P; c.scat_ptr = b->ph_ptr; c.max_scatter = b->max_np; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hp;
         c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
         if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); }
-        if ((rc = timed(c, l, 4 + nv, sp_))) return fail(rc);
+      }
+      if (node_side && fuse) {
+        if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);
+      } else {
+        for (int nv = 0; nv < 2; ++nv)
+          if ((rc = timed(phc[nv], l, 4 + nv, sp_))) return fail(rc);
       }
     }
     if (two) join();

@@ -65,7 +65,7 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("conv_fuse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -93,6 +93,8 @@ def _declare():
     L.dp_prepare.restype = C.c_int
     L.dp_forward.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWeights), C.POINTER(DpWork), VOIDP, VOIDP, VOIDP, VOIDP]
     L.dp_forward.restype = C.c_int
+    L.dp_forward_launch_of.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWeights), C.POINTER(DpWork), c_i32, c_i32] + [C.POINTER(c_i32)] * 3
+    L.dp_forward_launch_of.restype = C.c_int
     L.dp_conformer_update.argtypes = [C.POINTER(DpBatch), C.POINTER(DpStepParams)] + [VOIDP] * 8
     L.dp_conformer_update.restype = C.c_int
     L.dp_sample_step.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWeights), C.POINTER(DpWork), C.POINTER(DpStepParams)] + [VOIDP] * 7
@@ -478,6 +480,7 @@ class Engine:
         self.L.dp_resolve_conv_algo.argtypes = [c_i32, c_i32, c_i32]
         self.L.dp_resolve_conv_algo.restype = C.c_int
         self.conv_algo = {1: "edge", 2: "node"}[self.L.dp_resolve_conv_algo(CONV_ALGOS[conv_algo], model.struct.precision, pb.B)]
+        self.ws.struct.conv_fuse = 1 if os.environ.get("DIFFPHORE_CONV_FUSE", "1") == "0" else 0
         self._handles = None
         self._graph = None
         two = os.environ.get("DIFFPHORE_TWO_STREAMS", "auto")
@@ -505,6 +508,14 @@ class Engine:
                 self.L.dp_sample_graph_destroy(self._graph)
             except Exception:      # noqa: BLE001
                 pass
+
+    def launch_of(self, layer: int, conv: int):
+        """(first, count, node_side) of the dp_forward launch that carries conv `conv` of interaction layer `layer` (conv numbering of
+        DpWork.prof_conv: 0 lig_conv, 1 phore_to_lig, 2 phore_to_lig_norm, 3 phore_conv, 4 lig_to_phore, 5 lig_to_phore_norm)."""
+        f, n, ns = c_i32(), c_i32(), c_i32()
+        _lib.check(self.L.dp_forward_launch_of(C.byref(self.pb.struct), C.byref(self.model.struct), C.byref(self.ws.struct), layer, conv,
+                                               C.byref(f), C.byref(n), C.byref(ns)), "dp_forward_launch_of")
+        return f.value, n.value, bool(ns.value)
 
     def forward(self):
         ws = self.ws

@@ -51,7 +51,8 @@ def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: in
     if node_side:
         w1n = torch.empty(L.dp_conv_w1n_floats(kind), dtype=torch.float32)
         w2n = torch.empty(L.dp_conv_w2n_floats(kind), dtype=torch.float32)
+        # the node-side kernel carries the BatchNorm scale inside its packed second layer (see include/diffphore_amd.h)
         _lib.check(L.dp_pack_conv_weights_node(kind, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
-                                               w1n.data_ptr(), w2n.data_ptr()), "dp_pack_conv_weights_node")
+                                               scale.data_ptr(), w1n.data_ptr(), w2n.data_ptr()), "dp_pack_conv_weights_node")
         out.update(w1n=w1n, w2n=w2n)
     return out

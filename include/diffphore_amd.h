@@ -31,7 +31,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 3
+#define DP_ABI_VERSION 4
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -72,7 +72,8 @@ typedef struct DpConvArgs {
   int32_t kind;          /* DpConvKind */
   int32_t mode;          /* DpEdgeMode */
   int32_t B;             /* poses */
-  int32_t slices;        /* workgroups per pose (>=1); scatter nodes of a pose are split evenly between them */
+  int32_t slices;        /* workgroups per pose (>=1); scatter nodes of a pose are split evenly between them (node-side kernel: a pose
+                            uses only the ceil(nodes / 16) groups it needs, the pose's other workgroups leave at once) */
   int32_t precision;     /* DpPrecision; must match the precision w2p was packed for */
   int32_t max_scatter;   /* largest number of scatter nodes of any pose; ceil(max_scatter / slices) must be <= dp_conv_max_nodes() */
   /* pose CSRs (B+1 entries each) */
@@ -139,8 +140,18 @@ int dp_conv_node_max_nodes(void);
 int dp_conv_w1n_floats(int32_t kind);
 int dp_conv_w2n_floats(int32_t kind);
 /* HOST pointers: the same reference tensors as dp_pack_conv_weights, re-ordered for the node-side kernel */
-int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b, float* w1n,
-                              float* w2n);
+int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
+                              const float* bn_scale, float* w1n, float* w2n);
+/* `bn_scale` (HOST, [D_out], the `scale` output of dp_pack_bn; NULL = ones) is folded into the packed second layer: the node-side
+ * kernel applies the scatter mean and the BatchNorm scale inside its operands and only ADDS bn_shift in its epilogue, which is what lets
+ * several convs share one set of accumulators (below).  DpConvArgs.bn_scale is therefore ignored by the node-side kernel. */
+
+/* Fused node-side launch: convs[0..n) (n <= 3) scatter onto the same node groups and their outputs are summed, as the reference sums
+ * the outputs of lig_conv + phore_to_lig + phore_to_lig_norm (score_model_phore.py:703-706) and of lig_to_phore + lig_to_phore_norm
+ * (:708-710).  Allowed sequences: [LLPAIR] [P2L] [P2L] (any non-empty sub-sequence in that order) or [L2P] [L2P].  convs[0] names
+ * out / resid / accumulate; kind, B, slices, scat_ptr, max_scatter and path_split must agree.  One prologue, one reduction of the
+ * k-partials, one epilogue and one write of `out` instead of one read-modify-write per conv. */
+int dp_tp_conv_node_fused(const DpConvArgs* convs, int32_t n, void* stream);
 /* what DP_ALGO_AUTO resolves to for a batch of B poses at `precision` (returns DP_ALGO_EDGE or DP_ALGO_NODE) */
 int dp_resolve_conv_algo(int32_t algo, int32_t precision, int32_t B);
 
@@ -254,6 +265,8 @@ typedef struct DpWork {
    * layer (and the torsion head) on `aux_stream`, forked from / joined back to the launch stream with the events.  Results are
    * bit-identical; it only helps batches too small to fill the chip with one conv at a time.  Capturable into a hipGraph. */
   void *aux_stream, *ev_fork, *ev_join;
+  int32_t conv_fuse;                /* node-side convs of a layer that scatter onto the same nodes: 0 = one fused launch per side (default),
+                                       1 = one launch per conv (A/B runs and tests) */
 } DpWork;
 
 typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */
@@ -267,6 +280,14 @@ typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampl
 int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream);
 /* score model forward: writes tr [B,3], rot [B,3], tor [n_tor].   score_model_phore.py:294-310 */
 int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float* rot, float* tor, void* stream);
+
+/* Which launch of dp_forward carries conv `conv` (0 lig_conv, 1 phore_to_lig, 2 phore_to_lig_norm, 3 phore_conv, 4 lig_to_phore,
+ * 5 lig_to_phore_norm) of interaction layer `layer` for this batch / workspace: the launch runs convs [*first, *first + *count) (count > 1:
+ * a fused node-side launch, dp_tp_conv_node_fused); *node_side (may be NULL) = 1 when that launch is a node-side kernel.  The same conv
+ * numbering as DpWork.prof_conv: the prof_start / prof_stop events bracket exactly this launch.  Pure host logic, no GPU work. */
+int dp_forward_launch_of(const DpBatch* b, const DpWeights* w, const DpWork* k, int32_t layer, int32_t conv, int32_t* first, int32_t* count,
+                         int32_t* node_side);
+
 /* SDE/ODE perturbation + modify_conformer for every pose (updates b->pos / b->norm in place).
  * sampling.py:223-254, diffusion_utils.py:23-79.  z_* may be NULL (treated as zeros). */
 int dp_conformer_update(const DpBatch* b, const DpStepParams* sp, const float* tr, const float* rot, const float* tor,

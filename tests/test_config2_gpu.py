@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 from diffphore_amd import config, synthetic, weights  # noqa: E402
 from diffphore_amd.hetero import Batch  # noqa: E402
-from test_forward_gpu import (_assert_poses_or_decision_flip, _golden_graph, _model, _oracle_run_with_margins, _rel, _rmsd)  # noqa: E402
+from test_forward_gpu import (MARGIN_FP32, _assert_poses_or_decision_flip, _golden_graph, _model, _oracle_run_with_margins, _rel, _rmsd)  # noqa: E402
 
 
 def _margs(**kw):
@@ -52,15 +52,50 @@ def test_conformer_update_many_torsions_matches_reference_golden(golden_dir):
     pos, norm = pb.pos.cpu().numpy(), pb.norm.cpu().numpy()
     for c in range(n_case):
         lo, hi = int(pb.lig_ptr[c]), int(pb.lig_ptr[c + 1])
-        err = np.abs(pos[lo:hi] - G[f"c{c}_mc_pos_out"]).max()
-        print(f"case {c}: {hi - lo} atoms, max |dpos| vs reference = {err:.2e} A")
-        np.testing.assert_allclose(pos[lo:hi], G[f"c{c}_mc_pos_out"], atol=5e-6)
-        np.testing.assert_allclose(norm[lo:hi], G[f"c{c}_mc_norm_out"], atol=1e-5)
+        want = G[f"c{c}_mc_pos_out"]
+        err = np.abs(pos[lo:hi] - want).max()
+        # 5e-6 A at the configs[2] shape (80 atoms x 25 torsions; measured 2e-6).  The 128-atom x 40-torsion limit shape gets 2e-5: the
+        # reference itself works in fp32 there (fp32 norms of the rotation axes, an fp32 rigid transform and an fp32 SVD in Kabsch,
+        # geometry.py:88-136) - its output moves by 3e-6 A when only the SVD runs in fp64 - and 40 sequential rotations of a 7 A lever
+        # accumulate the 1-ulp differences of each step (measured 1.1e-5 A on one coordinate of 384, the rest below 1e-5).
+        ext = float(np.abs(want - want.mean(0)).max())
+        tol = 2e-5 if hi - lo > 80 else 5e-6
+        print(f"case {c}: {hi - lo} atoms, extent {ext:.1f} A, max |dpos| vs reference = {err:.2e} A (tolerance {tol:.1e})")
+        np.testing.assert_allclose(pos[lo:hi], want, atol=tol, rtol=0)
+        np.testing.assert_allclose(norm[lo:hi], G[f"c{c}_mc_norm_out"], atol=2 * tol, rtol=0)
 
 
-def test_conformer_update_configs2_shape_matches_oracle():
+def _fp64_conformer_update(g, tr, rot, tor):
+    """modify_conformer (diffusion_utils.py:23-79) with EVERY step in fp64 - rigid motion, the sequential torsion rotations
+    (torsion.py:64-109) and the Kabsch alignment: the exact answer the fp32 routes (the reference's and the kernel's) both approximate."""
+    from scipy.spatial.transform import Rotation as R
+    from oracle import conformer
+    L_ = g["ligand"]
+    pos = L_.pos.double()
+    center = pos.mean(0, keepdim=True)
+    rm = conformer.axis_angle_to_matrix(torch.from_numpy(rot).double())
+    rigid = (pos - center) @ rm.T + torch.from_numpy(tr).double() + center
+    bonds = g["ligand", "ligand"].edge_index.T[L_.edge_mask.bool()].numpy()
+    mr = conformer._mask_rotate(L_)
+    p = rigid.numpy().copy()
+    for k, (u, v) in enumerate(bonds):
+        rv = p[u] - p[v]
+        M = R.from_rotvec(rv * float(tor[k]) / np.linalg.norm(rv)).as_matrix()
+        p[mr[k]] = (p[mr[k]] - p[v]) @ M.T + p[v]
+    flex = torch.from_numpy(p)
+    Rk, tk = conformer.kabsch(flex.T, rigid.T)
+    return (flex @ Rk.T + tk.T).numpy()
+
+
+@pytest.mark.parametrize("tor_range", ["step", "full"])
+def test_conformer_update_configs2_shape_matches_oracle(tor_range):
     """One dp_conformer_update call on synthetic configs[2] poses (80 atoms, 25 torsions) vs oracle.conformer.modify_conformer
-    (itself pinned to the reference at this torsion count by tests/test_oracle_golden.py) <= 5e-6 A."""
+    (itself pinned to the reference at this torsion count by tests/test_oracle_golden.py).
+      step: torsion updates of the size a reverse-diffusion step applies (sigma 0.3 rad)                         <= 5e-6 A
+      full: uniform in (-pi, pi) - 25 sequential large rotations about axes that are themselves fp32 atom differences.  A 1-ulp
+            difference in an axis atom (the rigid transform's summation order is enough) moves everything downstream by ~2e-6 A per
+            torsion, so two correct fp32 evaluations differ by ~1e-5 A.  Both are therefore held to the all-fp64 evaluation: the
+            reference's fp32 route sits 3e-6 .. 9e-6 A from it on these poses (the kernel, measured, 3e-6 .. 9e-6 A too), the bound is 2e-5 A."""
     from diffphore_amd.engine import DpStepParams, PackedBatch, _declare, _stream
     from oracle import conformer
     gs = synthetic.synthetic_pairs(3, 4, 80, 25, 32)
@@ -68,10 +103,11 @@ def test_conformer_update_configs2_shape_matches_oracle():
     rng = np.random.default_rng(31)
     tr = rng.normal(size=(4, 3)).astype(np.float32)
     rot = (0.4 * rng.normal(size=(4, 3))).astype(np.float32)
-    tor = rng.uniform(-np.pi, np.pi, size=(4, 25)).astype(np.float32)
+    tor = (rng.uniform(-np.pi, np.pi, size=(4, 25)) if tor_range == "full" else 0.3 * rng.normal(size=(4, 25))).astype(np.float32)
     ref = copy.deepcopy(gs)
     for i, g in enumerate(ref):
         conformer.modify_conformer(g, torch.from_numpy(tr[i:i + 1]), torch.from_numpy(rot[i]), tor[i])
+    truth = [_fp64_conformer_update(g, tr[i:i + 1], rot[i], tor[i]) for i, g in enumerate(gs)]
     L = _declare()
     pb = PackedBatch(gs, "cuda")
     sp = DpStepParams()
@@ -83,10 +119,15 @@ def test_conformer_update_configs2_shape_matches_oracle():
     torch.cuda.synchronize()
     assert int(status.abs().sum()) == 0
     pos, norm = pb.pos.cpu().numpy(), pb.norm.cpu().numpy()
+    tol = 5e-6 if tor_range == "step" else 2e-5
     for i, g in enumerate(ref):
         lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
-        np.testing.assert_allclose(pos[lo:hi], g["ligand"].pos.numpy(), atol=5e-6)
-        np.testing.assert_allclose(norm[lo:hi], g["ligand"].norm.numpy().reshape(-1, 33), atol=1e-5)
+        want = g["ligand"].pos.numpy()
+        e_o, e_t, o_t = np.abs(pos[lo:hi] - want).max(), np.abs(pos[lo:hi] - truth[i]).max(), np.abs(want - truth[i]).max()
+        print(f"pose {i} ({tor_range}): max |dpos| kernel vs oracle {e_o:.2e} A, kernel vs all-fp64 {e_t:.2e} A, oracle vs all-fp64 {o_t:.2e} A")
+        np.testing.assert_allclose(pos[lo:hi], truth[i], atol=tol, rtol=0)
+        np.testing.assert_allclose(pos[lo:hi], want, atol=1.5 * tol, rtol=0)
+        np.testing.assert_allclose(norm[lo:hi], g["ligand"].norm.numpy().reshape(-1, 33), atol=3 * tol, rtol=0)
 
 
 @pytest.mark.parametrize("ode,algo", [(False, "edge"), (False, "node"), (True, "edge"), (True, "node")])
@@ -129,32 +170,58 @@ def test_configs2_sampler_trajectory_matches_oracle(ode, algo, monkeypatch):
 
 def test_node_side_above_the_ligand_ligand_cap():
     """20 poses of 100-110 atoms forced onto DIFFPHORE_CONV_ALGO=node: the cross convs run node-side (7 node groups per pose), the
-    ligand-ligand convs fall back to the edge-side CSR kernel (more than DP_NODE_LL_MAX_ATOMS = 96 atoms) - vs the fp64 oracle."""
-    from diffphore_amd.engine import Engine, PackedBatch
+    ligand-ligand convs fall back to the edge-side CSR kernel (more than DP_NODE_LL_MAX_ATOMS = 96 atoms) - vs the fp64 oracle, pose by
+    pose.  4 400 cross edges per pose make a near-tie in the sign of the direction MLP (score_model_phore.py:813-816) likely somewhere in
+    the batch: a pose may deviate only if the oracle recorded such a tie for it (relative margin < 1e-5), as in the trajectory tests."""
     from diffphore_amd.score_model import TensorProductScoreModel
     from oracle import sampler as osampler
     gs = synthetic.synthetic_pairs(811, 10, 100, 14, 24) + synthetic.synthetic_pairs(812, 10, 110, 10, 40)
     sd, om = _model()
     batch = Batch.from_data_list(gs)
     osampler.set_time_phore(batch, 0.45, 0.45, 0.45, batch.num_graphs)
-    tr_o, rot_o, tor_o = om(batch)
+    om.track_margins = True
+    try:
+        tr_o, rot_o, tor_o = om(batch)
+    finally:
+        om.track_margins = False
+    margin = np.min(np.stack([v.numpy() for v in om.margins.values()]), 0)
+    lb, pbt = batch["ligand"].batch, batch["phore"].batch
+    tor_pose = torch.repeat_interleave(torch.arange(len(gs)), torch.tensor([int(g["ligand"].edge_mask.sum()) for g in gs]))
+
+    def per_pose(m, tr, rot, tor):
+        """largest relative error of every compared quantity, per pose (the ping-pong buffers still hold the previous layers' outputs:
+        ligand buffer 1 = layer 3's output, pharmacophore buffer 1 = h_p3, buffer 0 = h_p2)"""
+        t_ = m._engine.ws.t
+        items = [(t_["h_l0"][:, :100], om.debug["h_l4"], lb), (t_["h_l1"][:, :100], om.debug["h_l3"], lb), (t_["h_p1"][:, :100], om.debug["h_p3"], pbt),
+                 (t_["h_p0"][:, :80], om.debug["h_p2"], pbt), (tr, tr_o, torch.arange(len(gs))), (rot, rot_o, torch.arange(len(gs))),
+                 (tor, tor_o, tor_pose)]
+        e = np.zeros(len(gs))
+        for got, want, idx in items:
+            got, want = got.double().cpu(), want.double().cpu()
+            d = (got - want).abs().reshape(got.shape[0], -1).max(1).values / want.abs().max()
+            for p in range(len(gs)):
+                e[p] = max(e[p], float(d[idx == p].max()))
+        return e
+
     os.environ["DIFFPHORE_CONV_ALGO"] = "node"
     try:
         m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
         tr, rot, tor = m(batch)
         torch.cuda.synchronize()
-        assert m._engine.conv_algo == "node"
-        errs = dict(h_l4=_rel(m._engine.ws.t["h_l0"][:, :100], om.debug["h_l4"]), tr=_rel(tr, tr_o), rot=_rel(rot, rot_o), tor=_rel(tor, tor_o))
-        print("node-side above the lig-lig cap, relative errors vs fp64 oracle:", {k: f"{v:.1e}" for k, v in errs.items()})
-        assert all(v < 1e-5 for v in errs.values()), errs
-        # and the edge-side formulation agrees with it on the same batch
+        assert m._engine.conv_algo == "node" and int(m._engine.ws.t["status"].abs().sum()) == 0
+        e_node = per_pose(m, tr, rot, tor)
+        print("node-side above the lig-lig cap, per-pose relative error vs fp64 oracle:", " ".join(f"{x:.1e}" for x in e_node))
+        bad = np.nonzero(~(e_node < 1e-5))[0]
+        print("poses beyond 1e-5:", bad.tolist(), "their smallest decision margin:", [float(margin[i]) for i in bad])
+        assert np.isfinite(e_node).all() and bad.size <= 2 and all(margin[i] < MARGIN_FP32 for i in bad), (e_node, margin)
+        assert (e_node < 1e-5).sum() >= 18
+        # and the edge-side formulation agrees with it on the same batch, tie poses included (both take the same branch)
         os.environ["DIFFPHORE_CONV_ALGO"] = "edge"
         m2 = TensorProductScoreModel(device="cuda").load_state_dict(sd)
         tr2, rot2, tor2 = m2(batch)
         assert _rel(tr2, tr.cpu()) < 1e-5 and _rel(rot2, rot.cpu()) < 1e-5 and _rel(tor2, tor.cpu()) < 1e-5
     finally:
         os.environ.pop("DIFFPHORE_CONV_ALGO", None)
-    del Engine, PackedBatch
 
 
 def test_repeated_ordered_bond_falls_back_to_the_edge_side_lig_conv():
@@ -180,3 +247,29 @@ def test_repeated_ordered_bond_falls_back_to_the_edge_side_lig_conv():
     assert eng.conv_algo == "node" and not eng.pb.ll_pairs_ok
     assert int(eng.ws.t["status"].abs().sum()) == 0
     assert _rel(tr, tr_o) < 1e-5 and _rel(rot, rot_o) < 1e-5 and _rel(tor, tor_o) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(24, 30, 8, 32), (24, 20, 5, 79), (20, 100, 10, 24)])
+def test_fused_layer_launches_equal_one_launch_per_conv(shape, monkeypatch):
+    """dp_forward with the node-side convs of a layer fused per side (ligand-ligand + phore->ligand + normals in one launch,
+    ligand->phore + normals in another; DpWork.conv_fuse = 0, the default) against one launch per conv (conv_fuse = 1): the same sums in
+    a different order.  The third shape (100 atoms) keeps the ligand-ligand conv on the edge-side kernel: only the cross pair fuses."""
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import sampler as osampler
+    n, nl, nt, npn = shape
+    gs = synthetic.synthetic_pairs(900 + nl, n, nl, nt, npn)
+    batch = Batch.from_data_list(gs)
+    osampler.set_time_phore(batch, 0.5, 0.5, 0.5, batch.num_graphs)
+    sd = weights.init_state_dict()
+    res = {}
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", "node")
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DIFFPHORE_CONV_FUSE", fuse)
+        m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+        tr, rot, tor = m(batch)
+        torch.cuda.synchronize()
+        res[fuse] = (tr.cpu(), rot.cpu(), tor.cpu(), m._engine.ws.t["h_l0"][:, :100].cpu().clone())
+    for i, (a, b) in enumerate(zip(res["1"], res["0"])):
+        assert torch.isfinite(a).all()
+        # node features to fp32 rounding; the scores are sums of cancelling terms (|tr| ~ 1e-4 here): 1e-5 measured
+        assert _rel(a, b) < (5e-6 if i == 3 else 3e-5), (i, _rel(a, b))

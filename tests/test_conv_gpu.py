@@ -177,9 +177,11 @@ def test_conv_dense_cross(kind, mode, prec):
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3])
 @pytest.mark.parametrize("mode", ["p2l", "l2p"])
-def test_conv_node_side_dense_cross(kind, mode):
+@pytest.mark.parametrize("big", [False, True])
+def test_conv_node_side_dense_cross(kind, mode, big):
     """Node-side formulation (dp_conv_node.hip, DP_ALGO_NODE) of the dense cross convs vs the fp64 oracle AND vs the edge-side
-    kernel: ragged pose sizes (1 node, < 16, > 16 nodes; 5 / 32 / 79 edges per node = 1-3 edge passes), residual + accumulate."""
+    kernel: ragged pose sizes (1 node, < 16, > 16 nodes; 5 / 32 / 79 edges per node = 1-3 edge passes), residual + accumulate.
+    `big`: ligands above the ligand-ligand cap of dp_forward (100 / 110 atoms: 7 node groups per pose, four edge passes)."""
     g = torch.Generator().manual_seed(700 + kind)
     sd = weights.init_state_dict(11)
     fam = "phore_to_lig_conv_layers" if mode == "p2l" else "lig_to_phore_norm_conv_layers"
@@ -187,7 +189,7 @@ def test_conv_node_side_dense_cross(kind, mode):
         fam = "lig_to_phore_conv_layers"
     prefix = f"encoder.{fam}.{kind}"
     dims = _lib.conv_dims(kind)
-    NL, NP = [7, 30, 13, 1, 40], [32, 5, 79, 33, 17]
+    NL, NP = ([7, 30, 13, 1, 40], [32, 5, 79, 33, 17]) if not big else ([100, 110, 97], [24, 40, 16])
     B = len(NL)
     lig_ptr = np.concatenate([[0], np.cumsum(NL)])
     ph_ptr = np.concatenate([[0], np.cumsum(NP)])
@@ -400,3 +402,85 @@ def test_conv_rejects_too_many_nodes_per_workgroup():
     assert _lib.lib().dp_tp_conv(C.byref(a), None) == -3          # DP_E_TOOLARGE: 79 nodes > 32 per workgroup
     a.max_scatter = 0
     assert _lib.lib().dp_tp_conv(C.byref(a), None) == -1
+
+
+@pytest.mark.parametrize("kind,mode", [(0, "p2l"), (2, "p2l"), (3, "p2l"), (1, "l2p"), (2, "l2p")])
+def test_conv_node_fused_pair_equals_the_two_launches(kind, mode):
+    """dp_tp_conv_node_fused([conv, norm-conv]) - one launch, shared accumulators - against the two convs launched one after the other
+    (accumulate = 1 for the second): same sums in a different order -> equal to fp32 rounding; and against the fp64 oracle's sum.  Ragged
+    poses as above (1-3 edge passes incl. half passes)."""
+    g = torch.Generator().manual_seed(1700 + kind)
+    sd = weights.init_state_dict(11)
+    fams = ("phore_to_lig_conv_layers", "phore_to_lig_norm_conv_layers") if mode == "p2l" else ("lig_to_phore_conv_layers", "lig_to_phore_norm_conv_layers")
+    dims = _lib.conv_dims(kind)
+    NL, NP = [7, 30, 13, 1, 40, 16], [32, 5, 79, 33, 17, 48]
+    B = len(NL)
+    lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+    ph_ptr = np.concatenate([[0], np.cumsum(NP)])
+    x_ptr = np.concatenate([[0], np.cumsum(np.asarray(NL) * np.asarray(NP))])
+    hl = torch.randn(int(lig_ptr[-1]), dims["d_in"], generator=g)
+    hp = torch.randn(int(ph_ptr[-1]), dims["d_in"], generator=g)
+    E = int(x_ptr[-1])
+    emb = torch.randn(E, 20, generator=g)
+    shs = []
+    for _ in range(2):
+        sh = torch.randn(E, 9, generator=g)
+        sh[:, 0] = 1.0
+        shs.append(sh)
+    src = torch.cat([torch.arange(lig_ptr[b], lig_ptr[b + 1]).repeat_interleave(NP[b]) for b in range(B)])
+    dst = torch.cat([torch.arange(ph_ptr[b], ph_ptr[b + 1]).repeat(NL[b]) for b in range(B)])
+    attr = torch.cat([emb, hl[src, :20], hp[dst, :20]], 1)
+    if mode == "p2l":
+        n_out, gt, scat_ptr, m, mx = hl.shape[0], hp, lig_ptr, _lib.EDGES_P2L, max(NL)
+        refs = [_oracle_conv(sd, f"encoder.{fams[i]}.{kind}", kind, hp[dst], attr, shs[i], src, n_out) for i in range(2)]
+    else:
+        n_out, gt, scat_ptr, m, mx = hp.shape[0], hl, ph_ptr, _lib.EDGES_L2P, max(NP)
+        refs = [_oracle_conv(sd, f"encoder.{fams[i]}.{kind}", kind, hl[src], attr, shs[i], dst, n_out) for i in range(2)]
+    pks = [packing.pack_conv(sd, f"encoder.{fams[i]}.{kind}", kind, _lib.PREC_F32, node_side=True) for i in range(2)]
+    nb = _lib.lib().dp_conv_node_max_nodes()
+    resid = torch.randn(n_out, dims["d_in"], generator=g)
+    keep = []
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+
+    D = dict(scat_ptr=_dev(_i32(scat_ptr)), lig_ptr=_dev(_i32(lig_ptr)), ph_ptr=_dev(_i32(ph_ptr)), x_ptr=_dev(_i32(x_ptr)), gt=_dev(gt),
+             hl=_dev(hl), hp=_dev(hp), emb=_dev(emb), resid=_dev(resid), sh=[_dev(x) for x in shs],
+             pk=[{k_: _dev(v) for k_, v in pk.items()} for pk in pks])          # one device copy each: the convs of a fused launch share them
+
+    def args(i, out, accumulate, path_split=0):
+        pk = D["pk"][i]
+        d = dict(kind=kind, mode=m, B=B, slices=(mx + nb - 1) // nb, precision=_lib.PREC_F32, max_scatter=mx, scat_ptr=D["scat_ptr"],
+                 lig_ptr=D["lig_ptr"], ph_ptr=D["ph_ptr"], x_ptr=D["x_ptr"], gather_tab=D["gt"], gather_stride=dims["d_in"],
+                 attr1_tab=D["hl"], attr1_stride=dims["d_in"], attr2_tab=D["hp"], attr2_stride=dims["d_in"], attr_swap=0,
+                 edge_emb=D["emb"], edge_sh=D["sh"][i], sh_stride=9, w1p=pk["w1p"], w2p=pk["w2p"], w1n=pk["w1n"],
+                 w2n=pk["w2n"], bn_scale=pk["bn_scale"], bn_shift=pk["bn_shift"], out=out, out_stride=dims["d_out"],
+                 accumulate=accumulate, resid=D["resid"], resid_stride=dims["d_in"], resid_width=dims["d_in"], algo=_lib.ALGO_NODE,
+                 path_split=path_split)
+        a = _lib.DpConvArgs()
+        for k_, v in d.items():
+            if torch.is_tensor(v):
+                keep.append(v)
+                v = v.data_ptr()
+            setattr(a, k_, v)
+        return a
+
+    want = refs[0] + refs[1]
+    want[:, :dims["d_in"]] += resid.double()
+    scale = want.abs().max().item()
+    out_seq = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    _lib.check(L.dp_tp_conv_node(C.byref(args(0, out_seq, 0)), st), "conv 0")
+    _lib.check(L.dp_tp_conv_node(C.byref(args(1, out_seq, 1)), st), "conv 1")
+    for ps in (0, 1):
+        out_f = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+        arr = (_lib.DpConvArgs * 2)(args(0, out_f, 0, ps), args(1, out_f, 0, ps))
+        _lib.check(L.dp_tp_conv_node_fused(arr, 2, st), "fused")
+        torch.cuda.synchronize()
+        got = out_f.cpu().double()
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() / scale < TOL["f32"]
+        assert (got - out_seq.cpu().double()).abs().max().item() / scale < 2e-6
+    # sequences the kernel has no instantiation for are refused, not mis-run
+    bad = (_lib.DpConvArgs * 2)(args(0, out_seq, 0), args(1, out_seq, 0))
+    bad[1].mode = _lib.EDGES_L2P if mode == "p2l" else _lib.EDGES_P2L
+    assert L.dp_tp_conv_node_fused(bad, 2, st) == -2
+    assert L.dp_tp_conv_node_fused(bad, 4, st) == -1

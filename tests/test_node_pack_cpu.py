@@ -118,7 +118,7 @@ def test_node_side_packing_reproduces_the_conv(kind):
                             u, k = nu * ut + (s >> 2), 16 * q + 4 * gq + (s & 3)
                             out[:, out_off + w * d_out:out_off + (w + 1) * d_out] += blk[q, lane, s] * Tn[:, k, u, :]
     assert off == w2n.size
-    out /= NP                                                          # scatter mean
-    out = out * pk["bn_scale"].numpy().astype(np.float64) + pk["bn_shift"].numpy().astype(np.float64)
+    out /= NP                                                          # scatter mean (the kernel applies it to hid: same linear map)
+    out = out + pk["bn_shift"].numpy().astype(np.float64)              # the BatchNorm scale is folded into the packed second layer
     err = np.abs(out - ref).max() / np.abs(ref).max()
     assert err < 1e-6, err
