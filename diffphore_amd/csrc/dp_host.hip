@@ -70,6 +70,7 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   w.t_hb = c.take<float>(nt * 20);
   w.t_q = c.take<float>(nt * 40);
   w.status = c.take<int32_t>(B);
+  w.z_noise = c.take<float>(B * 6 + nt);
   float* tr_ = c.take<float>(B * 3);
   float* rot_ = c.take<float>(B * 3);
   float* tor_ = c.take<float>(nt);
@@ -273,14 +274,26 @@ int dp_pack_bn(int32_t kind, const float* running_mean, const float* running_var
 // ---------------------------------------------------------------------------------------------------------------------------
 int dp_sample(const DpBatch* b, const DpWeights* w, DpWork* k, const DpSchedule* s, float* tr, float* rot, float* tor, void* stream) {
   if (!b || !w || !k || !s || s->steps <= 0 || !s->sp || !s->t || !tr || !rot) return DP_E_BADARG;
+  if (s->noise_mode != DP_NOISE_TABLES && s->noise_mode != DP_NOISE_SEED) return DP_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < s->steps; ++i) {
     const DpStepParams& sp = s->sp[i];
     hipLaunchKernelGGL(dph::set_time_kernel, dim3((b->B * 3 + 255) / 256), dim3(256), 0, st, b->B, s->t + 3 * i, const_cast<float*>(b->t));
     // a noise table is consumed only where its coefficient is non-zero (ODE, no_random, no_final_step_noise: sampling.py:226-244)
-    const float* z_tr = (s->z_tr && sp.tr_c2 != 0.f) ? s->z_tr + (size_t)i * b->B * 3 : nullptr;
-    const float* z_rot = (s->z_rot && sp.rot_c2 != 0.f) ? s->z_rot + (size_t)i * b->B * 3 : nullptr;
-    const float* z_tor = (s->z_tor && sp.tor_c2 != 0.f && !sp.no_torsion) ? s->z_tor + (size_t)i * b->n_tor : nullptr;
+    const float *z_tr, *z_rot, *z_tor;
+    if (s->noise_mode == DP_NOISE_SEED) {
+      if (!k->z_noise) return DP_E_BADARG;
+      float* zt = sp.tr_c2 != 0.f ? k->z_noise : nullptr;
+      float* zr = sp.rot_c2 != 0.f ? k->z_noise + (size_t)b->B * 3 : nullptr;
+      float* zo = (sp.tor_c2 != 0.f && !sp.no_torsion && b->n_tor > 0) ? k->z_noise + (size_t)b->B * 6 : nullptr;
+      const int rn = dp_noise_normals(s->seed, i, b, s->pose_uid, s->uid_base, zt, zr, zo, stream);
+      if (rn) return rn;
+      z_tr = zt; z_rot = zr; z_tor = zo;
+    } else {
+      z_tr = (s->z_tr && sp.tr_c2 != 0.f) ? s->z_tr + (size_t)i * b->B * 3 : nullptr;
+      z_rot = (s->z_rot && sp.rot_c2 != 0.f) ? s->z_rot + (size_t)i * b->B * 3 : nullptr;
+      z_tor = (s->z_tor && sp.tor_c2 != 0.f && !sp.no_torsion) ? s->z_tor + (size_t)i * b->n_tor : nullptr;
+    }
     const int rc = dp_sample_step(b, w, k, &sp, tr, rot, tor, z_tr, z_rot, z_tor, stream);
     if (rc) return rc;
   }

@@ -441,8 +441,8 @@ int dp_fit_overlap(const DpBatch* b, const float* pos, float ex_lambda, float* s
 
 // sizeof() of every ABI struct, for the host binding's self-check
 extern "C" int dp_struct_sizes(int32_t* out, int32_t n) {
-  const int32_t v[6] = {(int32_t)sizeof(DpConvArgs), (int32_t)sizeof(DpBatch), (int32_t)sizeof(DpWeights), (int32_t)sizeof(DpWork),
-                        (int32_t)sizeof(DpStepParams), (int32_t)sizeof(DpMlp)};
-  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
-  return 6;
+  const int32_t v[7] = {(int32_t)sizeof(DpConvArgs), (int32_t)sizeof(DpBatch), (int32_t)sizeof(DpWeights), (int32_t)sizeof(DpWork),
+                        (int32_t)sizeof(DpStepParams), (int32_t)sizeof(DpMlp), (int32_t)sizeof(DpSchedule)};
+  for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
+  return 7;
 }

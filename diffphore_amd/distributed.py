@@ -97,3 +97,65 @@ def fit_complexes(graphs: Sequence, model, args, samples_per_complex: int = 40, 
         poses = data_list[c * samples_per_complex:(c + 1) * samples_per_complex]
         out.append(torch.stack([p["ligand"].pos for p in poses]).numpy())
     return idx, out
+
+
+def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None, samples_per_complex: int = 40, device="cuda",
+           max_poses: int = 8192, seed: int = 0, on_result=None):
+    """Streaming form of `fit_complexes` for library-scale screening (BASELINE configs[3] / configs[4]: 10^4-10^5 complexes x 40 samples
+    per GPU).  `load_unit(i)` builds complex i on demand (featurisation, parsing, ... stay with the caller); `costs[i]` (optional, cheap:
+    e.g. atoms x pharmacophore nodes) drives the LPT shard, otherwise units are dealt round-robin.  This rank
+
+        * takes ITS indices only (no rank ever builds or holds another rank's units),
+        * walks them in device batches of <= max_poses poses (whole complexes), building batch k+1 - `load_unit` calls included - on the
+          host while the GPU samples batch k (`sampling_phore_stream`),
+        * draws start randomisation and step noise on the device from (`seed`, pose uid = unit * samples + sample): results do not
+          depend on the world size, the batch size or the order of the stream,
+        * hands each finished complex to `on_result(i, poses [samples, n_atoms, 3] float32)` and drops it; with on_result=None the arrays
+          are collected and returned (only sensible for small runs).
+
+    Returns (indices owned by this rank in processing order, list of pose arrays or None).  Peak host memory: two device batches of
+    pose objects, whatever the library size."""
+    import torch.distributed as dist
+
+    from .diffusion import get_t_schedule, t_to_sigma_fn
+    from .sampling import sampling_phore_stream
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if costs is not None:
+        if len(costs) != n_units:
+            raise ValueError("costs needs one entry per unit")
+        mine = shard_indices(costs, world)[rank]
+    else:
+        mine = list(range(rank, n_units, world))
+    if int(n_units) * samples_per_complex >= 2 ** 31:
+        raise ValueError("pose uids are 32-bit: n_units * samples_per_complex must stay below 2^31")
+    steps = int(getattr(args, "inference_steps", 20))
+    sched = get_t_schedule(steps)
+    per = max(1, max_poses // samples_per_complex)
+
+    def parts():
+        for lo in range(0, len(mine), per):
+            poses, uids = [], []
+            for i in mine[lo:lo + per]:
+                g = load_unit(i)
+                for s_ in range(samples_per_complex):
+                    poses.append(g.sample_copy() if hasattr(g, "sample_copy") else __import__("copy").deepcopy(g))
+                    uids.append(i * samples_per_complex + s_)
+            yield poses, uids
+
+    collected = [] if on_result is None else None
+    done = 0
+    stream = sampling_phore_stream(parts(), model, steps, sched, sched, sched, device, t_to_sigma_fn(args), args, seed=seed,
+                                   no_random=getattr(args, "no_random", False), ode=getattr(args, "ode", False),
+                                   no_final_step_noise=getattr(args, "no_final_step_noise", False),
+                                   randomize=dict(no_torsion=getattr(args, "no_torsion", False), no_random=False, tr_sigma_max=args.tr_sigma_max))
+    for part in stream:
+        for c in range(len(part) // samples_per_complex):
+            arr = torch.stack([p["ligand"].pos for p in part[c * samples_per_complex:(c + 1) * samples_per_complex]]).numpy()
+            i = mine[done]
+            done += 1
+            if on_result is not None:
+                on_result(i, arr)
+            else:
+                collected.append(arr)
+    return mine, collected

@@ -65,7 +65,7 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("conv_fuse", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join", "z_noise")] + [("conv_fuse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -82,7 +82,8 @@ class DpModelScalars(C.Structure):
 
 
 class DpSchedule(C.Structure):
-    _fields_ = [("steps", c_i32), ("sp", C.POINTER(DpStepParams)), ("t", VOIDP), ("z_tr", VOIDP), ("z_rot", VOIDP), ("z_tor", VOIDP)]
+    _fields_ = [("steps", c_i32), ("sp", C.POINTER(DpStepParams)), ("t", VOIDP), ("z_tr", VOIDP), ("z_rot", VOIDP), ("z_tor", VOIDP),
+                ("noise_mode", c_i32), ("uid_base", c_i32), ("pose_uid", VOIDP), ("seed", C.c_uint64)]
 
 
 def _declare():
@@ -95,6 +96,10 @@ def _declare():
     L.dp_forward.restype = C.c_int
     L.dp_forward_launch_of.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWeights), C.POINTER(DpWork), c_i32, c_i32] + [C.POINTER(c_i32)] * 3
     L.dp_forward_launch_of.restype = C.c_int
+    L.dp_noise_normals.argtypes = [C.c_uint64, c_i32, C.POINTER(DpBatch), VOIDP, c_i32, VOIDP, VOIDP, VOIDP, VOIDP]
+    L.dp_noise_normals.restype = C.c_int
+    L.dp_randomize_draws.argtypes = [C.c_uint64, C.POINTER(DpBatch), VOIDP, c_i32, c_f32, VOIDP, VOIDP, VOIDP, VOIDP]
+    L.dp_randomize_draws.restype = C.c_int
     L.dp_conformer_update.argtypes = [C.POINTER(DpBatch), C.POINTER(DpStepParams)] + [VOIDP] * 8
     L.dp_conformer_update.restype = C.c_int
     L.dp_sample_step.argtypes = [C.POINTER(DpBatch), C.POINTER(DpWeights), C.POINTER(DpWork), C.POINTER(DpStepParams)] + [VOIDP] * 7
@@ -535,17 +540,24 @@ class Engine:
                                          ws.tr.data_ptr(), ws.rot.data_ptr(), ws.tor.data_ptr(), _lib.ptr(z_tr), _lib.ptr(z_rot),
                                          _lib.ptr(z_tor), _stream()), "dp_sample_step")
 
-    def sample(self, sps: Sequence[DpStepParams], times: torch.Tensor, z_tr=None, z_rot=None, z_tor=None, graph: bool = False):
+    def sample(self, sps: Sequence[DpStepParams], times: torch.Tensor, z_tr=None, z_rot=None, z_tor=None, graph: bool = False,
+               seed: Optional[int] = None, pose_uid: Optional[torch.Tensor] = None, uid_base: int = 0):
         """The whole reverse-diffusion loop in ONE library call (dp_sample): `sps` per-step scalars, `times` [S,3] device tensor,
-        `z_*` device noise tables [S,B,3] / [S,B,3] / [S,n_tor] or None.  `graph=True` captures the loop into a hipGraph (kept for
-        replays with the same tables) and launches it."""
+        `z_*` device noise tables [S,B,3] / [S,B,3] / [S,n_tor] or None.  `seed` (int) switches to on-device noise (DP_NOISE_SEED):
+        the tables are ignored and every step's normals are a function of (seed, pose uid, step, component), `pose_uid` an int32
+        device tensor [B] (default uid_base + position in the batch).  `graph=True` captures the loop into a hipGraph (kept for replays
+        with the same tables) and launches it."""
         ws, S = self.ws, len(sps)
         arr = (DpStepParams * S)(*sps)
         assert times.is_contiguous() and tuple(times.shape) == (S, 3) and times.dtype == torch.float32 and times.is_cuda
         sch = DpSchedule()
         sch.steps, sch.sp, sch.t = S, arr, times.data_ptr()
         sch.z_tr, sch.z_rot, sch.z_tor = _lib.ptr(z_tr), _lib.ptr(z_rot), _lib.ptr(z_tor)
-        self._keep = (arr, times, z_tr, z_rot, z_tor)            # the graph bakes these pointers in
+        if seed is not None:
+            if pose_uid is not None:
+                assert pose_uid.is_cuda and pose_uid.dtype == torch.int32 and pose_uid.numel() == self.pb.B and pose_uid.is_contiguous()
+            sch.noise_mode, sch.seed, sch.uid_base, sch.pose_uid = 1, int(seed) & 0xFFFFFFFFFFFFFFFF, int(uid_base), _lib.ptr(pose_uid)
+        self._keep = (arr, times, z_tr, z_rot, z_tor, pose_uid)            # the graph bakes these pointers in
         args = (C.byref(self.pb.struct), C.byref(self.model.struct), C.byref(ws.struct), C.byref(sch), ws.tr.data_ptr(), ws.rot.data_ptr(),
                 ws.tor.data_ptr())
         if not graph:

@@ -9,6 +9,11 @@ Extra, optional keywords:
                this path consume identical noise.  With noise=None the numbers are drawn from the global torch CPU
                generator in exactly the reference's order (per `batch_size` chunk: z_tr, z_rot, z_tor; sampling.py:230-243).
     engine     a prepared `diffphore_amd.engine.Engine` to reuse a packed batch across calls.
+    seed       int: draw the noise ON THE DEVICE instead (dp_noise_normals: Philox-4x32-10 keyed by `seed`, counter = (pose uid, step,
+               component)); with `randomize=` the start randomisation too (dp_randomize_draws).  Nothing is drawn or uploaded by the
+               host, and a pose's trajectory depends only on (seed, its uid), not on batching or sharding.  `pose_uid` (sequence of
+               ints, one per entry of data_list; default: the index) carries the global identity of a pose across ranks.  Not the
+               reference's random stream: use `noise=` / the global generators for runs that must be compared with a CPU run.
 """
 from __future__ import annotations
 
@@ -63,21 +68,50 @@ def _noisy_steps(inference_steps, ode, no_random, no_final_step_noise):
     return [t for t in range(inference_steps) if not (ode or no_random or (no_final_step_noise and t == inference_steps - 1))]
 
 
+def _device_noise(seed, noise, pose_uid, lo, n, device):
+    """(seed, int32 device tensor of the uids of poses lo .. lo+n) when the run draws its noise on the device, else None."""
+    if seed is None or noise is not None:
+        return None
+    if pose_uid is None:
+        uid = torch.arange(lo, lo + n, dtype=torch.int32)
+    else:
+        uid = torch.as_tensor(list(pose_uid[lo:lo + n]), dtype=torch.int32)
+        if uid.numel() != n:
+            raise ValueError("pose_uid needs one entry per pose of data_list")
+    return int(seed), uid.to(device)
+
+
+def _randomize_on_device(pb, dev_noise, randomize):
+    """`randomize_position` with its draws made on the device (dp_randomize_draws) - nothing crosses PCIe."""
+    if randomize.get("keep_update", False):
+        raise NotImplementedError("keep_update needs the host-drawn start randomisation (seed=None)")
+    L = _declare()
+    seed, uid = dev_noise
+    dev, B, nT = pb.device, pb.B, int(pb.tor_ptr[-1])
+    no_torsion, no_random = bool(randomize["no_torsion"]), bool(randomize["no_random"])
+    theta = torch.empty(max(nT, 1), dtype=torch.float32, device=dev) if (not no_torsion and nT) else None
+    rm = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+    tr = torch.empty(B, 3, dtype=torch.float32, device=dev) if not no_random else None
+    _lib.check(L.dp_randomize_draws(seed & 0xFFFFFFFFFFFFFFFF, C.byref(pb.struct), uid.data_ptr(), 0, float(randomize["tr_sigma_max"]),
+                                    _lib.ptr(theta), rm.data_ptr(), _lib.ptr(tr), _stream()), "dp_randomize_draws")
+    _randomize_launch(pb, theta, rm, tr, no_torsion)
+
+
 def _host_stage(part, device, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise,
-                randomize=None, rz=None):
+                randomize=None, rz=None, on_dev=False):
     """Everything that needs no device: pack the graphs, draw the start randomisation (if asked and not pre-drawn: `rz`) and then the
     run's normals - the reference's order for one complex: randomize_position(...) first, sampling_phore(...) after - and tabulate the
     times."""
     pb = PackedBatch(part, device, upload=False)
-    if randomize is not None and rz is None:
+    if randomize is not None and rz is None and not on_dev:
         rz = _randomize_draws(part, pb.nt, randomize["no_torsion"], randomize["no_random"], randomize["tr_sigma_max"],
                               randomize.get("keep_update", False), randomize.get("draws"))
     return _host_stage_noise_only(pb, len(part), inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random,
-                                  no_final_step_noise, batch_size, noise) + (rz,)
+                                  no_final_step_noise, batch_size, noise, on_dev) + (rz,)
 
 
 def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, no_random, ode,
-                 no_final_step_noise, visualization_list):
+                 no_final_step_noise, visualization_list, dev_noise=None):
     """Upload the run's noise / times and enqueue every step; no host synchronisation unless keep_update / visualisation ask for it."""
     pb, dev = eng.pb, eng.pb.device
     no_torsion = bool(getattr(model_args, "no_torsion", False))
@@ -97,7 +131,9 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
         g = os.environ.get("DIFFPHORE_GRAPH", "auto")
         use_graph = g == "1" or (g == "auto" and pb.B <= GRAPH_MAX_POSES)
         z_tor = Z["tor"] if (Z is not None and not no_torsion and Z["tor"].numel()) else None
-        eng.sample(sps, T_all, Z["tr"] if Z is not None else None, Z["rot"] if Z is not None else None, z_tor, graph=use_graph)
+        seed, uid = dev_noise if dev_noise is not None else (None, None)
+        eng.sample(sps, T_all, Z["tr"] if Z is not None else None, Z["rot"] if Z is not None else None, z_tor, graph=use_graph, seed=seed,
+                   pose_uid=uid)
         return
     for t_idx in range(inference_steps):
         last = t_idx == inference_steps - 1
@@ -105,7 +141,14 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
         sp = sps[t_idx]
         pb.t.copy_(T_all[t_idx].expand(pb.B, 3))
         z_tr = z_rot = z_tor = None
-        if not (ode or zero):
+        if not (ode or zero) and dev_noise is not None:
+            seed, uid = dev_noise
+            nT = int(pb.tor_ptr[-1])
+            z_tr, z_rot = torch.empty(pb.B, 3, device=dev), torch.empty(pb.B, 3, device=dev)
+            z_tor = torch.empty(nT, device=dev) if (not no_torsion and nT) else None
+            _lib.check(eng.L.dp_noise_normals(seed & 0xFFFFFFFFFFFFFFFF, t_idx, C.byref(pb.struct), uid.data_ptr(), 0, z_tr.data_ptr(),
+                                              z_rot.data_ptr(), _lib.ptr(z_tor), _stream()), "dp_noise_normals")
+        elif not (ode or zero):
             z_tr, z_rot, z_tor = Z["tr"][t_idx].contiguous(), Z["rot"][t_idx].contiguous(), Z["tor"][t_idx].contiguous()
             z_tor = z_tor if (not no_torsion and z_tor.numel()) else None
         eng.sample_step(sp, z_tr, z_rot, z_tor)
@@ -143,7 +186,8 @@ def _finish_run(eng, part):
 def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
                    no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
                    confidence_model_args=None, batch_size=20, no_final_step_noise=False, noise=None, engine: Optional[Engine] = None,
-                   write_back=True, max_poses: int = 8192, timing: Optional[dict] = None, randomize: Optional[dict] = None):
+                   write_back=True, max_poses: int = 8192, timing: Optional[dict] = None, randomize: Optional[dict] = None,
+                   seed: Optional[int] = None, pose_uid=None):
     """`randomize={'no_torsion','no_random','tr_sigma_max'[,'keep_update','draws']}` fuses `randomize_position` into the call: every
     device batch is packed once, randomised on the device and sampled, without the pack / D2H / re-pack round trip of two calls."""
     import time as _time
@@ -155,8 +199,10 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
         engine.pb.set_state(torch.cat([g["ligand"].pos for g in data_list]), torch.cat([g["ligand"].norm.reshape(-1, 33) for g in data_list]))
         if randomize is not None:
             raise ValueError("randomize= needs a batch packed by this call (engine=None)")
-        _, Z, T_all = _host_stage_noise_only(engine.pb, N, *common, ode, no_random, no_final_step_noise, batch_size, noise)
-        _enqueue_run(engine, Z, T_all, data_list, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list)
+        dev_noise = _device_noise(seed, noise, pose_uid, 0, N, engine.pb.device)
+        _, Z, T_all = _host_stage_noise_only(engine.pb, N, *common, ode, no_random, no_final_step_noise, batch_size, noise, dev_noise is not None)
+        _enqueue_run(engine, Z, T_all, data_list, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list,
+                     dev_noise)
         if write_back:
             _finish_run(engine, data_list)
         return data_list, None
@@ -168,7 +214,8 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
     # (S x N x (6 + T) floats on the host); the batches then take their slices.  The host stage of batch k+1 (packing, uploads) runs
     # while the GPU works on batch k: the step loop is enqueued without any host synchronisation.
     rz_all = None
-    if N > max_poses and noise is None:
+    on_dev = seed is not None and noise is None
+    if N > max_poses and noise is None and not on_dev:
         nt_all = np.asarray([int(torch.as_tensor(g["ligand"].edge_mask).sum()) for g in data_list], dtype=np.int64)
         if randomize is not None:
             rz_all = _randomize_draws(data_list, nt_all, randomize["no_torsion"], randomize["no_random"], randomize["tr_sigma_max"],
@@ -195,37 +242,84 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
             rzs.append(None)
         parts.append(part)
         t_off += nt_part
+    def gen():
+        for k, part in enumerate(parts):
+            lo = k * max_poses
+            yield part, subs[k], rzs[k], (list(pose_uid[lo:lo + len(part)]) if pose_uid is not None else range(lo, lo + len(part)))
+
+    for _ in _run_parts(gen(), model, device, common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, batch_size,
+                        visualization_list, randomize, seed if on_dev else None, write_back, timing):
+        pass
+    return data_list, None
+
+
+def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, batch_size,
+               visualization_list, randomize, seed, write_back, timing=None):
+    """The device-batch pipeline behind `sampling_phore` and `sampling_phore_stream`.  `parts_iter` yields
+    (pose list, noise tables | None, pre-drawn start randomisation | None, pose uids); the NEXT item is pulled - whatever lazy loading
+    the iterator does included - and host-staged while the GPU runs the current batch (the step loop is enqueued without any host
+    synchronisation), so at most two batches of host objects are alive.  Yields each pose list once its results are written back."""
+    import time as _time
+    on_dev = seed is not None
     _t0 = _time.time()
-    stage = _host_stage(parts[0], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[0], randomize, rzs[0])
-    for k, part in enumerate(parts):
-        pb, Z, T_all, rz = stage
+    it = iter(parts_iter)
+
+    def pull():
+        item = next(it, None)
+        if item is None:
+            return None
+        part, sub, rz, uids = item
+        return (part, uids) + _host_stage(part, device, *common, ode, no_random, no_final_step_noise, batch_size, sub, randomize, rz, on_dev)
+
+    cur, first = pull(), True
+    while cur is not None:
+        part, uids, pb, Z, T_all, rz = cur
         pb.upload()
+        dev_noise = _device_noise(seed, None, uids, 0, len(part), pb.device) if on_dev else None
         if rz is not None:
             _randomize_launch(pb, *rz, randomize["no_torsion"])
+        elif randomize is not None and on_dev:
+            _randomize_on_device(pb, dev_noise, randomize)
         eng = Engine(model.device_model, pb)
-        if timing is not None and k == 0:
+        if timing is not None and first:
             torch.cuda.synchronize()
             timing["pack_and_noise_s"] = _time.time() - _t0
             _t0 = _time.time()
-        _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list)
-        stage = (_host_stage(parts[k + 1], device, *common, ode, no_random, no_final_step_noise, batch_size, subs[k + 1], randomize, rzs[k + 1])
-                 if k + 1 < len(parts) else None)
-        if timing is not None and k == len(parts) - 1:
+        _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list, dev_noise)
+        nxt = pull()
+        if timing is not None and nxt is None:
             torch.cuda.synchronize()
             timing["loop_s"] = _time.time() - _t0
             _t0 = _time.time()
         if write_back:
             _finish_run(eng, part)
-    if timing is not None:
-        timing["write_back_s"] = _time.time() - _t0
-    return data_list, None
+        if timing is not None and nxt is None:
+            timing["write_back_s"] = _time.time() - _t0
+        yield part
+        cur, first = nxt, False
 
 
-def _host_stage_noise_only(pb, N, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise):
-    """`_host_stage` for an already packed batch."""
+def sampling_phore_stream(parts, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args, *, seed: int,
+                          no_random=False, ode=False, no_final_step_noise=False, randomize: Optional[dict] = None, write_back=True):
+    """`sampling_phore` over a STREAM of device batches for library-scale runs (virtual screening shards 10^5 ligands x 40
+    samples per GPU; the reference's loop is `for graph in dataset: [deepcopy(graph) x N] -> randomize -> sample`, inference.py:139-228).
+    `parts` is an iterable (typically a generator that builds its poses lazily) of `(pose_list, pose_uids)`; each pose list is one device
+    batch.  Noise - and with `randomize=` the start randomisation - is drawn on the device from (`seed`, pose uid), so nothing depends on
+    how the stream is cut into batches or ranks.  A generator: yields each pose list after its final positions are written back
+    (`g['ligand'].pos`); the caller consumes and drops it, the pipeline keeps at most two batches of host objects alive."""
+    if seed is None:
+        raise ValueError("the streaming sampler draws its noise on the device: seed is required")
+    common = (inference_steps, tr_schedule, rot_schedule, tor_schedule)
+    yield from _run_parts(((p, None, None, u) for p, u in parts), model, device, common, t_to_sigma, model_args, no_random, ode,
+                          no_final_step_noise, 20, None, randomize, int(seed), write_back)
+
+
+def _host_stage_noise_only(pb, N, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise,
+                           on_dev=False):
+    """`_host_stage` for an already packed batch (`on_dev`: the noise is drawn on the device, nothing to prepare here)."""
     steps = _noisy_steps(inference_steps, ode, no_random, no_final_step_noise)
     Z = None
-    if steps:
+    if steps and not on_dev:
         if noise is not None:
             Z = {k: noise[k].to(torch.float32) for k in ("tr", "rot", "tor")}
         else:

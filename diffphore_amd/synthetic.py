@@ -274,6 +274,56 @@ def example_complex(sdf_path: str, phore_path: str, seed: int = BASE_SEED + 1, n
     return make_complex(lig, phore_io.phore_graph(ph), name=name)
 
 
+class ScreenLibrary:
+    """A lazily generated synthetic screening library with the shapes of BASELINE configs[3] (cfg_id 4: ONE 79-node pharmacophore x
+    ligands of 15-45 atoms) or configs[4] (cfg_id 5: pharmacophores of 12-80 nodes x ONE ligand).  Unit i is a pure function of
+    (seed, i): a rank can size the whole library (`sizes`, `cost`: a few integers per unit, no graph is built), shard it, and then build
+    only the units it owns, one at a time - the reference walks its dataset the same way (`for idx, graph in enumerate(loader)`,
+    src/inference.py:139), here without ever holding more than the units of two device batches."""
+
+    def __init__(self, cfg_id: int, n_units: int, seed: Optional[int] = None):
+        if cfg_id not in (4, 5):
+            raise ValueError("screening libraries exist for configs 4 (virtual screen) and 5 (target fishing)")
+        self.cfg_id, self.n_units = cfg_id, int(n_units)
+        self.seed = BASE_SEED + cfg_id if seed is None else int(seed)
+        self.shape = CONFIGS[cfg_id]
+        rng = np.random.Generator(np.random.PCG64([self.seed, 0x5EED]))
+        na, nt, npn = self.shape["n_atoms"], self.shape["n_tor"], self.shape["n_phore"]
+        # the replicated side: the pharmacophore (built around a template ligand) or the ligand
+        tmpl = make_ligand(rng, 30 if not np.isscalar(na) else int(na), 8 if not np.isscalar(nt) else int(nt))
+        self._shared_lig = tmpl if cfg_id == 5 else None
+        self._shared_ph = make_phore(rng, int(npn), tmpl["pos"]) if cfg_id == 4 else None
+        self._tmpl_pos = tmpl["pos"]
+
+    def __len__(self):
+        return self.n_units
+
+    def _rng(self, i: int) -> np.random.Generator:
+        return np.random.Generator(np.random.PCG64([self.seed, int(i)]))
+
+    def _draw_sizes(self, rng):
+        def draw(v):
+            return int(v) if np.isscalar(v) else int(rng.integers(v[0], v[1] + 1))
+        nl, nt, npn = draw(self.shape["n_atoms"]), draw(self.shape["n_tor"]), draw(self.shape["n_phore"])
+        return nl, min(nt, nl // 3), npn            # a small random tree cannot carry many rotatable bonds
+
+    def sizes(self, i: int) -> Tuple[int, int, int]:
+        """(atoms, requested torsions, pharmacophore nodes) of unit i"""
+        return self._draw_sizes(self._rng(i))
+
+    def cost(self, i: int) -> int:
+        """the same estimate as `distributed.pose_cost`, from the sizes alone"""
+        nl, _, npn = self.sizes(i)
+        return nl * npn + 25 * nl + 8 * npn
+
+    def unit(self, i: int) -> HeteroData:
+        rng = self._rng(i)
+        nl, nt, npn = self._draw_sizes(rng)
+        lig = self._shared_lig if self._shared_lig is not None else make_ligand(rng, nl, nt)
+        ph = self._shared_ph if self._shared_ph is not None else make_phore(rng, npn, self._tmpl_pos)
+        return make_complex(lig, ph, name=f"lib{self.cfg_id}_{i}")
+
+
 # BASELINE.json configs -> shapes (SURVEY.md §8d)
 CONFIGS = {
     1: dict(n_atoms=20, n_tor=5, n_phore=79, samples=40, steps=20),     # shape of STK936575 x sQC phore example

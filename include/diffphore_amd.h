@@ -31,7 +31,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 4
+#define DP_ABI_VERSION 5
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -265,6 +265,7 @@ typedef struct DpWork {
    * layer (and the torsion head) on `aux_stream`, forked from / joined back to the launch stream with the events.  Results are
    * bit-identical; it only helps batches too small to fill the chip with one conv at a time.  Capturable into a hipGraph. */
   void *aux_stream, *ev_fork, *ev_join;
+  float* z_noise;                   /* [6 B + n_tor] scratch of DP_NOISE_SEED: one step's z_tr | z_rot | z_tor */
   int32_t conv_fuse;                /* node-side convs of a layer that scatter onto the same nodes: 0 = one fused launch per side (default),
                                        1 = one launch per conv (A/B runs and tests) */
 } DpWork;
@@ -343,7 +344,29 @@ typedef struct DpSchedule {
   const float* t;                /* DEVICE [steps,3]: t_tr, t_rot, t_tor of every step (set_time_phore broadcasts them to all poses) */
   const float *z_tr, *z_rot;     /* DEVICE pre-drawn normals [steps,B,3] or NULL */
   const float* z_tor;            /* DEVICE [steps,n_tor] or NULL */
+  /* noise_mode DP_NOISE_TABLES (0): the z_* tables above (NULL = zeros) - the parity path, identical noise for a CPU run.
+   * noise_mode DP_NOISE_SEED (1): z_* are ignored; every step's normals are drawn on the device into DpWork.z_noise by
+   * dp_noise_normals(seed, step, ...) - a pure function of (seed, pose uid, step, component), so a pose's trajectory does not depend on
+   * the rank / device batch / position it is processed at.  Stands where the reference draws inside its loop (sampling.py:230-243). */
+  int32_t noise_mode;
+  int32_t uid_base;              /* pose p's uid = pose_uid ? pose_uid[p] : uid_base + p */
+  const int32_t* pose_uid;       /* DEVICE [B] or NULL */
+  uint64_t seed;
 } DpSchedule;
+#define DP_NOISE_TABLES 0
+#define DP_NOISE_SEED 1
+#define DP_RNG_STEP_START 0xFFFFFFFFu    /* the `step` word of the start-randomisation draws */
+
+/* N(0, 1) draws of reverse step `step` for every pose of the batch: z_tr [B,3], z_rot [B,3], z_tor [n_tor] (DEVICE; any may be NULL).
+ * Philox-4x32-10, key = seed, counter = (pose uid, step, block, stream) - layout in csrc/dp_rng.hip. */
+int dp_noise_normals(uint64_t seed, int32_t step, const DpBatch* b, const int32_t* pose_uid, int32_t uid_base, float* z_tr, float* z_rot,
+                     float* z_tor, void* stream);
+/* the draws of randomize_position (sampling.py:16-63) on the device, same keying: theta [n_tor] ~ U(-pi, pi), rot_mats [B,3,3] uniform
+ * on SO(3), tr [B,3] ~ N(0, tr_sigma_max) - the arguments dp_randomize_position takes (any may be NULL). */
+int dp_randomize_draws(uint64_t seed, const DpBatch* b, const int32_t* pose_uid, int32_t uid_base, float tr_sigma_max, float* theta,
+                       float* rot_mats, float* tr, void* stream);
+/* the generator itself on the host (known-answer tests) */
+int dp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 int dp_sample(const DpBatch* b, const DpWeights* w, DpWork* k, const DpSchedule* s, float* tr, float* rot, float* tor, void* stream);
 /* the same loop captured into a hipGraph (all pointers are baked in): create once per (batch, workspace, schedule), replay with
  * dp_sample_graph_launch; bit-identical to dp_sample */
@@ -357,7 +380,7 @@ int dp_sample_graph_destroy(void* graph_exec);
 int dp_aux_create(void** aux_stream, void** ev_fork, void** ev_join);
 int dp_aux_destroy(void* aux_stream, void* ev_fork, void* ev_join);
 
-/* sizeof() of DpConvArgs, DpBatch, DpWeights, DpWork, DpStepParams, DpMlp (binding self-check) */
+/* sizeof() of DpConvArgs, DpBatch, DpWeights, DpWork, DpStepParams, DpMlp, DpSchedule (binding self-check); returns how many exist */
 int dp_struct_sizes(int32_t* out, int32_t n);
 
 int dp_abi_version(void);

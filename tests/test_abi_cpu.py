@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
             "dp_sample_graph_destroy", "dp_conformer_update", "dp_prepare", "dp_randomize_position", "dp_fit_overlap",
             "dp_pack_conv_weights", "dp_pack_conv_weights_node", "dp_pack_bn", "dp_work_bytes", "dp_work_bind", "dp_work_init",
             "dp_weights_segments", "dp_weights_blob_floats", "dp_weights_bind", "dp_resolve_conv_algo", "dp_abi_version",
-            "dp_struct_sizes"} <= names
+            "dp_struct_sizes", "dp_noise_normals", "dp_randomize_draws", "dp_philox4x32", "dp_forward_launch_of", "dp_tp_conv_node_fused"} <= names
     L = _lib.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in the header but not exported"
@@ -26,11 +26,11 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_compiler():
     L = _lib.lib()
-    out = (C.c_int32 * 6)()
+    out = (C.c_int32 * 7)()
     L.dp_struct_sizes.argtypes = [C.POINTER(C.c_int32), C.c_int32]
-    assert L.dp_struct_sizes(out, 6) == 6
+    assert L.dp_struct_sizes(out, 7) == 7
     want = [C.sizeof(_lib.DpConvArgs), C.sizeof(engine.DpBatch), C.sizeof(engine.DpWeights), C.sizeof(engine.DpWork),
-            C.sizeof(engine.DpStepParams), C.sizeof(engine.DpMlp)]
+            C.sizeof(engine.DpStepParams), C.sizeof(engine.DpMlp), C.sizeof(engine.DpSchedule)]
     assert list(out) == want
 
 
@@ -107,3 +107,19 @@ def test_product_fails_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.DiffPhoreLibraryError):
         _lib.lib()
+
+
+def test_philox_known_answers():
+    """Philox-4x32-10 against the known-answer vectors published with Random123 (kat_vectors: philox4x32 10): the generator behind
+    dp_noise_normals / dp_randomize_draws, evaluated by the library's host entry point (same code as the device function)."""
+    L = _lib.lib()
+    U4, U2 = C.c_uint32 * 4, C.c_uint32 * 2
+    L.dp_philox4x32.argtypes = [U4, U2, U4]
+    L.dp_philox4x32.restype = C.c_int
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        out = U4()
+        assert L.dp_philox4x32(U4(*ctr), U2(*key), out) == 0
+        assert tuple(out) == want, [hex(x) for x in out]

@@ -66,3 +66,29 @@ def test_two_rank_broadcast_shard_gather():
         assert p.exitcode == 0
     assert all(r[0] and r[1] for r in res)
     assert sum(r[2] for r in res) == 7
+
+
+def test_screen_library_units_are_pure_functions_of_seed_and_index():
+    """synthetic.ScreenLibrary: sizes / cost of a unit without building it, identical units from any rank in any order, and the
+    replicated side (the pharmacophore of a virtual screen, the ligand of target fishing) shared by every unit."""
+    import torch
+    from diffphore_amd import distributed as D
+    from diffphore_amd import synthetic
+    lib = synthetic.ScreenLibrary(4, 50)
+    costs = [lib.cost(i) for i in range(len(lib))]
+    for i in (0, 7, 49):
+        g = lib.unit(i)
+        nl, nt, npn = lib.sizes(i)
+        assert g["ligand"].pos.shape[0] == nl and g["phore"].pos.shape[0] == npn == 79 and int(g["ligand"].edge_mask.sum()) <= nt
+        assert D.pose_cost(g) == costs[i]
+        assert torch.equal(lib.unit(i)["ligand"].pos, g["ligand"].pos)
+    assert torch.equal(lib.unit(3)["phore"].pos, lib.unit(30)["phore"].pos) and not torch.equal(lib.unit(3)["ligand"].pos[:5], lib.unit(30)["ligand"].pos[:5])
+    assert len({lib.sizes(i)[0] for i in range(50)}) > 10                       # 15..45 atoms
+    # every unit is owned by exactly one rank, whatever the world size
+    for world in (1, 2, 8):
+        sh = D.shard_indices(costs, world)
+        assert sorted(i for s_ in sh for i in s_) == list(range(50))
+    lib5 = synthetic.ScreenLibrary(5, 10)
+    a, b = lib5.unit(1), lib5.unit(8)                                           # the same ligand, placed relative to each phore's centre
+    assert torch.allclose(a["ligand"].pos + a["original_center"], b["ligand"].pos + b["original_center"], atol=1e-5)
+    assert torch.equal(a["ligand"].x, b["ligand"].x) and a["phore"].pos.shape[0] == lib5.sizes(1)[2] != b["phore"].pos.shape[0]

@@ -1,0 +1,282 @@
+"""On-device noise (dp_noise_normals / dp_randomize_draws, SURVEY.md 8b `seed` path of dp_sample) and the streaming screen driver
+(distributed.screen).
+
+The seeded path is NOT the reference's random stream (that is what `noise=` / the global generators are for); what it must be is
+    * statistically right: N(0, 1) normals, U(-pi, pi) torsions, Haar-uniform rotations (scipy KS tests on ~10^5 draws),
+    * a pure function of (seed, pose uid, step, component): the same pose gets the same trajectory whatever the batch composition,
+      the device-batch size, the order of the stream or the number of ranks - bit for bit on the noise, <= 2e-5 A on trajectories
+      (the batch composition changes the workgroup slicing of the edge-side convs, not the noise),
+    * built from the Philox words the host entry point returns (tests/test_abi_cpu.py pins those to the published vectors).
+"""
+import ctypes as C
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+from scipy import stats
+
+pytestmark = pytest.mark.gpu
+
+from diffphore_amd import config, synthetic, weights  # noqa: E402
+
+
+def _args():
+    cfg = config.ModelConfig()
+    return types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False, inference_steps=3)
+
+
+def _rmsd(a, b):
+    return float(np.sqrt(((np.asarray(a) - np.asarray(b)) ** 2).sum(-1).mean()))
+
+
+def _draw(pb, seed, step, uid=None, uid_base=0):
+    from diffphore_amd import _lib
+    from diffphore_amd.engine import _declare, _stream
+    L = _declare()
+    B, nT = pb.B, int(pb.tor_ptr[-1])
+    ztr, zrot, ztor = torch.empty(B, 3, device="cuda"), torch.empty(B, 3, device="cuda"), torch.empty(max(nT, 1), device="cuda")
+    _lib.check(L.dp_noise_normals(seed, step, C.byref(pb.struct), _lib.ptr(uid), uid_base, ztr.data_ptr(), zrot.data_ptr(), ztor.data_ptr(),
+                                  _stream()), "dp_noise_normals")
+    torch.cuda.synchronize()
+    return ztr.cpu().numpy(), zrot.cpu().numpy(), ztor.cpu().numpy()[:nT]
+
+
+_POOL = []
+
+
+def _pool():
+    """300 small complexes (seconds to build), shared by the statistics tests: sample counts come from steps / seeds, not from poses"""
+    if not _POOL:
+        _POOL.extend(synthetic.synthetic_pairs(41, 300, (15, 30), (2, 5), 12))
+    return _POOL
+
+
+def test_step_normals_are_standard_normal_and_keyed_by_uid_and_step():
+    from diffphore_amd import _lib
+    from diffphore_amd.engine import PackedBatch
+    gs = _pool()
+    pb = PackedBatch(gs, "cuda")
+    a = _draw(pb, 1234, 0)
+    steps = [a] + [_draw(pb, 1234, s_) for s_ in range(1, 12)]
+    allz = np.concatenate([x.reshape(-1) for st in steps for x in st])
+    assert allz.size > 25000 and np.isfinite(allz).all()
+    print("n =", allz.size, "mean %.4f var %.4f skew %.4f kurt %.4f" % (allz.mean(), allz.var(), stats.skew(allz), stats.kurtosis(allz)))
+    assert abs(allz.mean()) < 4 / np.sqrt(allz.size) and abs(allz.var() - 1) < 0.03
+    assert stats.kstest(allz, "norm").pvalue > 1e-3
+    for t in range(3):                                                      # each table on its own, too
+        assert stats.kstest(np.concatenate([st[t].reshape(-1) for st in steps]), "norm").pvalue > 1e-3
+    # components of one pose are independent draws (no word is used twice): correlation of z_tr vs z_rot columns ~ 0
+    cc = np.corrcoef(np.concatenate([np.concatenate([st[0], st[1]], 1) for st in steps]).T)
+    assert np.abs(cc - np.eye(6)).max() < 5 / np.sqrt(len(gs) * len(steps))
+    # same (seed, step) -> same numbers; another step or seed -> fresh ones
+    b = _draw(pb, 1234, 0)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    c, d = steps[1], _draw(pb, 1235, 0)
+    assert abs(np.corrcoef(a[0].reshape(-1), c[0].reshape(-1))[0, 1]) < 0.15 and abs(np.corrcoef(a[2], d[2])[0, 1]) < 0.15
+    # keyed by the pose uid, not by the position in the batch: a permuted batch with the uids carried along draws the same numbers
+    perm = np.random.default_rng(0).permutation(len(gs))
+    pb2 = PackedBatch([gs[i] for i in perm], "cuda")
+    uid = torch.from_numpy(perm.astype(np.int32)).cuda()
+    e = _draw(pb2, 1234, 0, uid=uid)
+    assert np.array_equal(e[0], a[0][perm]) and np.array_equal(e[1], a[1][perm])
+    tp = pb.tor_ptr
+    assert np.array_equal(e[2], np.concatenate([a[2][int(tp[i]):int(tp[i + 1])] for i in perm]))
+    # uid_base shifts the default uids
+    f = _draw(PackedBatch(gs[100:110], "cuda"), 1234, 0, uid_base=100)
+    assert np.array_equal(f[0], a[0][100:110])
+    # the first normal of pose 0 from the host-side Philox words (Box-Muller on (x >> 8 + 0.5) * 2^-24)
+    U4, U2 = C.c_uint32 * 4, C.c_uint32 * 2
+    L = _lib.lib()
+    L.dp_philox4x32.argtypes = [U4, U2, U4]
+    out = U4()
+    L.dp_philox4x32(U4(0, 0, 0, 0), U2(1234, 0), out)
+    u = [((x >> 8) + 0.5) / 16777216.0 for x in out]
+    want = [np.sqrt(-2 * np.log(u[0])) * np.cos(2 * np.pi * u[1]), np.sqrt(-2 * np.log(u[0])) * np.sin(2 * np.pi * u[1]),
+            np.sqrt(-2 * np.log(u[2])) * np.cos(2 * np.pi * u[3]), np.sqrt(-2 * np.log(u[2])) * np.sin(2 * np.pi * u[3])]
+    got = [a[0][0, 0], a[0][0, 1], a[0][0, 2], a[1][0, 0]]
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_start_randomisation_draws_are_uniform():
+    from diffphore_amd import _lib
+    from diffphore_amd.engine import PackedBatch, _declare, _stream
+    gs = _pool()
+    pb = PackedBatch(gs, "cuda")
+    B, nT = pb.B, int(pb.tor_ptr[-1])
+    L = _declare()
+    ths, rms, trs = [], [], []
+    for seed in range(77, 87):                                              # 10 seeds x 300 poses
+        th, rm, tr = torch.empty(nT, device="cuda"), torch.empty(B, 3, 3, device="cuda"), torch.empty(B, 3, device="cuda")
+        _lib.check(L.dp_randomize_draws(seed, C.byref(pb.struct), None, 0, 5.0, th.data_ptr(), rm.data_ptr(), tr.data_ptr(), _stream()), "draws")
+        torch.cuda.synchronize()
+        ths.append(th.cpu().numpy()), rms.append(rm.cpu().numpy().astype(np.float64)), trs.append(tr.cpu().numpy())
+    th, rm, tr = np.concatenate(ths), np.concatenate(rms), np.concatenate(trs)
+    assert np.abs(th).max() < np.pi and stats.kstest(th, "uniform", args=(-np.pi, 2 * np.pi)).pvalue > 1e-3
+    assert stats.kstest(tr.reshape(-1) / 5.0, "norm").pvalue > 1e-3
+    # proper rotations ...
+    assert np.abs(rm @ rm.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5 and np.abs(np.linalg.det(rm) - 1).max() < 1e-5
+    # ... Haar-uniform: the image of a fixed vector is uniform on the sphere (z ~ U(-1, 1)), and the rotation angle has density
+    # (1 - cos w) / pi on [0, pi]
+    z = rm[:, 2, 0]
+    assert stats.kstest(z, "uniform", args=(-1, 2)).pvalue > 1e-3
+    w = np.arccos(np.clip((np.trace(rm, axis1=1, axis2=2) - 1) / 2, -1, 1))
+    assert stats.kstest(w, lambda x: (x - np.sin(x)) / np.pi).pvalue > 1e-3
+
+
+def _model():
+    from diffphore_amd.score_model import TensorProductScoreModel
+    return TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+
+
+def test_seeded_sampler_is_independent_of_batching_and_order():
+    """sampling_phore(seed=...) with start randomisation on the device: one device batch vs three (max_poses), and a shuffled pose list
+    carrying its uids - the same pose ends at the same place."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    gs = synthetic.synthetic_pairs(43, 12, (14, 30), (2, 4), (10, 40))
+    args, S = _args(), 3
+    sched = get_t_schedule(20)[:S + 1]
+    m = _model()
+    rz = dict(no_torsion=False, no_random=False, tr_sigma_max=args.tr_sigma_max)
+
+    def run(order, **kw):
+        poses = [gs[i].sample_copy() for i in order]
+        out, _ = sampling_phore(poses, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, seed=99, randomize=rz,
+                                pose_uid=list(order), **kw)
+        return {i: g["ligand"].pos.numpy().copy() for i, g in zip(order, out)}
+
+    base = run(list(range(12)))
+    assert all(np.isfinite(v).all() for v in base.values())
+    small = run(list(range(12)), max_poses=5)
+    shuf = run([7, 3, 11, 0, 5, 9, 1, 2, 10, 4, 8, 6], max_poses=7)
+    for other, what in ((small, "three device batches"), (shuf, "shuffled + two device batches")):
+        worst = max(_rmsd(base[i], other[i]) for i in range(12))
+        print(what, "worst RMSD vs one batch (A):", worst)
+        assert worst < 2e-5
+    # another seed gives other trajectories
+    poses = [gs[i].sample_copy() for i in range(12)]
+    out, _ = sampling_phore(poses, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, seed=100, randomize=rz)
+    assert min(_rmsd(base[i], out[i]["ligand"].pos.numpy()) for i in range(12)) > 0.1
+    # the step-by-step host loop (keep_update path) consumes the same device draws as the whole-loop call
+    os.environ["DIFFPHORE_WHOLE_LOOP"] = "0"
+    try:
+        step = run(list(range(12)))
+    finally:
+        os.environ.pop("DIFFPHORE_WHOLE_LOOP")
+    assert max(_rmsd(base[i], step[i]) for i in range(12)) < 2e-5
+
+
+def test_seeded_poses_of_one_complex_differ():
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    g = synthetic.synthetic_pairs(44, 1, 20, 5, 16)[0]
+    args, S = _args(), 2
+    sched = get_t_schedule(20)[:S + 1]
+    poses = [g.sample_copy() for _ in range(6)]
+    out, _ = sampling_phore(poses, _model(), S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, seed=5,
+                            randomize=dict(no_torsion=False, no_random=False, tr_sigma_max=args.tr_sigma_max), pose_uid=[0, 1, 2, 3, 4, 0])
+    p = [x["ligand"].pos.numpy() for x in out]
+    assert _rmsd(p[0], p[5]) < 1e-6                      # same uid -> same pose
+    assert min(_rmsd(p[i], p[j]) for i in range(5) for j in range(i)) > 0.5
+
+
+def test_screen_stream_equals_one_call_and_keeps_two_batches_alive():
+    """distributed.screen over a lazily built library: equal to sampling_phore on the materialised pose list (same seed / uids), the
+    loader is called once per owned unit, and never more than two device batches' worth of units are alive at once."""
+    import gc
+    import weakref
+
+    from diffphore_amd import distributed as D
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    lib = synthetic.ScreenLibrary(4, 9)
+    args, NS = _args(), 4
+    m = _model()
+    alive, calls, peak = [], [], [0]
+
+    def load(i):
+        g = lib.unit(i)
+        calls.append(i)
+        alive.append(weakref.ref(g))
+        gc.collect()
+        peak[0] = max(peak[0], sum(r() is not None for r in alive))
+        return g
+
+    res = {}
+    mine, coll = D.screen(len(lib), load, m, args, costs=[lib.cost(i) for i in range(len(lib))], samples_per_complex=NS, max_poses=2 * NS,
+                          seed=321, on_result=lambda i, arr: res.__setitem__(i, arr))
+    assert coll is None and sorted(mine) == list(range(9)) and sorted(calls) == list(range(9)) and sorted(res) == list(range(9))
+    print("units alive at once (2 units per device batch):", peak[0])
+    assert peak[0] <= 4 + 1                      # current batch + the staged next one (+ the unit being built)
+    poses = [lib.unit(i).sample_copy() for i in range(9) for _ in range(NS)]
+    sched = get_t_schedule(args.inference_steps)
+    out, _ = sampling_phore(poses, m, args.inference_steps, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, seed=321,
+                            randomize=dict(no_torsion=False, no_random=False, tr_sigma_max=args.tr_sigma_max),
+                            pose_uid=[i * NS + s for i in range(9) for s in range(NS)])
+    worst = max(_rmsd(res[i][s], out[i * NS + s]["ligand"].pos.numpy()) for i in range(9) for s in range(NS))
+    print("worst RMSD streamed vs one call (A):", worst)
+    assert worst < 2e-5 and all(r.shape == (NS, lib.sizes(i)[0], 3) for i, r in res.items())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _screen_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from diffphore_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        lib = synthetic.ScreenLibrary(4, 7)
+        built = []
+
+        def load(i):
+            built.append(i)
+            return lib.unit(i)
+        res = {}
+        mine, _ = D.screen(len(lib), load, _model(), _args(), costs=[lib.cost(i) for i in range(len(lib))], samples_per_complex=3,
+                           max_poses=6, seed=11, on_result=lambda i, arr: res.__setitem__(i, arr))
+        assert sorted(built) == sorted(mine)                    # a rank builds its own units only
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(res, gathered, dst=0)
+        if rank == 0:
+            q.put({k: v for d in gathered for k, v in d.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_screen_two_ranks_equal_one_rank_with_the_same_seed():
+    import torch.multiprocessing as mp
+    from diffphore_amd import distributed as D
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_screen_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        sharded = q.get(timeout=150)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    lib = synthetic.ScreenLibrary(4, 7)
+    res = {}
+    D.screen(len(lib), lib.unit, _model(), _args(), samples_per_complex=3, max_poses=8192, seed=11, on_result=lambda i, arr: res.__setitem__(i, arr))
+    assert sorted(sharded) == sorted(res) == list(range(7))
+    worst = max(_rmsd(sharded[i][s], res[i][s]) for i in range(7) for s in range(3))
+    print("worst RMSD two ranks vs one (A):", worst)
+    assert worst < 2e-5

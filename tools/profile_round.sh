@@ -5,12 +5,12 @@ tag=${1:-r2}
 cd "$(dirname "$0")/.." || exit 1
 export PYTHONPATH=. TMPDIR=/tmp
 mkdir -p gpurun_out
-CMD="python bench.py --steps 40 --warmup 5 --no-alt --no-e2e --no-cpu-baseline"
+CMD="python bench.py --steps 40 --warmup 5 --no-alt --no-e2e --no-cpu-baseline --no-other"
 $CMD > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rm -rf /tmp/prof_$tag; mkdir -p /tmp/prof_$tag
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag/trace -o t -- python $OLDPWD/bench.py --steps 40 --warmup 5 --no-alt --no-e2e --no-cpu-baseline > /tmp/prof_$tag/trace.out 2>&1)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_$tag/fetch -o f -- python $OLDPWD/bench.py --steps 8 --warmup 2 --no-alt --no-e2e --no-cpu-baseline > /tmp/prof_$tag/fetch.out 2>&1)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_$tag/write -o w -- python $OLDPWD/bench.py --steps 8 --warmup 2 --no-alt --no-e2e --no-cpu-baseline > /tmp/prof_$tag/write.out 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag/trace -o t -- python $OLDPWD/bench.py --steps 40 --warmup 5 --no-alt --no-e2e --no-cpu-baseline --no-other > /tmp/prof_$tag/trace.out 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_$tag/fetch -o f -- python $OLDPWD/bench.py --steps 8 --warmup 2 --no-alt --no-e2e --no-cpu-baseline --no-other > /tmp/prof_$tag/fetch.out 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_$tag/write -o w -- python $OLDPWD/bench.py --steps 8 --warmup 2 --no-alt --no-e2e --no-cpu-baseline --no-other > /tmp/prof_$tag/write.out 2>&1)
 T=$(find /tmp/prof_$tag/trace -name '*.db' | head -1); F=$(find /tmp/prof_$tag/fetch -name '*.db' | head -1); W=$(find /tmp/prof_$tag/write -name '*.db' | head -1)
 echo "dbs: $T $F $W"
 python tools/summarize_prof.py gpurun_out/$tag "$T" --fetch "$F" --write "$W" --bench gpurun_out/${tag}_bench.json --command "rocprofv3 --kernel-trace --stats -- $CMD (PMC passes: --steps 8 --warmup 2)"

@@ -14,16 +14,20 @@ import sqlite3
 # launch order of the convs of one kernel instantiation inside one dp_forward (dp_graph.hip)
 EDGE_ALL = ["lig-lig", "phore->lig", "phore->lig(norm)", "phore-phore", "lig->phore", "lig->phore(norm)"]
 SLOTS = {}
+# node-side kernels: tp_conv_node_kernel<KIND, HAS_LL, XMODE> (and the _split_ twin for small batches); default dp_forward fuses the convs
+# of a side into one launch, so every instantiation is launched once per forward
+LIG3, LIG2, PH2 = "lig-lig + phore->lig + phore->lig(norm)", "phore->lig + phore->lig(norm)", "lig->phore + lig->phore(norm)"
 for k in range(4):
-    SLOTS[f"tp_conv_node_kernel<{k}, 4>"] = ["lig-lig"]
-    SLOTS[f"tp_conv_node_kernel<{k}, 1>"] = ["phore->lig", "phore->lig(norm)"]
-    SLOTS[f"tp_conv_node_kernel<{k}, 2>"] = ["lig->phore", "lig->phore(norm)"]
+    for kn in ("tp_conv_node_kernel", "tp_conv_node_split_kernel"):
+        SLOTS[f"{kn}<{k}, true, 1>"] = [LIG3]
+        SLOTS[f"{kn}<{k}, false, 1>"] = [LIG2]
+        SLOTS[f"{kn}<{k}, false, 2>"] = [PH2]
 SLOTS["tp_conv_kernel<4>"] = ["centre (final_conv)"]
 SLOTS["tp_conv_kernel<5>"] = ["torsion bonds (tor_bond_conv)"]
 # SURVEY.md 8d per edge-conv (edge-side count): 2*(n_attr*hid + hid*numel) + 2*sum_paths mul_in*mul_out*(2 l_out + 1); kinds 4 / 5 = the
 # centre head (fc 40->40->200, out 2x1o+2x1e) and the torsion head (fc 60->60->1600, scalar outputs)
 FLOPS = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400, 4: 19200 + 1200, 5: 199200 + 3200}
-EDGE_SET = {"lig-lig": "ll", "phore-phore": "pp", "phore->lig": "x", "phore->lig(norm)": "x", "lig->phore": "x", "lig->phore(norm)": "x",
+EDGE_SET = {LIG3: ("ll", "x", "x"), LIG2: ("x", "x"), PH2: ("x", "x"), "lig-lig": "ll", "phore-phore": "pp", "phore->lig": "x", "phore->lig(norm)": "x", "lig->phore": "x", "lig->phore(norm)": "x",
             "centre (final_conv)": "center", "torsion bonds (tor_bond_conv)": "tor"}
 
 
@@ -36,8 +40,8 @@ def slot_names(kernels_seen):
     """edge-side layer kernels: all six slots when the node-side kernel is absent, only phore-phore (and lig-lig when that ran
     edge-side) otherwise"""
     s = dict(SLOTS)
-    node = any("tp_conv_node_kernel" in k for k in kernels_seen)
-    node_ll = any("tp_conv_node_kernel" in k and ", 4>" in k for k in kernels_seen)
+    node = any("tp_conv_node" in k for k in kernels_seen)
+    node_ll = any("tp_conv_node" in k and ", true, " in k for k in kernels_seen)
     for k in range(4):
         n = f"tp_conv_kernel<{k}>"
         if not node:
@@ -89,8 +93,10 @@ def main():
                 continue
             avg = sum(d) / len(d)
             tf = ""
-            if kind in FLOPS and EDGE_SET.get(sname) in edges:
-                tf = f"{FLOPS[kind] * edges[EDGE_SET[sname]] / (avg * 1e-6) / 1e12:.1f}"
+            es = EDGE_SET.get(sname)
+            es = es if isinstance(es, tuple) else (es,)
+            if kind in FLOPS and all(x in edges for x in es):
+                tf = f"{FLOPS[kind] * sum(edges[x] for x in es) / (avg * 1e-6) / 1e12:.1f}"
             lines.append(f"{k},{sname},{len(d)},{avg:.2f},{min(d):.2f},{max(d):.2f},{tf}")
     open(f"{a.prefix}_conv_slots.csv", "w").write("\n".join(lines) + "\n")
 
@@ -115,7 +121,7 @@ def main():
                 if f and w:
                     fa, wa = sum(f) / len(f), sum(w) / len(w)
                     res.append(f"{k},{sname},{len(f)},{fa:.1f},{wa:.1f},{2 * fa / 1024:.2f},{wa / 1024:.2f}")
-                    if k.startswith(("tp_conv_node_kernel<2, 1>", "tp_conv_kernel<2>")) and sname == "phore->lig":
+                    if (k.startswith("tp_conv_node") and k.endswith("<2, true, 1>")) or (k == "tp_conv_kernel<2>" and sname == "phore->lig"):
                         rec = int((2 * fa + wa) * 1024)
         open(f"{a.prefix}_conv_hbm_traffic.csv", "w").write("\n".join(res) + "\n")
         if rec is not None and bench is not None:
