@@ -364,7 +364,59 @@ def main():
         e2e = {"what": "drop-in sampling_phore(data_list) incl. host packing, noise draw/upload and write-back", "poses": len(gl),
                "steps": S_total, "seconds": dt, "value": len(gl) * S_total / dt, "unit": "pose-steps/s",
                "breakdown_s": {k: round(v, 4) for k, v in tm.items()}}
+        # the same call with the noise drawn on the device (seed=): no S x N x (6 + T) normals drawn by one host thread and uploaded
+        gl = [g.sample_copy() for g in graphs]
+        tm2 = {}
+        t0 = time.perf_counter()
+        sampling_phore(gl, m, S_total, sched, sched, sched, dev, t2s, margs, batch_size=20, timing=tm2, seed=607201)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        e2e["seeded"] = {"what": "same call, noise drawn on the device (dp_noise_normals, seed=)", "seconds": dt2, "value": len(gl) * S_total / dt2,
+                         "breakdown_s": {k: round(v, 4) for k, v in tm2.items()}}
         del copy
+
+    e2e_screen = None
+    if not a.no_e2e and world == 1 and (a.config in (4, 5) or (a.config == 2 and not a.no_other and a.precision is None and a.conv_algo is None and a.poses is None)):
+        # secondary figure for the library workloads (configs[3] virtual screen / configs[4] target fishing): the streaming driver
+        # distributed.screen over a lazily generated library 3x the per-GPU bench size - units are built on the host (`load_unit`) while
+        # the GPU samples the previous device batch, start randomisation and noise are drawn on the device (seed), every finished
+        # complex is handed to a sink and dropped.  Reported: whole-call pose-steps/s, the host time spent building units (hidden behind
+        # the device loop except for the first batch) and the process RSS before / after (flat = nothing accumulates).
+        import resource
+
+        from diffphore_amd import distributed as D
+        from diffphore_amd import synthetic
+        from diffphore_amd.score_model import TensorProductScoreModel
+        c = a.config if a.config in (4, 5) else 4
+        n_lib = 3 * (units if a.config in (4, 5) else workloads.DEFAULT_UNITS[c])
+        lib = synthetic.ScreenLibrary(c, n_lib)
+        prec_c = "bf16x3" if c == 5 else "f32"
+        m = TensorProductScoreModel(device=dev, precision=prec_c)
+        m.load_state_dict(sd)
+        sargs = types.SimpleNamespace(**vars(margs), inference_steps=workloads.steps_of(c) if c == 4 else 20)
+        t_load = [0.0]
+
+        def load(i):
+            t1 = time.perf_counter()
+            g = lib.unit(i)
+            t_load[0] += time.perf_counter() - t1
+            return g
+        n_done = [0]
+        per_batch = workloads.DEFAULT_UNITS[c] * workloads.SAMPLES
+        D.screen(2, load, m, sargs, samples_per_complex=2, max_poses=per_batch, seed=1, on_result=lambda i, arr: None)      # warm-up
+        torch.cuda.synchronize()
+        t_load[0] = 0.0
+        rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        t0 = time.perf_counter()
+        D.screen(n_lib, load, m, sargs, costs=[lib.cost(i) for i in range(n_lib)], samples_per_complex=workloads.SAMPLES, max_poses=per_batch,
+                 seed=607201, on_result=lambda i, arr: n_done.__setitem__(0, n_done[0] + arr.shape[0]))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        e2e_screen = {"what": f"distributed.screen (streaming) over a lazily built configs[{c - 1}] library: {n_lib} units x {workloads.SAMPLES} samples, "
+                              f"device batches of {per_batch} poses, on-device start randomisation + noise (seed)", "poses": n_done[0],
+                      "steps": sargs.inference_steps, "precision": prec_c, "seconds": dt, "value": n_done[0] * sargs.inference_steps / dt,
+                      "unit": "pose-steps/s", "host_unit_build_s": round(t_load[0], 3), "max_rss_mib_before": rss0 // 1024,
+                      "max_rss_mib_after": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024}
 
     n_x = int(pb.x_ptr[-1])
 
@@ -447,7 +499,7 @@ def main():
                        "poses_per_gpu": B, "poses_total": total_poses, f"poses_per_sec_at_{S_total}_steps": total_poses * a.steps / elapsed / S_total,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
                        "kabsch_flagged_poses": bad, "finite": finite, "precision": precision, "conv_algo": algo_used,
-                       "edge_counts": edge_counts, "alt_runs": alt, "e2e": e2e, "other_configs": other},
+                       "edge_counts": edge_counts, "alt_runs": alt, "e2e": e2e, "e2e_screen": e2e_screen, "other_configs": other},
             # The dominant kernel generates the per-edge TP weights on the matrix pipe in registers (they never reach HBM), so it is
             # bound by the fp32 matrix pipe; SURVEY.md 8d asks for both views when the radial MLP is fused into the TP kernel.
             # alg_flops_per_edge is the EDGE-SIDE count of SURVEY.md 8d (radial GEMM per edge); the node-side formulation computes
