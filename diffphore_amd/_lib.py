@@ -12,7 +12,7 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 5
+DP_ABI_VERSION = 6
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3

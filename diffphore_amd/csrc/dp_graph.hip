@@ -644,6 +644,15 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while (B * slices < 512 && slices < 8) ++slices;
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
+  // the convs that stay edge-side in an fp32 model (phore-phore, torsion bonds) take the bf16x6 form of their radial contraction when the
+  // blob carries it (DpConvW.w2x): same tolerances, 16x the matrix rate per product
+  const bool edge_x6 = w->precision == DP_PREC_F32 && k->edge_x6 != 1;
+  int slices_x6 = 1;
+  {
+    const int mx = b->max_nl > b->max_np ? b->max_nl : b->max_np;
+    while ((mx + slices_x6 - 1) / slices_x6 > dp_conv_max_nodes(DP_PREC_BF16X6)) ++slices_x6;
+    while (B * slices_x6 < 512 && slices_x6 < 8) ++slices_x6;
+  }
   const int nb = dp_conv_node_max_nodes();
   const int slices_pl = (b->max_nl + nb - 1) / nb, slices_lp = (b->max_np + nb - 1) / nb;
   // optional second stream: phore-side convs of a layer (and the torsion head) run beside the ligand-side ones
@@ -738,6 +747,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_scat = b->pp_src; c.gather_tab = hp; c.attr1_tab = hp; c.attr2_tab = hp; c.edge_emb = k->pp_emb; c.edge_sh = k->pp_sh;
         c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
+        if (edge_x6 && w->ph_conv[l].w2x) { c.precision = DP_PREC_BF16X6; c.w2p = w->ph_conv[l].w2x; c.slices = slices_x6; c.phase_split = 0; }
         if ((rc = timed(c, l, 3, sp_))) return fail(rc);
       }
       DpConvArgs phc[2];
@@ -791,6 +801,11 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.attr_swap = 1; c.edge_emb = k->t_emb; c.edge_sh = k->t_sh; c.sh_stride = 7;
     c.w1p = w->tor_conv.w1p; c.w2p = w->tor_conv.w2p; c.bn_scale = w->tor_conv.bn_scale; c.bn_shift = w->tor_conv.bn_shift;
     c.out = k->t_q; c.out_stride = 40;
+    if (edge_x6 && w->tor_conv.w2x) {
+      c.precision = DP_PREC_BF16X6; c.w2p = w->tor_conv.w2x;
+      c.slices = 1;
+      while ((b->max_t + c.slices - 1) / c.slices > dp_conv_max_nodes(DP_PREC_BF16X6)) ++c.slices;
+    }
     if ((rc = dp_tp_conv(&c, s2))) return fail(rc);
     hipLaunchKernelGGL(dp::tor_head_kernel, dim3((b->n_tor + 63) / 64), dim3(64), 0, s2, *b, *w, *k, tor);
     if (tor_aux) join();

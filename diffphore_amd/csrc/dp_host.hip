@@ -131,6 +131,9 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
         snprintf(nm, sizeof(nm), "%s.%d.w1n", FAMS[f], l); s.add(nm, dp_conv_w1n_floats(l));
         snprintf(nm, sizeof(nm), "%s.%d.w2n", FAMS[f], l); s.add(nm, dp_conv_w2n_floats(l));
       }
+      if (f == 1 && l < 3 && precision == DP_PREC_F32) {     // phore-phore stays edge-side: its second layer for the bf16 pipe as well (DpConvW.w2x)
+        snprintf(nm, sizeof(nm), "%s.%d.w2x", FAMS[f], l); s.add(nm, dp_conv_w2p_floats(l, DP_PREC_BF16X6));
+      }
     }
   static const char* const heads[2] = {"final_conv", "tor_conv"};
   for (int h = 0; h < 2; ++h) {
@@ -139,6 +142,7 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
     snprintf(nm, sizeof(nm), "%s.w2p", heads[h]); s.add(nm, dp_conv_w2p_floats(kind, precision));
     snprintf(nm, sizeof(nm), "%s.bn_scale", heads[h]); s.add(nm, D_OUT_KIND[kind]);
     snprintf(nm, sizeof(nm), "%s.bn_shift", heads[h]); s.add(nm, D_OUT_KIND[kind]);
+    if (h == 1 && precision == DP_PREC_F32) { snprintf(nm, sizeof(nm), "%s.w2x", heads[h]); s.add(nm, dp_conv_w2p_floats(kind, DP_PREC_BF16X6)); }
   }
   s.add("so3_table", 1000); s.add("torus_table", 5001);
   s.add("lig_gauss_mu", 20); s.add("ph_gauss_mu", 20); s.add("x_gauss_mu", 20); s.add("center_gauss_mu", 20);
@@ -214,6 +218,7 @@ int dp_weights_bind(const float* blob, int32_t precision, const DpModelScalars* 
     snprintf(nm, sizeof(nm), "%s.bn_shift", name); c.bn_shift = find(nm);
     snprintf(nm, sizeof(nm), "%s.w1n", name); c.w1n = find(nm);
     snprintf(nm, sizeof(nm), "%s.w2n", name); c.w2n = find(nm);
+    snprintf(nm, sizeof(nm), "%s.w2x", name); c.w2x = find(nm);
   };
   w->lig_emb = find("lig_emb"); w->lig_lin_w = find("lig_lin_w"); w->lig_lin_b = find("lig_lin_b");
   w->boarder_emb = find("boarder_emb"); w->boarder_lin_w = find("boarder_lin_w"); w->boarder_lin_b = find("boarder_lin_b");

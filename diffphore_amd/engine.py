@@ -40,7 +40,7 @@ class DpMlp(C.Structure):
 
 
 class DpConvW(C.Structure):
-    _fields_ = [(n, VOIDP) for n in ("w1p", "w2p", "bn_scale", "bn_shift", "w1n", "w2n")]
+    _fields_ = [(n, VOIDP) for n in ("w1p", "w2p", "bn_scale", "bn_shift", "w1n", "w2n", "w2x")]
 
 
 class DpWeights(C.Structure):
@@ -65,7 +65,7 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join", "z_noise")] + [("conv_fuse", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("edge_x6", c_i32), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -186,11 +186,12 @@ class DeviceModel:
         for name, fam in fams.items():
             for l in range(4):
                 node = name != "ph_conv" and prec == _lib.PREC_F32
-                for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node).items():
+                x6 = name == "ph_conv" and l < 3 and prec == _lib.PREC_F32          # edge-side in an fp32 model: bf16x6 second layer as well
+                for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6).items():
                     H[f"{name}.{l}.{part}"] = t
         for part, t in packing.pack_conv(sd, "final_conv", _lib.CONV_FINAL, prec).items():
             H[f"final_conv.{part}"] = t
-        for part, t in packing.pack_conv(sd, "tor_bond_conv", _lib.CONV_TOR, prec).items():
+        for part, t in packing.pack_conv(sd, "tor_bond_conv", _lib.CONV_TOR, prec, x6=prec == _lib.PREC_F32).items():
             H[f"tor_conv.{part}"] = t
         so3, torus = tables if tables is not None else load_tables()
         H["so3_table"] = torch.as_tensor(np.asarray(so3), dtype=torch.float64).float()
@@ -486,6 +487,7 @@ class Engine:
         self.L.dp_resolve_conv_algo.restype = C.c_int
         self.conv_algo = {1: "edge", 2: "node"}[self.L.dp_resolve_conv_algo(CONV_ALGOS[conv_algo], model.struct.precision, pb.B)]
         self.ws.struct.conv_fuse = 1 if os.environ.get("DIFFPHORE_CONV_FUSE", "1") == "0" else 0
+        self.ws.struct.edge_x6 = 1 if os.environ.get("DIFFPHORE_EDGE_X6", "1") == "0" else 0
         self._handles = None
         self._graph = None
         two = os.environ.get("DIFFPHORE_TWO_STREAMS", "auto")

@@ -31,7 +31,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 5
+#define DP_ABI_VERSION 6
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -200,7 +200,14 @@ typedef struct DpBatch {
 } DpBatch;
 
 typedef struct DpMlp { const float *w0, *b0, *w3, *b3; } DpMlp;   /* nn.Sequential(Linear, act, Dropout, Linear) */
-typedef struct DpConvW { const float *w1p, *w2p, *bn_scale, *bn_shift, *w1n, *w2n; } DpConvW;   /* w1n/w2n: node-side layout or NULL */
+typedef struct DpConvW {
+  const float *w1p, *w2p, *bn_scale, *bn_shift;
+  const float *w1n, *w2n;     /* node-side layout or NULL */
+  const float* w2x;           /* the second layer packed for DP_PREC_BF16X6 beside an fp32 `w2p`, or NULL: the convs that stay on the edge-side
+                                 kernel in an fp32 model (phore-phore: low degree; torsion bonds) then run their radial contraction as a 3-way
+                                 bf16 split with 6 cross products on the bf16 pipe (16x the fp32 MFMA rate) - ~2^-24 relative per product, fp32
+                                 accumulate, held to the same tolerances as the fp32 kernel (DpWork.edge_x6 = 1 turns it off) */
+} DpConvW;
 
 /* Device pointers into the uploaded parameter blob.  Reference names: score_model_phore.py:248-291, 524-641. */
 typedef struct DpWeights {
@@ -265,6 +272,7 @@ typedef struct DpWork {
    * layer (and the torsion head) on `aux_stream`, forked from / joined back to the launch stream with the events.  Results are
    * bit-identical; it only helps batches too small to fill the chip with one conv at a time.  Capturable into a hipGraph. */
   void *aux_stream, *ev_fork, *ev_join;
+  int32_t edge_x6;                  /* 0 = edge-side convs of an fp32 model use DpConvW.w2x (bf16x6) when present (default), 1 = exact fp32 MFMA */
   float* z_noise;                   /* [6 B + n_tor] scratch of DP_NOISE_SEED: one step's z_tr | z_rot | z_tor */
   int32_t conv_fuse;                /* node-side convs of a layer that scatter onto the same nodes: 0 = one fused launch per side (default),
                                        1 = one launch per conv (A/B runs and tests) */

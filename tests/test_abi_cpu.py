@@ -47,7 +47,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
     base = 1 << 20                                                            # a fake (aligned) device address: bind touches no memory
     assert L.dp_work_bind(C.byref(b), base, n1, C.byref(w), *[C.byref(p) for p in ptrs]) == 0
     fields = [getattr(w, n) for n, _ in engine.DpWork._fields_ if n not in ("h_l", "h_p", "prof_start", "prof_stop", "prof_layer",
-                                                                            "prof_conv", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse")]
+                                                                            "prof_conv", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "edge_x6")]
     fields += list(w.h_l) + list(w.h_p) + [p.value for p in ptrs]
     assert all(f is not None and base <= f < base + n1 and f % 256 == 0 for f in fields) and len(set(fields)) == len(fields)
     assert L.dp_work_bind(C.byref(b), base, n1 - 1, C.byref(w), *[C.byref(p) for p in ptrs]) == -3
@@ -65,6 +65,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
         assert L.dp_weights_blob_floats(prec) >= end
         names = [sg.name.decode() for sg in segs]
         assert len(set(names)) == n and "p2l_conv.3.w2p" in names and ("p2l_conv.3.w2n" in names) == (prec == _lib.PREC_F32)
+        assert ("ph_conv.0.w2x" in names) == ("tor_conv.w2x" in names) == (prec == _lib.PREC_F32) and "ph_conv.3.w2x" not in names
 
 
 def test_pack_bn_matches_the_python_packer():

@@ -87,6 +87,36 @@ def test_forward_matches_oracle(prec, algo, monkeypatch):
     assert n_l == batch["ligand"].node_sigma_emb.shape[0]
 
 
+@pytest.mark.parametrize("algo", ["node", "edge"])
+def test_edge_side_convs_on_the_bf16_pipe_vs_exact_fp32(algo, monkeypatch):
+    """An fp32 model runs the convs that stay on the edge-side kernel - phore-phore, torsion bonds - with the bf16x6 form of the radial
+    contraction (DpConvW.w2x; 3-way operand split, 6 cross products, fp32 accumulate).  Default (on) and DIFFPHORE_EDGE_X6=0 (exact fp32
+    MFMA everywhere) are held to the fp64 oracle at the SAME tolerance, and to each other."""
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import sampler as osampler
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
+    gs = _mixed_graphs() + synthetic.synthetic_pairs(99, 18, 30, 8, 32)           # 24 poses: `node` is what a batch of this size takes by default
+    sd, om = _model()
+    batch = Batch.from_data_list(gs)
+    osampler.set_time_phore(batch, 0.55, 0.55, 0.55, batch.num_graphs)
+    tr_o, rot_o, tor_o = om(batch)
+    res = {}
+    for x6 in ("1", "0"):
+        monkeypatch.setenv("DIFFPHORE_EDGE_X6", x6)
+        m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+        tr, rot, tor = m(batch)
+        torch.cuda.synchronize()
+        ws = m._engine.ws
+        assert ws.struct.edge_x6 == (0 if x6 == "1" else 1)
+        errs = dict(h_l4=_rel(ws.t["h_l0"][:, :100], om.debug["h_l4"]), h_p3=_rel(ws.t["h_p1"][:, :100], om.debug["h_p3"]), tr=_rel(tr, tr_o),
+                    rot=_rel(rot, rot_o), tor=_rel(tor, tor_o))
+        print(algo, "edge_x6 =", x6, {k: f"{v:.1e}" for k, v in errs.items()})
+        assert all(v < 1e-5 for v in errs.values()), errs
+        res[x6] = (tr.cpu(), rot.cpu(), tor.cpu())
+    assert all(_rel(a, b) < 1e-5 for a, b in zip(res["1"], res["0"]))
+    assert not all(torch.equal(a, b) for a, b in zip(res["1"], res["0"]))        # the switch really selects another kernel
+
+
 def test_lig_graph_matches_oracle_edges():
     """radius graph (cap 32, index order, strict <) + bond edges: same multiset of (src,dst) as the oracle."""
     from diffphore_amd.score_model import TensorProductScoreModel
