@@ -5,14 +5,15 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdiffphore_hip.so")
+# DIFFPHORE_LIB: an alternative build of the library (A/B and ablation builds, tools/); the product default is the in-tree build
+LIB_PATH = os.environ.get("DIFFPHORE_LIB") or os.path.join(_HERE, "csrc", "libdiffphore_hip.so")
 
 c_i32 = C.c_int32
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 6
+DP_ABI_VERSION = 7
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
@@ -35,7 +36,7 @@ class DpConvArgs(C.Structure):
         ("out", VOIDP), ("out_stride", c_i32), ("accumulate", c_i32),
         ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32), ("phase_split", c_i32),
         ("w1n", VOIDP), ("w2n", VOIDP), ("algo", c_i32), ("path_split", c_i32),
-        ("pair_a", VOIDP), ("pair_b", VOIDP), ("pair_ptr", VOIDP),
+        ("pair_a", VOIDP), ("pair_b", VOIDP), ("pair_ptr", VOIDP), ("no_tail", c_i32),
     ]
 
 

@@ -141,6 +141,9 @@ int dp_tp_conv_node_fused(const DpConvArgs* convs, int32_t n, void* stream) {
     }
     fa.conv[i] = *a;
   }
+  fa.lean = 1;
+  for (int i = 0; i < n; ++i)
+    if (!convs[i].no_tail) fa.lean = 0;
   if (!convs[0].out) return DP_E_BADARG;
   return dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
 }

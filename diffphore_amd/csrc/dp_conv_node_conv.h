@@ -1,5 +1,5 @@
 // dp_conv_node_conv.h - every pass of ONE conv of a (possibly fused) node-side launch; included by dp_conv_node_wg.h once per edge mode.
-// Expects in scope: KIND, SIDE, P0; constexpr MODE; `const DpConvArgs& a` (this conv); grp; tid / lane / q / g / c; sT, s_pair, s_T, s_S,
+// Expects in scope: KIND, HALFOK, SIDE, P0; constexpr MODE; `const DpConvArgs& a` (this conv); grp; tid / lane / q / g / c; sT, s_pair, s_T, s_S,
 // s_inv; acc; prof_prev.
 {
   const Wg r = wg_of<MODE>(a, grp.pose);
@@ -15,10 +15,15 @@
   for (int et = 0; et < n_et; ++et) {
     // a last pass of <= 16 edge slots runs with one 16-edge tile per node (half of GEMM1 and GEMM-A); which variant a pass takes
     // depends on the pose's own edge count only, so a pose's result does not depend on the rest of the batch
-    if (DP_NODE_HALF_PASS && r.En - 32 * et <= 16) {
-      constexpr bool HALF = true;
+    if constexpr (HALFOK && DP_NODE_HALF_PASS) {
+      if (r.En - 32 * et <= 16) {
+        constexpr bool HALF = true;
 #include "dp_conv_node_pass.h"
-    } else {
+      } else {
+        constexpr bool HALF = false;
+#include "dp_conv_node_pass.h"
+      }
+    } else {        // lean instantiation (FusedArgs.lean: the host knows that no pose ends on a short pass) - or a short pass run as a full one
       constexpr bool HALF = false;
 #include "dp_conv_node_pass.h"
     }

@@ -61,6 +61,12 @@ typedef int NProfT;
 #ifndef DP_NABL    // ablation builds (tools/ablate_node.sh): 1 no sh factors / z arithmetic, 2 no T transpose through LDS, 3 no GEMM-B MFMAs,
 #define DP_NABL 0  // 4 no GEMM-B at all, 5 no GEMM-A MFMAs, 6 no GEMM1 MFMAs.  Results are wrong by construction; timing only.
 #endif
+#ifndef DP_NODE_PF
+#define DP_NODE_PF 4          // GEMM1: steps the edge operands are requested ahead
+#endif
+#ifndef DP_NODE_XR0_BACK
+#define DP_NODE_XR0_BACK 3    // GEMM1: the first column tile's gathered operands are requested this many steps before its end
+#endif
 #ifndef DP_NODE_HALF_PASS
 #define DP_NODE_HALF_PASS 1   // 0: every pass is a full 32-slot pass (A/B builds)
 #endif
@@ -513,10 +519,11 @@ struct AccStore {
 // scatters onto the same node groups; conv[0] names the output / residual.  HAS_LL instantiates the pair-dense pass as well.
 struct FusedArgs {
   int32_t n_ll, n_x;
+  int32_t lean;              // every conv of the launch carries DpConvArgs.no_tail: the instantiation without the half-pass variant
   DpConvArgs conv[3];
 };
 
-template <int KIND, bool HAS_LL, int XMODE>
+template <int KIND, bool HAS_LL, int XMODE, bool HALFOK>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(FusedArgs fa) {
   __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE + TDUMMY];     // wave-private T tiles + the shared dummy row; reused for the final reduction
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];         // per-edge sh factors of the current pass
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(FusedArgs fa) {
 // DpConvArgs.path_split: two workgroups per node group, each owning half of the out slots (split_owner).  Both run GEMM1 (4 % of the MFMAs
 // since the first-layer split) and their own paths' GEMM-A / GEMM-B: a conv's latency halves when the batch cannot fill the chip with one
 // workgroup per node group; every output channel is computed exactly as in the unsplit launch (bit-identical).
-template <int KIND, bool HAS_LL, int XMODE>
+template <int KIND, bool HAS_LL, int XMODE, bool HALFOK>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_split_kernel(FusedArgs fa) {
   __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE + TDUMMY];
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];
@@ -548,12 +555,15 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_split_kernel(FusedArgs fa
   }
 }
 
+// the lean instantiation exists for the unsplit kernel only: split launches (small batches) are latency-bound, not pipe-bound
 template <int KIND, bool HAS_LL, int XMODE> int launch_seq(const FusedArgs& fa, hipStream_t st) {
   const DpConvArgs& a = fa.conv[0];
   if (a.path_split) {
-    hipLaunchKernelGGL((tp_conv_node_split_kernel<KIND, HAS_LL, XMODE>), dim3((unsigned)(a.B * a.slices * 2)), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL((tp_conv_node_split_kernel<KIND, HAS_LL, XMODE, true>), dim3((unsigned)(a.B * a.slices * 2)), dim3(256), 0, st, fa);
+  } else if (fa.lean && DP_NODE_HALF_PASS) {
+    hipLaunchKernelGGL((tp_conv_node_kernel<KIND, HAS_LL, XMODE, false>), dim3((unsigned)(a.B * a.slices)), dim3(256), 0, st, fa);
   } else {
-    hipLaunchKernelGGL((tp_conv_node_kernel<KIND, HAS_LL, XMODE>), dim3((unsigned)(a.B * a.slices)), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL((tp_conv_node_kernel<KIND, HAS_LL, XMODE, true>), dim3((unsigned)(a.B * a.slices)), dim3(256), 0, st, fa);
   }
   return (int)hipGetLastError();
 }

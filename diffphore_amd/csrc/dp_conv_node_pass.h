@@ -55,7 +55,7 @@
       v1 = pe[4];
       msk = (!ok && g == 0) ? -1e30f : 0.f;
     };
-    constexpr int PF = 4;                                      // steps the edge operands are requested ahead (ring of PF + 1 register sets)
+    constexpr int PF = DP_NODE_PF;                             // steps the edge operands are requested ahead (ring of PF + 1 register sets)
     f4u e4[PF + 1];
     float e1[PF + 1], em[PF + 1];
     if constexpr (MODE != LL) {                                // dense modes: edge rows are arithmetic, the first requests can leave now
@@ -157,7 +157,7 @@
       const bool last_of_node = HALF || t2 == 1;
       if (step + PF < NSTEP) load_av(step + PF, e4[(step + PF) % (PF + 1)], e1[(step + PF) % (PF + 1)], em[(step + PF) % (PF + 1)], 0);
       if (t2 == 0 && nn + 1 < NB) { us_nxt = sT[(nn + 1) * 16 + c]; inv_nxt = s_inv[nn + 1]; }
-      if (step == NSTEP - 3) load_x<KIND, MODE, HALF, P0>(a, r, et, lane, 0, xr0);   // first column tile's operands: behind the last emb request
+      if (step == NSTEP - DP_NODE_XR0_BACK) load_x<KIND, MODE, HALF, P0>(a, r, et, lane, 0, xr0);   // first column tile's operands: behind the last emb request
       const f32x4 D = gemm1(e4[step % (PF + 1)], e1[step % (PF + 1)], em[step % (PF + 1)], us_cur, ug[t2]);
       if constexpr (MODE == LL) {                 // (scaled after the bond sweep below)
 #pragma unroll

@@ -11,7 +11,11 @@
 #include "dp_dev.h"
 
 #ifndef DP_NODE_LL_MAX_ATOMS
-#define DP_NODE_LL_MAX_ATOMS 96      // three 32-slot passes still beat the edge-side kernel (80 atoms: 10.5 vs 12.4 ms/step at 256 poses); beyond: untested
+// The ligand-ligand conv runs node-side (pair-dense: N x N slots) while every ligand of the batch fits ONE 32-slot pass; beyond, the
+// pair slots are < 50 % full (radius graph capped at 32 neighbours) and the edge-side CSR kernel in its bf16x6 form is faster: 256 poses
+// x 80 atoms 8.93 vs 9.53 ms/step, the 15-45-atom virtual-screen batch 18.80 vs 19.14, 512 x 30 atoms 5.74 vs 5.50 (node-side stays).
+// DpWork.ll_node_max_atoms overrides it.
+#define DP_NODE_LL_MAX_ATOMS 32
 #endif
 
 namespace dp {
@@ -595,7 +599,7 @@ static bool plan_node_side(const DpBatch* b, const DpWeights* w, const DpWork* k
 }
 static bool plan_node_ll(const DpBatch* b, const DpWeights* w, const DpWork* k) {
   return plan_node_side(b, w, k) && w->lig_conv[0].w2n != nullptr && b->llp_ptr != nullptr && k->ll_pair_rad != nullptr &&
-         k->ll_pair_bond != nullptr && b->max_nl <= DP_NODE_LL_MAX_ATOMS;
+         k->ll_pair_bond != nullptr && b->max_nl <= (k->ll_node_max_atoms > 0 ? k->ll_node_max_atoms : DP_NODE_LL_MAX_ATOMS);
 }
 
 int dp_forward_launch_of(const DpBatch* b, const DpWeights* w, const DpWork* k, int32_t layer, int32_t conv, int32_t* first, int32_t* count,
@@ -711,8 +715,10 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_scat = k->ll_src; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hl; c.edge_emb = k->ll_emb; c.edge_sh = k->ll_sh;
       c.w1p = w->lig_conv[l].w1p; c.w2p = w->lig_conv[l].w2p; c.bn_scale = w->lig_conv[l].bn_scale; c.bn_shift = w->lig_conv[l].bn_shift;
       c.out = hl2; c.accumulate = 0; c.resid = hl; c.resid_width = din;
+      if (!node_ll && edge_x6 && w->lig_conv[l].w2x) { c.precision = DP_PREC_BF16X6; c.w2p = w->lig_conv[l].w2x; c.slices = slices_x6; c.phase_split = 0; }
       if (node_ll) {
         c.algo = DP_ALGO_NODE; c.mode = DP_EDGES_LLPAIR; c.w1n = w->lig_conv[l].w1n; c.w2n = w->lig_conv[l].w2n; c.slices = slices_pl; c.phase_split = 0;
+        c.no_tail = b->no_tail_nl;
         c.path_split = node_path_split(B, slices_pl);
         c.pair_a = k->ll_pair_rad; c.pair_b = k->ll_pair_bond; c.pair_ptr = b->llp_ptr;
       }
@@ -725,7 +731,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
-      if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); }
+      if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); c.no_tail = b->no_tail_np; }
     }
     if (node_side && fuse && node_ll) {
       // one launch: the three convs scatter onto the same atoms and their outputs add up (:703-706)
@@ -759,7 +765,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
-        if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); }
+        if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); c.no_tail = b->no_tail_nl; }
       }
       if (node_side && fuse) {
         if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);

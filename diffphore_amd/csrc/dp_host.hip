@@ -131,7 +131,8 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
         snprintf(nm, sizeof(nm), "%s.%d.w1n", FAMS[f], l); s.add(nm, dp_conv_w1n_floats(l));
         snprintf(nm, sizeof(nm), "%s.%d.w2n", FAMS[f], l); s.add(nm, dp_conv_w2n_floats(l));
       }
-      if (f == 1 && l < 3 && precision == DP_PREC_F32) {     // phore-phore stays edge-side: its second layer for the bf16 pipe as well (DpConvW.w2x)
+      if (((f == 1 && l < 3) || f == 0) && precision == DP_PREC_F32) {     // phore-phore stays edge-side, ligand-ligand goes edge-side for large
+                                                                            // ligands: their second layer for the bf16 pipe as well (DpConvW.w2x)
         snprintf(nm, sizeof(nm), "%s.%d.w2x", FAMS[f], l); s.add(nm, dp_conv_w2p_floats(l, DP_PREC_BF16X6));
       }
     }

@@ -27,7 +27,7 @@ DEFAULT_PRECISION = "f32"
 # ----------------------------------------------------------------------------------------------------------------------
 class DpBatch(C.Structure):
     _fields_ = ([("B", c_i32)] + [(n, c_i32) for n in ("n_lig", "n_ph", "n_bond", "n_tor", "n_pp", "n_x", "ll_cap", "n_llp")]
-                + [(n, c_i32) for n in ("max_nl", "max_np", "max_t")]
+                + [(n, c_i32) for n in ("max_nl", "max_np", "max_t", "no_tail_nl", "no_tail_np")]
                 + [(n, VOIDP) for n in ("lig_ptr", "ph_ptr", "bond_ptr", "tor_ptr", "pp_ptr", "x_ptr", "ll_ptr", "mask_ptr",
                                         "pose_ptr", "llp_ptr", "lig_x", "bond_src", "bond_dst", "bond_type", "tor_u", "tor_v",
                                         "mask_rotate", "phorefp", "norm_angle1", "norm_angle2", "ph_pos", "ph_norm", "ph_x",
@@ -65,7 +65,7 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("edge_x6", c_i32), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("ll_node_max_atoms", c_i32), ("edge_x6", c_i32), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -186,7 +186,8 @@ class DeviceModel:
         for name, fam in fams.items():
             for l in range(4):
                 node = name != "ph_conv" and prec == _lib.PREC_F32
-                x6 = name == "ph_conv" and l < 3 and prec == _lib.PREC_F32          # edge-side in an fp32 model: bf16x6 second layer as well
+                # edge-side in an fp32 model (phore-phore always, ligand-ligand for large ligands): bf16x6 second layer as well
+                x6 = ((name == "ph_conv" and l < 3) or name == "lig_conv") and prec == _lib.PREC_F32
                 for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6).items():
                     H[f"{name}.{l}.{part}"] = t
         for part, t in packing.pack_conv(sd, "final_conv", _lib.CONV_FINAL, prec).items():
@@ -378,6 +379,9 @@ class PackedBatch:
         s.n_pp, s.n_x, s.ll_cap = int(self.pp_ptr[-1]), int(self.x_ptr[-1]), int(self.ll_ptr[-1])
         s.n_llp = int(self.llp_ptr[-1]) if self.ll_pairs_ok else 0
         s.max_nl, s.max_np, s.max_t = int(nl.max()), int(npn.max()), int(nt.max())
+        # hints for the node-side convs: no pose ends on a pass of <= 16 edge slots -> the lean kernel instantiation (DpConvArgs.no_tail)
+        tail = lambda v: bool((((v - 1) % 32) < 16).any())                     # noqa: E731  (v mod 32 in 1..16)
+        s.no_tail_nl, s.no_tail_np = (0 if tail(np.asarray(nl)) else 1), (0 if tail(np.asarray(npn)) else 1)
         for k, v in self.static.items():
             setattr(s, k, v.data_ptr())
         if not self.ll_pairs_ok:
@@ -488,6 +492,7 @@ class Engine:
         self.conv_algo = {1: "edge", 2: "node"}[self.L.dp_resolve_conv_algo(CONV_ALGOS[conv_algo], model.struct.precision, pb.B)]
         self.ws.struct.conv_fuse = 1 if os.environ.get("DIFFPHORE_CONV_FUSE", "1") == "0" else 0
         self.ws.struct.edge_x6 = 1 if os.environ.get("DIFFPHORE_EDGE_X6", "1") == "0" else 0
+        self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         self._handles = None
         self._graph = None
         two = os.environ.get("DIFFPHORE_TWO_STREAMS", "auto")

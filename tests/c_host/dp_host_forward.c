@@ -5,7 +5,7 @@
  * and writes tr / rot / tor.  tests/test_c_host_gpu.py compares them bit for bit with the Python host's result.
  *
  * Dump format: records of { char name[64]; int32 dtype (0 f32, 1 i32, 2 u8); int64 count; data }, names = DpBatch field names,
- * plus "dims" (i32[12]: B n_lig n_ph n_bond n_tor n_pp n_x ll_cap n_llp max_nl max_np max_t), "blob" (f32), "scalars" (f32[12]),
+ * plus "dims" (i32[14]: B n_lig n_ph n_bond n_tor n_pp n_x ll_cap n_llp max_nl max_np max_t no_tail_nl no_tail_np), "blob" (f32), "scalars" (f32[12]),
  * "precision" (i32[1]), "conv_algo" (i32[1]).
  */
 #include <hip/hip_runtime_api.h>
@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
   memset(&b, 0, sizeof(b));
   b.B = d[0]; b.n_lig = d[1]; b.n_ph = d[2]; b.n_bond = d[3]; b.n_tor = d[4]; b.n_pp = d[5]; b.n_x = d[6]; b.ll_cap = d[7];
   b.n_llp = d[8]; b.max_nl = d[9]; b.max_np = d[10]; b.max_t = d[11];
+  b.no_tail_nl = d[12]; b.no_tail_np = d[13];      /* hints: which node-side instantiation dp_forward may launch */
 #define I32(field) b.field = (const int32_t*)find(#field)->dev
 #define F32(field) b.field = (const float*)find(#field)->dev
   I32(lig_ptr); I32(ph_ptr); I32(bond_ptr); I32(tor_ptr); I32(pp_ptr); I32(x_ptr); I32(ll_ptr); I32(mask_ptr); I32(pose_ptr); I32(llp_ptr);

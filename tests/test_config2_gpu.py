@@ -5,7 +5,7 @@
   * 6-step SDE / ODE trajectories of 80-atom x 25-torsion poses, HIP {edge, node} vs the fp64 oracle, every pose <= 1e-4 A or an
     oracle-recorded near-tie decision;
   * a batch of >= 20 poses with >= 100 atoms each forced onto the node-side formulation: cross convs node-side, ligand-ligand convs on
-    the edge-side CSR kernel (DP_NODE_LL_MAX_ATOMS = 96), against the fp64 oracle.
+    the edge-side CSR kernel (more than DP_NODE_LL_MAX_ATOMS atoms), against the fp64 oracle.
 """
 import copy
 import ctypes as C
@@ -170,7 +170,7 @@ def test_configs2_sampler_trajectory_matches_oracle(ode, algo, monkeypatch):
 
 def test_node_side_above_the_ligand_ligand_cap():
     """20 poses of 100-110 atoms forced onto DIFFPHORE_CONV_ALGO=node: the cross convs run node-side (7 node groups per pose), the
-    ligand-ligand convs fall back to the edge-side CSR kernel (more than DP_NODE_LL_MAX_ATOMS = 96 atoms) - vs the fp64 oracle, pose by
+    ligand-ligand convs fall back to the edge-side CSR kernel (more than DP_NODE_LL_MAX_ATOMS atoms) - vs the fp64 oracle, pose by
     pose.  4 400 cross edges per pose make a near-tie in the sign of the direction MLP (score_model_phore.py:813-816) likely somewhere in
     the batch: a pose may deviate only if the oracle recorded such a tie for it (relative margin < 1e-5), as in the trajectory tests."""
     from diffphore_amd.score_model import TensorProductScoreModel

@@ -404,6 +404,52 @@ def test_conv_rejects_too_many_nodes_per_workgroup():
     assert _lib.lib().dp_tp_conv(C.byref(a), None) == -1
 
 
+@pytest.mark.parametrize("kind", [1, 3])
+def test_conv_node_lean_instantiation_is_bit_identical(kind):
+    """DpConvArgs.no_tail = 1 selects the node-side instantiation without the half-pass variant.  On a batch where the hint is true (no
+    pose ends on a pass of <= 16 edge slots) it must reproduce the general kernel bit for bit; where the hint is FALSE the lean kernel
+    still computes the right answer (a short pass run as a full, zero-padded one) - only the guarantee of identical bits is gone."""
+    g = torch.Generator().manual_seed(2700 + kind)
+    sd = weights.init_state_dict(11)
+    prefix = f"encoder.phore_to_lig_conv_layers.{kind}"
+    dims = _lib.conv_dims(kind)
+    for NL, NP, hint_true in (([30, 7, 20], [32, 64, 17], True), ([30, 7, 20], [40, 5, 33], False)):
+        B = len(NL)
+        lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+        ph_ptr = np.concatenate([[0], np.cumsum(NP)])
+        x_ptr = np.concatenate([[0], np.cumsum(np.asarray(NL) * np.asarray(NP))])
+        hl = torch.randn(int(lig_ptr[-1]), dims["d_in"], generator=g)
+        hp = torch.randn(int(ph_ptr[-1]), dims["d_in"], generator=g)
+        E = int(x_ptr[-1])
+        emb = torch.randn(E, 20, generator=g)
+        sh = torch.randn(E, 9, generator=g)
+        sh[:, 0] = 1.0
+        src = torch.cat([torch.arange(lig_ptr[b], lig_ptr[b + 1]).repeat_interleave(NP[b]) for b in range(B)])
+        dst = torch.cat([torch.arange(ph_ptr[b], ph_ptr[b + 1]).repeat(NL[b]) for b in range(B)])
+        attr = torch.cat([emb, hl[src, :20], hp[dst, :20]], 1)
+        ref = _oracle_conv(sd, prefix, kind, hp[dst], attr, sh, src, hl.shape[0])
+        pk = packing.pack_conv(sd, prefix, kind, _lib.PREC_F32, node_side=True)
+        nb = _lib.lib().dp_conv_node_max_nodes()
+        outs, keep = [], []
+        base = dict(kind=kind, mode=_lib.EDGES_P2L, B=B, slices=(max(NL) + nb - 1) // nb, precision=_lib.PREC_F32, max_scatter=max(NL),
+                    scat_ptr=_dev(_i32(lig_ptr)), lig_ptr=_dev(_i32(lig_ptr)), ph_ptr=_dev(_i32(ph_ptr)), x_ptr=_dev(_i32(x_ptr)), gather_tab=_dev(hp),
+                    gather_stride=dims["d_in"], attr1_tab=_dev(hl), attr1_stride=dims["d_in"], attr2_tab=_dev(hp), attr2_stride=dims["d_in"],
+                    attr_swap=0, edge_emb=_dev(emb), edge_sh=_dev(sh), sh_stride=9, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]), w1n=_dev(pk["w1n"]),
+                    w2n=_dev(pk["w2n"]), bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]), out_stride=dims["d_out"], accumulate=0,
+                    algo=_lib.ALGO_NODE)
+        for hint in (0, 1):
+            out = torch.full((hl.shape[0], dims["d_out"]), float("nan")).cuda()
+            base.update(out=out, no_tail=hint)
+            _run(base, keep)
+            outs.append(out.cpu())
+            assert torch.isfinite(outs[-1]).all()
+            assert (outs[-1].double() - ref).abs().max().item() / ref.abs().max().item() < TOL["f32"]
+        if hint_true:
+            assert torch.equal(outs[0], outs[1])
+        else:
+            assert (outs[0] - outs[1]).abs().max().item() / ref.abs().max().item() < 2e-6
+
+
 @pytest.mark.parametrize("kind,mode", [(0, "p2l"), (2, "p2l"), (3, "p2l"), (1, "l2p"), (2, "l2p")])
 def test_conv_node_fused_pair_equals_the_two_launches(kind, mode):
     """dp_tp_conv_node_fused([conv, norm-conv]) - one launch, shared accumulators - against the two convs launched one after the other
