@@ -631,15 +631,34 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   const bool node_side = plan_node_side(b, w, k);
   // lig-lig conv on the node-side kernel too (pair-dense form): pays while a pose's atoms fit a few 32-slot passes
   const bool node_ll = plan_node_ll(b, w, k);
+  // optional second stream: phore-side convs of a layer (and the torsion head) run beside the ligand-side ones
+  hipStream_t aux = (k->aux_stream && k->ev_fork && k->ev_join) ? (hipStream_t)k->aux_stream : nullptr;
+  int ev_rc = 0;                                   // first failing event / stream call (reported at the end: launches are asynchronous anyway)
+  auto note = [&](hipError_t e) { if (e != hipSuccess && ev_rc == 0) ev_rc = (int)e; };
+  bool aux_forked = false;
+  auto fork = [&]() {
+    if (aux) { note(hipEventRecord((hipEvent_t)k->ev_fork, st)); note(hipStreamWaitEvent(aux, (hipEvent_t)k->ev_fork, 0)); aux_forked = true; }
+  };
+  auto join = [&]() {
+    if (aux) { note(hipEventRecord((hipEvent_t)k->ev_join, aux)); note(hipStreamWaitEvent(st, (hipEvent_t)k->ev_join, 0)); }
+    aux_forked = false;
+  };
+  // error exit: never leave the aux stream forked (eager: later work on `st` must stay ordered after it; capture: an unjoined stream
+  // turns the caller's hipStreamEndCapture into an error that masks `rc`)
+  auto fail = [&](int rc_) { if (aux_forked) join(); return rc_; };
   hipLaunchKernelGGL(dp::time_params_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, b->t, *w, k->tparams);
+  // the three graph / embedding kernels only share their inputs (positions, time parameters): the ligand radius graph runs on the second
+  // stream beside the node embeddings and the cross edges (each is one workgroup per pose and latency-bound on its own)
+  if (aux) fork();
   {
     // the N x N pair tables are filled (and verified: status bit 1) only when the node-side ligand-ligand conv will read them
     DpWork kg = *k;
     if (!node_ll) kg.ll_pair_rad = kg.ll_pair_bond = nullptr;
-    hipLaunchKernelGGL(dp::lig_graph_kernel, dim3(B), dim3(256), 0, st, *b, *w, kg);
+    hipLaunchKernelGGL(dp::lig_graph_kernel, dim3(B), dim3(256), 0, aux ? aux : st, *b, *w, kg);
   }
   hipLaunchKernelGGL(dp::node_embed_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
   hipLaunchKernelGGL(dp::cross_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  if (aux) join();
   // workgroups per pose: keep <= 48 scatter nodes per workgroup and >= ~2 workgroups per CU in flight
   int slices = 1;
   {
@@ -659,21 +678,6 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   }
   const int nb = dp_conv_node_max_nodes();
   const int slices_pl = (b->max_nl + nb - 1) / nb, slices_lp = (b->max_np + nb - 1) / nb;
-  // optional second stream: phore-side convs of a layer (and the torsion head) run beside the ligand-side ones
-  hipStream_t aux = (k->aux_stream && k->ev_fork && k->ev_join) ? (hipStream_t)k->aux_stream : nullptr;
-  int ev_rc = 0;                                   // first failing event / stream call (reported at the end: launches are asynchronous anyway)
-  auto note = [&](hipError_t e) { if (e != hipSuccess && ev_rc == 0) ev_rc = (int)e; };
-  bool aux_forked = false;
-  auto fork = [&]() {
-    if (aux) { note(hipEventRecord((hipEvent_t)k->ev_fork, st)); note(hipStreamWaitEvent(aux, (hipEvent_t)k->ev_fork, 0)); aux_forked = true; }
-  };
-  auto join = [&]() {
-    if (aux) { note(hipEventRecord((hipEvent_t)k->ev_join, aux)); note(hipStreamWaitEvent(st, (hipEvent_t)k->ev_join, 0)); }
-    aux_forked = false;
-  };
-  // error exit: never leave the aux stream forked (eager: later work on `st` must stay ordered after it; capture: an unjoined stream
-  // turns the caller's hipStreamEndCapture into an error that masks `rc`)
-  auto fail = [&](int rc_) { if (aux_forked) join(); return rc_; };
   int cur = 0;
   static const int D[5] = {20, 50, 80, 100, 100};
   auto timed = [&](const DpConvArgs& c, int layer, int which, hipStream_t s_) -> int {
@@ -696,7 +700,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     a.phase_split = (B * slices < 512) ? 1 : 0;      // under-filled chip: one workgroup per accumulation phase (see DpConvArgs)
     a.sh_stride = 9; a.out_stride = 100; a.resid_stride = 100;
     a.gather_stride = a.attr1_stride = a.attr2_stride = 100;
-    const bool two = aux != nullptr && l != 3;
+    const bool two = aux != nullptr && l != 3 && k->aux_mode != 1;
     hipStream_t sp_ = two ? aux : st;           // stream of the phore-side convs
     if (two) fork();
     // timing hook around the launch that contains conv `which` (a fused launch answers for each of its convs)
@@ -779,7 +783,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   }
   const float* hl = k->h_l[cur];
   // translation / rotation head on the launch stream, torsion head beside it when a second stream was given
-  const bool tor_aux = aux != nullptr && b->n_tor > 0;
+  const bool tor_aux = aux != nullptr && b->n_tor > 0 && k->aux_mode != 1;
   if (tor_aux) fork();
   hipLaunchKernelGGL(dp::center_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
   {

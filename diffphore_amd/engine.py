@@ -65,7 +65,7 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("ll_node_max_atoms", c_i32), ("edge_x6", c_i32), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_x6", c_i32), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -495,17 +495,23 @@ class Engine:
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         self._handles = None
         self._graph = None
+        # second stream (DpWork.aux_stream): 'auto' runs the phore-side convs and the torsion head beside the ligand-side convs when one
+        # conv launch cannot keep the chip busy - small batches, and ragged ones (virtual screening: 15-45 atoms, the launch tails of the
+        # big poses leave CUs idle: 640 poses 34.8k vs 33.8k pose-steps/s) - and only the ligand radius graph otherwise (two matrix-bound
+        # convs side by side lose on a large homogeneous batch: 512 x 30 atoms 90.1k vs 94.9k)
         two = os.environ.get("DIFFPHORE_TWO_STREAMS", "auto")
-        if two == "1":
-            self.enable_two_streams()
-        elif two == "auto" and pb.B < TWO_STREAM_MAX_POSES:
+        nl_, np_ = np.asarray(pb.nl, dtype=np.float64), np.asarray(pb.np_, dtype=np.float64)
+        ragged = bool((nl_ * np_).max() > 1.3 * (nl_ * np_).mean())
+        if two in ("1", "graph"):
+            self.enable_two_streams(1 if two == "graph" else 0)
+        elif two == "auto":
             try:
-                self.enable_two_streams()
+                self.enable_two_streams(0 if (pb.B < TWO_STREAM_MAX_POSES or ragged) else 1)
             except _lib.DiffPhoreLibraryError:          # an optimisation only: a single stream computes the same result
                 self._handles = None
         _lib.check(self.L.dp_prepare(C.byref(pb.struct), C.byref(model.struct), C.byref(self.ws.struct), _stream()), "dp_prepare")
 
-    def enable_two_streams(self):
+    def enable_two_streams(self, aux_mode: int = 0):
         """dp_forward then runs the phore-side convs of a layer and the torsion head on a second stream (bit-identical results;
         pays when the batch is too small to fill the chip with one conv at a time)."""
         if self._handles is None:
@@ -513,6 +519,7 @@ class Engine:
             self._handles = _HipHandles.for_device(dev.index if dev.index is not None else torch.cuda.current_device())
             w = self.ws.struct
             w.aux_stream, w.ev_fork, w.ev_join = self._handles.stream, self._handles.ev_fork, self._handles.ev_join
+        self.ws.struct.aux_mode = int(aux_mode)
 
     def __del__(self):
         if getattr(self, "_graph", None):

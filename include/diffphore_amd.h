@@ -277,6 +277,8 @@ typedef struct DpWork {
    * layer (and the torsion head) on `aux_stream`, forked from / joined back to the launch stream with the events.  Results are
    * bit-identical; it only helps batches too small to fill the chip with one conv at a time.  Capturable into a hipGraph. */
   void *aux_stream, *ev_fork, *ev_join;
+  int32_t aux_mode;                 /* what runs on aux_stream: 0 = the phore-side convs of a layer, the torsion head and the ligand radius graph;
+                                       1 = the ligand radius graph only (large homogeneous batches: two matrix-bound convs side by side lose) */
   int32_t ll_node_max_atoms;        /* the ligand-ligand conv runs node-side (pair-dense) while the batch's largest ligand has at most this many
                                        atoms, edge-side (CSR) beyond; 0 = library default */
   int32_t edge_x6;                  /* 0 = edge-side convs of an fp32 model use DpConvW.w2x (bf16x6) when present (default), 1 = exact fp32 MFMA */
