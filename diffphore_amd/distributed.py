@@ -113,7 +113,7 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
         * hands each finished complex to `on_result(i, poses [samples, n_atoms, 3] float32)` and drops it; with on_result=None the arrays
           are collected and returned (only sensible for small runs).
 
-    Returns (indices owned by this rank in processing order, list of pose arrays or None).  Peak host memory: two device batches of
+    Returns (indices owned by this rank in processing order - heaviest first when `costs` is given -, list of pose arrays or None).  Peak host memory: two device batches of
     pose objects, whatever the library size."""
     import torch.distributed as dist
 
@@ -124,7 +124,9 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
     if costs is not None:
         if len(costs) != n_units:
             raise ValueError("costs needs one entry per unit")
-        mine = shard_indices(costs, world)[rank]
+        # heaviest first: similar sizes share a device batch (its launch geometry follows the largest pose), and inside a launch the
+        # workgroups - dispatched in pose order - end on the cheapest poses instead of on a straggler
+        mine = sorted(shard_indices(costs, world)[rank], key=lambda i: (-costs[i], i))
     else:
         mine = list(range(rank, n_units, world))
     if int(n_units) * samples_per_complex >= 2 ** 31:

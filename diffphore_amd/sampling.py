@@ -206,8 +206,6 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
         if write_back:
             _finish_run(engine, data_list)
         return data_list, None
-    if N > max_poses and visualization_list is not None:
-        raise NotImplementedError("visualization_list with more than max_poses poses")
     # Device-batch the pose list (`max_poses` per batch).  Poses are independent, so results do not depend on the batching.  With more
     # than one batch and noise=None the global generators are still consumed in the reference's order for the WHOLE list - start
     # randomisation of every pose first, then step-major normals per `batch_size` chunk - by drawing everything before the first batch
@@ -271,7 +269,7 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
         part, sub, rz, uids = item
         return (part, uids) + _host_stage(part, device, *common, ode, no_random, no_final_step_noise, batch_size, sub, randomize, rz, on_dev)
 
-    cur, first = pull(), True
+    cur, first, n_seen = pull(), True, 0
     while cur is not None:
         part, uids, pb, Z, T_all, rz = cur
         pb.upload()
@@ -285,7 +283,9 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
             torch.cuda.synchronize()
             timing["pack_and_noise_s"] = _time.time() - _t0
             _t0 = _time.time()
-        _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, visualization_list, dev_noise)
+        vis = visualization_list[n_seen:n_seen + len(part)] if visualization_list is not None else None      # this device batch's recorders
+        n_seen += len(part)
+        _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, vis, dev_noise)
         nxt = pull()
         if timing is not None and nxt is None:
             torch.cuda.synchronize()
@@ -496,6 +496,10 @@ def sampling_phore_with_fitscore(data_list, model, inference_steps, tr_schedule,
         raise NotImplementedError("sampling_phore_with_fitscore(ode=True) with torsions is undefined in the reference (NameError at sampling.py:378)")
     if R > 1 and not no_random and fitscore_fn is None:
         raise ValueError("random_samples > 1 needs fitscore_fn (the reference calls the AncPhore binary here)")
+    if N > 65536:
+        # one device batch by construction (the candidates of a step are scored together); the reference calls this with one complex's
+        # samples (tens of poses)
+        raise ValueError("sampling_phore_with_fitscore packs all poses into one device batch: split the list (<= 65536 poses per call)")
     eng = Engine(model.device_model, PackedBatch(data_list, device))
     eng.ws.t["status"].zero_()
     pb = eng.pb

@@ -54,7 +54,10 @@ def build(config: int, units_per_gpu: int, rank: int = 0, world: int = 1) -> Tup
     n_units = units_per_gpu * world
     cplx = synthetic.synthetic_pairs(config, n_units, s["n_atoms"], s["n_tor"], s["n_phore"], seed=synthetic.BASE_SEED + config,
                                      shared_phore=(config == 4), shared_ligand=(config == 5))
-    mine = shard_indices([pose_cost(g) for g in cplx], world)[rank]
+    costs = [pose_cost(g) for g in cplx]
+    mine = shard_indices(costs, world)[rank]
+    # heaviest complexes first: workgroups are dispatched in pose order, so a launch then ends on its cheapest poses instead of on a straggler
+    mine = sorted(mine, key=lambda i: (-costs[i], i))
     poses = [cplx[i].sample_copy() for i in mine for _ in range(SAMPLES)]
     return poses, mine
 

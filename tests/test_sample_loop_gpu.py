@@ -79,3 +79,42 @@ def test_graph_replay_reproduces_the_run():
     torch.cuda.synchronize()
     assert torch.equal(pb.pos, a) and not torch.equal(a, pos0)
     assert int(eng.ws.t["status"].abs().sum()) == 0
+
+
+def test_visualization_recorders_follow_their_poses_across_device_batches():
+    """`visualization_list` (one recorder per pose, `.add(coords, part=1, order=step + 2)` after every step, sampling.py:251-254) with more
+    poses than `max_poses`: every device batch feeds the recorders of ITS poses - same frames as a single-batch run."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    from diffphore_amd.score_model import TensorProductScoreModel
+
+    class Rec:
+        def __init__(self):
+            self.frames = []
+
+        def add(self, coords, part, order):
+            self.frames.append((order, part, coords.numpy().copy()))
+
+    gs = synthetic.synthetic_pairs(77, 6, (14, 22), (2, 4), (10, 20))
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    S = 3
+    sched = get_t_schedule(20)[:S + 1]
+    m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+    g0 = torch.Generator().manual_seed(5)
+    nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
+    noise = dict(tr=torch.randn(S, 6, 3, generator=g0), rot=torch.randn(S, 6, 3, generator=g0), tor=torch.randn(S, nT, generator=g0))
+    runs = []
+    for mp in (8192, 4):
+        recs = [Rec() for _ in gs]
+        out, _ = sampling_phore([g.sample_copy() for g in gs], m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise,
+                                visualization_list=recs, max_poses=mp)
+        assert all(len(r.frames) == S and [f[0] for f in r.frames] == [2, 3, 4] for r in recs)
+        # the last frame is the final pose in the original frame
+        for r, g in zip(recs, out):
+            np.testing.assert_allclose(r.frames[-1][2], (g["ligand"].pos + g.original_center).numpy(), atol=1e-6)
+        runs.append(recs)
+    for a, b in zip(*runs):
+        for fa, fb in zip(a.frames, b.frames):
+            assert np.abs(fa[2] - fb[2]).max() < 2e-5
