@@ -14,14 +14,16 @@ import sqlite3
 # launch order of the convs of one kernel instantiation inside one dp_forward (dp_graph.hip)
 EDGE_ALL = ["lig-lig", "phore->lig", "phore->lig(norm)", "phore-phore", "lig->phore", "lig->phore(norm)"]
 SLOTS = {}
-# node-side kernels: tp_conv_node_kernel<KIND, HAS_LL, XMODE> (and the _split_ twin for small batches); default dp_forward fuses the convs
-# of a side into one launch, so every instantiation is launched once per forward
+# node-side kernels: tp_conv_node_kernel<KIND, HAS_LL, XMODE, HALFOK> (and the _split_ twin for small batches; HALFOK = false is the lean
+# instantiation without the half-pass variant); default dp_forward fuses the convs of a side into one launch, so every instantiation
+# is launched once per forward
 LIG3, LIG2, PH2 = "lig-lig + phore->lig + phore->lig(norm)", "phore->lig + phore->lig(norm)", "lig->phore + lig->phore(norm)"
 for k in range(4):
     for kn in ("tp_conv_node_kernel", "tp_conv_node_split_kernel"):
-        SLOTS[f"{kn}<{k}, true, 1>"] = [LIG3]
-        SLOTS[f"{kn}<{k}, false, 1>"] = [LIG2]
-        SLOTS[f"{kn}<{k}, false, 2>"] = [PH2]
+        for h in ("true", "false"):
+            SLOTS[f"{kn}<{k}, true, 1, {h}>"] = [LIG3]
+            SLOTS[f"{kn}<{k}, false, 1, {h}>"] = [LIG2]
+            SLOTS[f"{kn}<{k}, false, 2, {h}>"] = [PH2]
 SLOTS["tp_conv_kernel<4>"] = ["centre (final_conv)"]
 SLOTS["tp_conv_kernel<5>"] = ["torsion bonds (tor_bond_conv)"]
 # SURVEY.md 8d per edge-conv (edge-side count): 2*(n_attr*hid + hid*numel) + 2*sum_paths mul_in*mul_out*(2 l_out + 1); kinds 4 / 5 = the
@@ -38,18 +40,22 @@ def short(name):
 
 def slot_names(kernels_seen):
     """edge-side layer kernels: all six slots when the node-side kernel is absent, only phore-phore (and lig-lig when that ran
-    edge-side) otherwise"""
+    edge-side) otherwise; in an fp32 model those edge-side convs run as tp_conv_bf16_kernel<KIND, 3, false> (bf16x6)"""
     s = dict(SLOTS)
     node = any("tp_conv_node" in k for k in kernels_seen)
-    node_ll = any("tp_conv_node" in k and ", true, " in k for k in kernels_seen)
+    node_ll = any("tp_conv_node" in k and ", true, " in k.split("<")[1][:12] for k in kernels_seen)
+    x6 = any(k.startswith("tp_conv_bf16_kernel<") and k.endswith(", 3, false>") for k in kernels_seen)
     for k in range(4):
-        n = f"tp_conv_kernel<{k}>"
-        if not node:
-            s[n] = EDGE_ALL if k < 3 else EDGE_ALL[:3]
-        elif node_ll:
-            s[n] = ["phore-phore"]
-        else:
-            s[n] = ["lig-lig", "phore-phore"] if k < 3 else ["lig-lig"]
+        names = [f"tp_conv_kernel<{k}>"] + ([f"tp_conv_bf16_kernel<{k}, 3, false>"] if node and x6 else [])
+        for n in names:
+            if not node:
+                s[n] = EDGE_ALL if k < 3 else EDGE_ALL[:3]
+            elif node_ll:
+                s[n] = ["phore-phore"]
+            else:
+                s[n] = ["lig-lig", "phore-phore"] if k < 3 else ["lig-lig"]
+    if node and x6:
+        s["tp_conv_bf16_kernel<5, 3, false>"] = ["torsion bonds (tor_bond_conv)"]
     return s
 
 
@@ -121,7 +127,7 @@ def main():
                 if f and w:
                     fa, wa = sum(f) / len(f), sum(w) / len(w)
                     res.append(f"{k},{sname},{len(f)},{fa:.1f},{wa:.1f},{2 * fa / 1024:.2f},{wa / 1024:.2f}")
-                    if (k.startswith("tp_conv_node") and k.endswith("<2, true, 1>")) or (k == "tp_conv_kernel<2>" and sname == "phore->lig"):
+                    if (k.startswith("tp_conv_node_kernel<2, true, 1, ")) or (k == "tp_conv_kernel<2>" and sname == "phore->lig"):
                         rec = int((2 * fa + wa) * 1024)
         open(f"{a.prefix}_conv_hbm_traffic.csv", "w").write("\n".join(res) + "\n")
         if rec is not None and bench is not None:
