@@ -609,7 +609,7 @@ int dp_forward_launch_of(const DpBatch* b, const DpWeights* w, const DpWork* k, 
   int f = conv, n = 1;
   bool ns = false;
   if (conv <= 2) {                                  // ligand side: lig_conv, phore_to_lig, phore_to_lig_norm
-    if (node_side && fuse && node_ll) { f = 0; n = 3; }
+    if (node_side && fuse && node_ll && k->conv_fuse != 2) { f = 0; n = 3; }
     else if (node_side && fuse && conv >= 1) { f = 1; n = 2; }
     ns = conv == 0 ? node_ll : node_side;
   } else if (conv >= 4) {                           // pharmacophore side: lig_to_phore, lig_to_phore_norm (conv 3 = phore_conv, edge-side)
@@ -737,7 +737,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.out = hl2; c.accumulate = 1;
       if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); c.no_tail = b->no_tail_np; }
     }
-    if (node_side && fuse && node_ll) {
+    if (node_side && fuse && node_ll && k->conv_fuse != 2) {
       // one launch: the three convs scatter onto the same atoms and their outputs add up (:703-706)
       ligc[1].accumulate = ligc[2].accumulate = 0;
       if ((rc = timed_fused(ligc, 3, 0, 2, st))) return fail(rc);

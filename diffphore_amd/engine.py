@@ -490,7 +490,7 @@ class Engine:
         self.L.dp_resolve_conv_algo.argtypes = [c_i32, c_i32, c_i32]
         self.L.dp_resolve_conv_algo.restype = C.c_int
         self.conv_algo = {1: "edge", 2: "node"}[self.L.dp_resolve_conv_algo(CONV_ALGOS[conv_algo], model.struct.precision, pb.B)]
-        self.ws.struct.conv_fuse = 1 if os.environ.get("DIFFPHORE_CONV_FUSE", "1") == "0" else 0
+        self.ws.struct.conv_fuse = {"1": 0, "0": 1, "pairs": 2}[os.environ.get("DIFFPHORE_CONV_FUSE", "1")]
         self.ws.struct.edge_x6 = 1 if os.environ.get("DIFFPHORE_EDGE_X6", "1") == "0" else 0
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         self._handles = None

@@ -170,6 +170,23 @@ def test_seeded_sampler_is_independent_of_batching_and_order():
     assert max(_rmsd(base[i], step[i]) for i in range(12)) < 2e-5
 
 
+def test_seeded_loop_captured_into_a_hipgraph_equals_the_eager_loop(monkeypatch):
+    """DP_NOISE_SEED inside dp_sample_graph_create: the per-step dp_noise_normals launches are captured with their step index baked in;
+    a replay draws the same numbers as the eager loop (bit-identical final poses)."""
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    gs = synthetic.synthetic_pairs(45, 5, (14, 24), (2, 4), (10, 24))
+    args, S = _args(), 4
+    sched = get_t_schedule(20)[:S + 1]
+    m = _model()
+    res = {}
+    for graph in ("0", "1"):
+        monkeypatch.setenv("DIFFPHORE_GRAPH", graph)
+        out, _ = sampling_phore([g.sample_copy() for g in gs], m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, seed=2024)
+        res[graph] = torch.cat([g["ligand"].pos for g in out])
+    assert torch.isfinite(res["0"]).all() and torch.equal(res["0"], res["1"])
+
+
 def test_seeded_poses_of_one_complex_differ():
     from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
     from diffphore_amd.sampling import sampling_phore
