@@ -190,7 +190,6 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
                    seed: Optional[int] = None, pose_uid=None):
     """`randomize={'no_torsion','no_random','tr_sigma_max'[,'keep_update','draws']}` fuses `randomize_position` into the call: every
     device batch is packed once, randomised on the device and sampled, without the pack / D2H / re-pack round trip of two calls."""
-    import time as _time
     if confidence_model is not None:
         raise NotImplementedError("confidence models are outside the accelerated path (SURVEY.md 8b)")
     N = len(data_list)
