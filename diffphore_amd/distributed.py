@@ -99,6 +99,24 @@ def fit_complexes(graphs: Sequence, model, args, samples_per_complex: int = 40, 
     return idx, out
 
 
+def screen_plan(n_units: int, costs, rank: int, world: int, samples_per_complex: int = 40, max_poses: int = 8192) -> List[List[int]]:
+    """Which units rank `rank` of `world` processes, cut into device batches (lists of unit indices, in processing order).  Pure host
+    arithmetic on the cost list: every rank computes its own plan without building or exchanging anything.  With `costs` the shard is
+    the LPT partition (`shard_indices`) walked heaviest first - similar sizes share a device batch (its launch geometry follows the
+    largest pose), and inside a launch the workgroups, dispatched in pose order, end on the cheapest poses instead of on a straggler;
+    without, units are dealt round-robin.  A batch holds whole complexes, at most `max_poses` poses (at least one complex)."""
+    if costs is not None:
+        if len(costs) != n_units:
+            raise ValueError("costs needs one entry per unit")
+        mine = sorted(shard_indices(costs, world)[rank], key=lambda i: (-costs[i], i))
+    else:
+        mine = list(range(rank, n_units, world))
+    if int(n_units) * samples_per_complex >= 2 ** 31:
+        raise ValueError("pose uids are 32-bit: n_units * samples_per_complex must stay below 2^31")
+    per = max(1, max_poses // samples_per_complex)
+    return [mine[lo:lo + per] for lo in range(0, len(mine), per)]
+
+
 def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None, samples_per_complex: int = 40, device="cuda",
            max_poses: int = 8192, seed: int = 0, on_result=None):
     """Streaming form of `fit_complexes` for library-scale screening (BASELINE configs[3] / configs[4]: 10^4-10^5 complexes x 40 samples
@@ -121,24 +139,15 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
     from .sampling import sampling_phore_stream
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    if costs is not None:
-        if len(costs) != n_units:
-            raise ValueError("costs needs one entry per unit")
-        # heaviest first: similar sizes share a device batch (its launch geometry follows the largest pose), and inside a launch the
-        # workgroups - dispatched in pose order - end on the cheapest poses instead of on a straggler
-        mine = sorted(shard_indices(costs, world)[rank], key=lambda i: (-costs[i], i))
-    else:
-        mine = list(range(rank, n_units, world))
-    if int(n_units) * samples_per_complex >= 2 ** 31:
-        raise ValueError("pose uids are 32-bit: n_units * samples_per_complex must stay below 2^31")
+    batches = screen_plan(n_units, costs, rank, world, samples_per_complex, max_poses)
+    mine = [i for bt in batches for i in bt]
     steps = int(getattr(args, "inference_steps", 20))
     sched = get_t_schedule(steps)
-    per = max(1, max_poses // samples_per_complex)
 
     def parts():
-        for lo in range(0, len(mine), per):
+        for bt in batches:
             poses, uids = [], []
-            for i in mine[lo:lo + per]:
+            for i in bt:
                 g = load_unit(i)
                 for s_ in range(samples_per_complex):
                     poses.append(g.sample_copy() if hasattr(g, "sample_copy") else __import__("copy").deepcopy(g))

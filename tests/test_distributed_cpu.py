@@ -92,3 +92,62 @@ def test_screen_library_units_are_pure_functions_of_seed_and_index():
     a, b = lib5.unit(1), lib5.unit(8)                                           # the same ligand, placed relative to each phore's centre
     assert torch.allclose(a["ligand"].pos + a["original_center"], b["ligand"].pos + b["original_center"], atol=1e-5)
     assert torch.equal(a["ligand"].x, b["ligand"].x) and a["phore"].pos.shape[0] == lib5.sizes(1)[2] != b["phore"].pos.shape[0]
+
+
+def test_screen_plan_covers_every_unit_once_and_walks_heaviest_first():
+    """distributed.screen_plan: pure host arithmetic every rank does on the cost list alone"""
+    from diffphore_amd import distributed as D
+    from diffphore_amd import synthetic
+    lib = synthetic.ScreenLibrary(4, 203)
+    costs = [lib.cost(i) for i in range(len(lib))]
+    for world in (1, 2, 8):
+        seen, loads = [], []
+        for rank in range(world):
+            batches = D.screen_plan(len(lib), costs, rank, world, samples_per_complex=40, max_poses=640)
+            flat = [i for bt in batches for i in bt]
+            assert all(1 <= len(bt) <= 16 for bt in batches) and all(len(bt) == 16 for bt in batches[:-1])      # 640 // 40 complexes
+            assert [costs[i] for i in flat] == sorted((costs[i] for i in flat), reverse=True)                  # heaviest first
+            seen += flat
+            loads.append(sum(costs[i] for i in flat))
+        assert sorted(seen) == list(range(len(lib)))
+        assert max(loads) - min(loads) <= max(costs)                                                          # LPT balance
+    # no cost list: round-robin; one complex larger than a device batch still gets its own batch
+    assert D.screen_plan(7, None, 1, 3, 40, 8192) == [[1, 4]]
+    assert D.screen_plan(3, [1, 2, 3], 0, 1, samples_per_complex=40, max_poses=8) == [[2], [1], [0]]
+    with pytest.raises(ValueError):
+        D.screen_plan(3, [1, 2], 0, 1)
+    with pytest.raises(ValueError):
+        D.screen_plan(2 ** 27, None, 0, 1, samples_per_complex=40)
+
+
+def _plan_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from diffphore_amd import distributed as D
+    from diffphore_amd import synthetic
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = synthetic.ScreenLibrary(5, 37)
+        plan = D.screen_plan(len(lib), [lib.cost(i) for i in range(len(lib))], dist.get_rank(), dist.get_world_size(), 40, 400)
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(plan, gathered, dst=0)
+        if rank == 0:
+            q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_plan_disjoint_shards_without_exchanging_anything():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    plans = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    a, b = ([i for bt in pl for i in bt] for pl in plans)
+    assert not set(a) & set(b) and sorted(a + b) == list(range(37)) and all(len(bt) <= 10 for pl in plans for bt in pl)
