@@ -277,7 +277,17 @@ class PackedBatch:
         nl = np.asarray([g["ligand"].pos.shape[0] for g in graphs], dtype=np.int64)
         npn = np.asarray([g["phore"].pos.shape[0] for g in graphs], dtype=np.int64)
         nb = np.asarray([g["ligand", "ligand"].edge_index.shape[1] for g in graphs], dtype=np.int64)
-        nt = np.asarray([int(torch.as_tensor(g["ligand"].edge_mask).sum()) for g in graphs], dtype=np.int64)
+        # the samples of one complex share their static tensors (HeteroData.sample_copy): whatever is derived from a static tensor is
+        # computed once per tensor OBJECT and reused for its other samples (a screening batch: 40 samples per complex)
+        memo: Dict[tuple, object] = {}
+
+        def once(v, fn):
+            k = (id(v), fn)
+            if k not in memo:
+                memo[k] = (v, fn(v))                   # (the tensor is kept alive with its entry: ids are not recycled meanwhile)
+            return memo[k][1]
+        n_true = lambda m: int(torch.as_tensor(m).sum())      # noqa: E731
+        nt = np.asarray([once(g["ligand"].edge_mask, n_true) for g in graphs], dtype=np.int64)
         npp = np.asarray([g["phore", "phore"].edge_index.shape[1] for g in graphs], dtype=np.int64)
         if nl.max() > 256 or npn.max() > 256 or nt.max() > 128:
             raise ValueError("diffphore_amd kernel limits: <=256 ligand atoms, <=256 pharmacophore nodes, <=128 torsions per pose")
@@ -296,13 +306,16 @@ class PackedBatch:
         P = [g["phore"] for g in graphs]
         # Host packing is numpy, not torch: on a many-core host every small torch CPU op (cat / reshape) pays the intra-op thread
         # pool (measured 1 ms per torch.cat on a 256-thread box: 170 ms to pack 512 poses, 15 ms with numpy).
-        def A(v):
+        def to_np(v):
             if not torch.is_tensor(v):
                 return np.asarray(v)
             try:
                 return v.numpy()                       # CPU tensor without grad: zero-copy
             except (RuntimeError, TypeError):
                 return v.detach().cpu().numpy()
+
+        def A(v):
+            return once(v, to_np)
 
         def cat(vals, dtype, axis=0):
             return np.ascontiguousarray(np.concatenate([A(v) for v in vals], axis=axis).astype(dtype, copy=False))
