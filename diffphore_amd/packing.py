@@ -33,7 +33,7 @@ def bn_affine(sd: Dict[str, torch.Tensor], prefix: str, irreps, eps: float = 1e-
 
 def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: int = 0, node_side: bool = False, x6: bool = False) -> Dict[str, torch.Tensor]:
     """fc.0 / fc.3 / batch_norm of one TensorProductConvLayer -> MFMA operand order (host tensors).  `node_side` adds the layout of
-    the node-side kernel (dp_conv_node.hip: layer convs over the dense cross edge sets, fp32); `x6` adds the second layer packed for
+    the node-side kernel (dp_conv_node_impl.h: layer convs over the dense cross edge sets, fp32); `x6` adds the second layer packed for
     DP_PREC_BF16X6 (`w2x`: what the edge-side convs of an fp32 model run on, DpConvW.w2x)."""
     L = _lib.lib()
     dims = _lib.conv_dims(kind)

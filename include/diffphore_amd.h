@@ -65,7 +65,7 @@ enum DpPrecision {
 enum DpConvAlgo {
   DP_ALGO_AUTO = 0,     /* library's choice by precision and batch size (dp_resolve_conv_algo) */
   DP_ALGO_EDGE = 1,     /* dp_conv.hip: w[e] = W2 hid[e] on the matrix pipe per edge, CG contraction on the VALU, segmented mean */
-  DP_ALGO_NODE = 2      /* dp_conv_node.hip: T[n] = hid^T z over the node's edges, out[n] = W2 T[n] batched over 16 nodes */
+  DP_ALGO_NODE = 2      /* dp_conv_node*.{hip,h}: T[n] = hid^T z over the node's edges, out[n] = W2 T[n] batched over 16 nodes */
 };
 
 typedef struct DpConvArgs {
