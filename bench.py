@@ -383,7 +383,7 @@ def main():
     e2e_screen = None
     if not a.no_e2e and world == 1 and (a.config in (4, 5) or (a.config == 2 and not a.no_other and a.precision is None and a.conv_algo is None and a.poses is None)):
         # secondary figure for the library workloads (configs[3] virtual screen / configs[4] target fishing): the streaming driver
-        # distributed.screen over a lazily generated library 3x the per-GPU bench size - units are built on the host (`load_unit`) while
+        # distributed.screen over a lazily generated library 6x the per-GPU bench size - units are built on the host (`load_unit`) while
         # the GPU samples the previous device batch, start randomisation and noise are drawn on the device (seed), every finished
         # complex is handed to a sink and dropped.  Reported: whole-call pose-steps/s, the host time spent building units (hidden behind
         # the device loop except for the first batch) and the process RSS before / after (flat = nothing accumulates).
@@ -393,7 +393,7 @@ def main():
         from diffphore_amd import synthetic
         from diffphore_amd.score_model import TensorProductScoreModel
         c = a.config if a.config in (4, 5) else 4
-        n_lib = 3 * (units if a.config in (4, 5) else workloads.DEFAULT_UNITS[c])
+        n_lib = 6 * (units if a.config in (4, 5) else workloads.DEFAULT_UNITS[c])     # 6 device batches: the pipeline's fill / drain is a sixth of the run
         lib = synthetic.ScreenLibrary(c, n_lib)
         prec_c = "bf16x3" if c == 5 else "f32"
         m = TensorProductScoreModel(device=dev, precision=prec_c)

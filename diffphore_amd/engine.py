@@ -265,6 +265,43 @@ def _i32(x):
     return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.int32)
 
 
+# Host <-> device copies go through a side stream.  A synchronous copy on the launch stream waits for every kernel already queued there;
+# the sampler keeps the NEXT device batch's uploads and the PREVIOUS batch's write-back off that queue so that the GPU always has a loop
+# to run (sampling._run_parts).  Ordering is by the host: an upload has landed when h2d returns (pageable source: the call blocks on the
+# side stream only), a download is issued after the producing loop's event has been waited for.
+_COPY_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _copy_stream(device) -> "torch.cuda.Stream":
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _COPY_STREAMS:
+        _COPY_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _COPY_STREAMS[idx]
+
+
+def h2d(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    """CPU tensor -> `device` without touching the launch stream's queue (device tensors pass through)."""
+    if t is None or t.device.type != "cpu":
+        return t if t is None else t.to(device)
+    # The destination comes from the COPY stream's pool of the caching allocator: a block the launch stream has just freed may still be
+    # read by a kernel that is queued but has not run (a temporary of the batch being enqueued), and this copy executes at once.
+    # record_stream hands the block's lifetime to the launch stream, where its consumers are queued.
+    with torch.cuda.stream(_copy_stream(device)):
+        dst = torch.empty(t.shape, dtype=t.dtype, device=device)
+        dst.copy_(t)
+    dst.record_stream(torch.cuda.current_stream(dst.device))
+    return dst
+
+
+def d2h(t: torch.Tensor) -> torch.Tensor:
+    """device tensor -> CPU on the side stream; the caller has waited for the kernels that produced it"""
+    if t.device.type == "cpu":
+        return t
+    with torch.cuda.stream(_copy_stream(t.device)):
+        return t.cpu()
+
+
 class PackedBatch:
     """Struct-of-arrays image of a list of complexes on the device (static topology + diffusion state)."""
 
@@ -381,9 +418,9 @@ class PackedBatch:
         if self.static is not None:
             return self
         B, nl, npn, nt, n_ph = self.B, self.nl, self.np_, self.nt, self._n_ph
-        self.static = {k: v.to(self.device) for k, v in self._host.items()}
-        self.pos = self._host_pos.to(self.device)
-        self.norm = self._host_norm.to(self.device)
+        self.static = {k: h2d(v, self.device) for k, v in self._host.items()}
+        self.pos = h2d(self._host_pos, self.device)
+        self.norm = h2d(self._host_norm, self.device)
         self._host = self._host_pos = self._host_norm = None
         self.t = torch.zeros(B, 3, dtype=torch.float32, device=self.device)
         s = DpBatch()

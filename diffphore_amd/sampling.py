@@ -26,7 +26,7 @@ import torch
 from scipy.spatial.transform import Rotation as R
 
 from . import _lib
-from .engine import DpStepParams, Engine, PackedBatch, _declare, _stream
+from .engine import DpStepParams, Engine, PackedBatch, _declare, _stream, d2h, h2d
 
 
 GRAPH_MAX_POSES = 0        # `auto` never captures: the loop is GPU-bound down to 8 poses, a replay gains <= 0.5 % and the capture of a
@@ -78,7 +78,7 @@ def _device_noise(seed, noise, pose_uid, lo, n, device):
         uid = torch.as_tensor(list(pose_uid[lo:lo + n]), dtype=torch.int32)
         if uid.numel() != n:
             raise ValueError("pose_uid needs one entry per pose of data_list")
-    return int(seed), uid.to(device)
+    return int(seed), h2d(uid, device)
 
 
 def _randomize_on_device(pb, dev_noise, randomize):
@@ -118,8 +118,8 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
     keep_update = bool(getattr(model_args, "keep_update", False))
     eng.ws.t["status"].zero_()     # dp_conformer_update ORs its flag in: a run on a reused engine must not inherit an old failure
     if Z is not None:
-        Z = {k: v.to(dev, torch.float32).contiguous() for k, v in Z.items()}
-    T_all = T_all.to(dev).contiguous()
+        Z = {k: h2d(v.to(torch.float32).contiguous(), dev) for k, v in Z.items()}
+    T_all = h2d(T_all.contiguous(), dev)
     sps = []
     for t_idx in range(inference_steps):
         last = t_idx == inference_steps - 1
@@ -161,9 +161,12 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
                 vis.add((pos[lo:hi] + part[idx].original_center).detach().cpu(), part=1, order=t_idx + 2)
 
 
-def _check_status(eng):
-    """Per-pose status words of the device loop -> the exceptions the reference's callers expect."""
-    status = eng.ws.t["status"].cpu()
+def _check_status(eng, synced=False):
+    """Per-pose status words of the device loop -> the exceptions the reference's callers expect.  `synced`: the caller has already
+    waited for the loop (the download runs on the copy stream and is not ordered behind the launch stream by itself)."""
+    if not synced:
+        torch.cuda.current_stream(eng.pb.device).synchronize()
+    status = d2h(eng.ws.t["status"])
     if bool((status & 2).any()):
         raise ValueError("ligand graph lists the same ordered atom pair twice among its bond (or radius) edges for poses "
                          f"{torch.nonzero(status & 2).flatten().tolist()}: not representable by the node-side ligand-ligand conv "
@@ -173,10 +176,16 @@ def _check_status(eng):
         raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status & 1).flatten().tolist()}")
 
 
-def _finish_run(eng, part):
+def _finish_run(eng, part, done=None):
+    """Wait for the batch's loop (`done`: an event recorded behind it; None = the whole launch stream) and write the final state back.
+    The downloads run on the copy stream: on the launch stream they would queue behind the NEXT batch's loop."""
     pb = eng.pb
-    _check_status(eng)
-    pos, norm = pb.pos.cpu(), pb.norm.cpu()
+    if done is not None:
+        done.synchronize()
+    else:
+        torch.cuda.current_stream(pb.device).synchronize()
+    _check_status(eng, synced=True)
+    pos, norm = d2h(pb.pos), d2h(pb.norm)
     for i, g in enumerate(part):
         lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
         g["ligand"].pos = pos[lo:hi].clone()
@@ -268,9 +277,13 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
         part, sub, rz, uids = item
         return (part, uids) + _host_stage(part, device, *common, ode, no_random, no_final_step_noise, batch_size, sub, randomize, rz, on_dev)
 
-    cur, first, n_seen = pull(), True, 0
-    while cur is not None:
-        part, uids, pb, Z, T_all, rz = cur
+    n_seen = 0
+
+    def launch(item, first):
+        """upload, (randomise,) and enqueue the whole loop of one device batch; nothing here waits for work already queued on the launch
+        stream, so the GPU runs the previous batch meanwhile"""
+        nonlocal n_seen, _t0
+        part, uids, pb, Z, T_all, rz = item
         pb.upload()
         dev_noise = _device_noise(seed, None, uids, 0, len(part), pb.device) if on_dev else None
         if rz is not None:
@@ -285,17 +298,26 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
         vis = visualization_list[n_seen:n_seen + len(part)] if visualization_list is not None else None      # this device batch's recorders
         n_seen += len(part)
         _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, vis, dev_noise)
-        nxt = pull()
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(pb.device))
+        return part, eng, done
+
+    item = pull()
+    cur = launch(item, True) if item is not None else None
+    while cur is not None:
+        part, eng, done = cur
+        item = pull()                                # host stage of the next batch (the caller's lazy loading included) ...
+        nxt = launch(item, False) if item is not None else None      # ... and its loop, queued behind the running one
         if timing is not None and nxt is None:
-            torch.cuda.synchronize()
+            done.synchronize()
             timing["loop_s"] = _time.time() - _t0
             _t0 = _time.time()
         if write_back:
-            _finish_run(eng, part)
+            _finish_run(eng, part, done)
         if timing is not None and nxt is None:
             timing["write_back_s"] = _time.time() - _t0
         yield part
-        cur, first = nxt, False
+        cur = nxt
 
 
 def sampling_phore_stream(parts, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args, *, seed: int,
@@ -385,9 +407,7 @@ def _randomize_launch(pb, theta, rm, tr, no_torsion):
     L.dp_randomize_position.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]
     L.dp_randomize_position.restype = C.c_int
     dev = pb.device
-    theta = theta.to(dev) if theta is not None else None
-    rm = rm.to(dev)
-    tr = tr.to(dev) if tr is not None else None
+    theta, rm, tr = h2d(theta, dev), h2d(rm, dev), h2d(tr, dev)
     _lib.check(L.dp_randomize_position(C.byref(pb.struct), _lib.ptr(theta), rm.data_ptr(), _lib.ptr(tr), 1 if no_torsion else 0,
                                        _stream()), "dp_randomize_position")
 
