@@ -124,3 +124,50 @@ def test_philox_known_answers():
         out = U4()
         assert L.dp_philox4x32(U4(*ctr), U2(*key), out) == 0
         assert tuple(out) == want, [hex(x) for x in out]
+
+
+def test_rng_stream_fixture_words_and_box_muller():
+    """tests/golden/rng_stream.npz (made on an MI355X by make_rng_golden.py) pins the seeded noise stream: the Philox words of every
+    counter are exact integers - recomputed here through the host entry point - and the device's normals / uniform angles / rotation
+    matrices follow from them by the documented construction (Box-Muller on (x >> 8 + 0.5) * 2^-24; csrc/dp_rng.hip), recomputed in
+    numpy float64 and compared at 2e-6 (device logf / sincosf are not bit-specified)."""
+    import numpy as np
+    G = np.load(os.path.join(ROOT, "tests", "golden", "rng_stream.npz"))
+    L = _lib.lib()
+    U4, U2 = C.c_uint32 * 4, C.c_uint32 * 2
+    L.dp_philox4x32.argtypes = [U4, U2, U4]
+    seed = int(G["seed"])
+
+    def words(uid, step, block, stream):
+        out = U4()
+        assert L.dp_philox4x32(U4(uid & 0xFFFFFFFF, step & 0xFFFFFFFF, block, stream), U2(seed & 0xFFFFFFFF, seed >> 32), out) == 0
+        return np.asarray(list(out), dtype=np.uint32)
+
+    def unit(w):
+        return ((w >> 8).astype(np.float64) + 0.5) / 16777216.0
+
+    def normals(w):
+        u = unit(w)
+        r0, r1 = np.sqrt(-2 * np.log(u[0])), np.sqrt(-2 * np.log(u[2]))
+        return np.asarray([r0 * np.cos(2 * np.pi * u[1]), r0 * np.sin(2 * np.pi * u[1]), r1 * np.cos(2 * np.pi * u[3]), r1 * np.sin(2 * np.pi * u[3])])
+
+    for st in G["steps"]:
+        for i, uid in enumerate(G["uids"]):
+            W = [words(int(uid), int(st), blk, strm) for (blk, strm) in ((0, 0), (1, 0), (0, 1), (1, 1))]
+            assert np.array_equal(np.stack(W), G[f"words_{st}"][i])
+            n0, n1, t0, t1 = (normals(w) for w in W)
+            np.testing.assert_allclose(G[f"z_tr_{st}"][i], n0[:3], atol=2e-6, rtol=2e-6)
+            np.testing.assert_allclose(G[f"z_rot_{st}"][i], [n0[3], n1[0], n1[1]], atol=2e-6, rtol=2e-6)
+            np.testing.assert_allclose(G[f"z_tor_{st}"][i], np.concatenate([t0, t1[:3]]), atol=2e-6, rtol=2e-6)
+    for i, uid in enumerate(G["uids"]):
+        W = [words(int(uid), 0xFFFFFFFF, blk, strm) for (blk, strm) in ((0, 2), (1, 2), (0, 3), (1, 3))]
+        assert np.array_equal(np.stack(W), G["words_start"][i])
+        q = normals(W[0])
+        x, y, z, w = q / np.linalg.norm(q)                  # scalar-last unit quaternion -> rotation matrix
+        R = np.asarray([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        np.testing.assert_allclose(G["rot_mats"][i], R, atol=3e-6)
+        np.testing.assert_allclose(G["tr0"][i], 5.0 * normals(W[1])[:3], atol=1e-5, rtol=2e-6)
+        th = (2 * np.concatenate([unit(W[2]), unit(W[3])[:3]]) - 1) * np.pi
+        np.testing.assert_allclose(G["theta"][i], th, atol=2e-6)

@@ -297,3 +297,28 @@ def test_screen_two_ranks_equal_one_rank_with_the_same_seed():
     worst = max(_rmsd(sharded[i][s], res[i][s]) for i in range(7) for s in range(3))
     print("worst RMSD two ranks vs one (A):", worst)
     assert worst < 2e-5
+
+
+def test_device_stream_reproduces_the_committed_fixture(golden_dir):
+    """The seeded stream is part of the interface (a pinned seed must keep giving the same poses): the device regenerates
+    tests/golden/rng_stream.npz (uids up to 2^31 - 1, steps 0 / 5 / 19, both torsion blocks, the start-randomisation streams)."""
+    from diffphore_amd import _lib
+    from diffphore_amd.engine import PackedBatch, _declare, _stream
+    G = np.load(os.path.join(golden_dir, "rng_stream.npz"))
+    gs = synthetic.synthetic_pairs(4242, len(G["uids"]), 16, 7, 9)
+    pb = PackedBatch(gs, "cuda")
+    uid = torch.from_numpy(G["uids"].astype(np.int32)).cuda()
+    seed = int(G["seed"])
+    for st in G["steps"]:
+        a = _draw(pb, seed, int(st), uid=uid)
+        np.testing.assert_allclose(a[0], G[f"z_tr_{st}"], atol=2e-6, rtol=2e-6)
+        np.testing.assert_allclose(a[1], G[f"z_rot_{st}"], atol=2e-6, rtol=2e-6)
+        np.testing.assert_allclose(a[2].reshape(-1, 7), G[f"z_tor_{st}"], atol=2e-6, rtol=2e-6)
+    L = _declare()
+    B, nT = pb.B, int(pb.tor_ptr[-1])
+    th, rm, tr = torch.empty(nT, device="cuda"), torch.empty(B, 3, 3, device="cuda"), torch.empty(B, 3, device="cuda")
+    _lib.check(L.dp_randomize_draws(seed, C.byref(pb.struct), uid.data_ptr(), 0, 5.0, th.data_ptr(), rm.data_ptr(), tr.data_ptr(), _stream()), "draws")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(th.cpu().numpy().reshape(B, 7), G["theta"], atol=2e-6)
+    np.testing.assert_allclose(rm.cpu().numpy(), G["rot_mats"], atol=3e-6)
+    np.testing.assert_allclose(tr.cpu().numpy(), G["tr0"], atol=1e-5, rtol=2e-6)
