@@ -13,7 +13,7 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 7
+DP_ABI_VERSION = 8
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
@@ -78,6 +78,8 @@ def _declare(L):
     L.dp_tp_conv_node.argtypes = [C.POINTER(DpConvArgs), VOIDP]
     L.dp_tp_conv_node_fused.argtypes = [C.POINTER(DpConvArgs), c_i32, VOIDP]
     L.dp_tp_conv_node_fused.restype = C.c_int
+    L.dp_tp_conv_node_fused_split.argtypes = [C.POINTER(DpConvArgs), c_i32, c_i32, VOIDP, C.c_int64, VOIDP]
+    L.dp_tp_conv_node_fused_split.restype = C.c_int
     L.dp_tp_conv_node.restype = C.c_int
     L.dp_conv_w1n_floats.argtypes = [c_i32]
     L.dp_conv_w1n_floats.restype = C.c_int

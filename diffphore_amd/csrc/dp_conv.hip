@@ -29,7 +29,8 @@
 #define DP_ABLATE 0
 #endif
 #ifndef DP_NODE_AUTO_MIN_POSES          // DP_ALGO_AUTO picks the node-side kernel from this batch size on
-#define DP_NODE_AUTO_MIN_POSES 20        // profiles/r2_batch_sweep.csv: with the path split the node-side kernel wins from 20 poses
+#define DP_NODE_AUTO_MIN_POSES 1         // profiles/r3_batch_sweep.csv: with path split + conv split the node-side kernel wins at every batch size
+                                         // (1 pose: 0.86 vs 1.06 ms/step; round 2, before the conv split: from 20 poses on)
 #endif
 #ifdef DP_PROF   // cycle-stamp breakdown of the bf16 kernel (ablation builds only; tools/bench_conv.py --prof)
 __device__ unsigned long long dp_prof[16];

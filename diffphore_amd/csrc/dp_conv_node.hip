@@ -68,6 +68,30 @@ template <int KIND> void pack_w2n(const float* fc3_w, const float* fc3_b, const 
   }
 }
 
+// conv split: out = (previous out | residual stream | 0) + ((part[0] + part[1]) + part[2]) + the convs' BatchNorm shifts, in this fixed order
+struct CombineArgs {
+  const float* part;
+  int n_conv, part_stride, n_nodes, d_out;
+  float* out;
+  int out_stride, accumulate;
+  const float* resid;
+  int resid_stride, resid_width;
+  const float* shift[3];
+};
+__global__ void conv_combine_kernel(CombineArgs c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.n_nodes * c.d_out) return;
+  const int node = i / c.d_out, ch = i - node * c.d_out;
+  float p = c.part[(size_t)node * c.out_stride + ch], sh = c.shift[0][ch];
+  for (int k = 1; k < c.n_conv; ++k) {
+    p += c.part[(size_t)k * c.part_stride + (size_t)node * c.out_stride + ch];
+    sh += c.shift[k][ch];
+  }
+  float* o = c.out + (size_t)node * c.out_stride + ch;
+  const float base = c.accumulate ? *o : ((c.resid != nullptr && ch < c.resid_width) ? c.resid[(size_t)node * c.resid_stride + ch] : 0.f);
+  *o = base + (p + sh);
+}
+
 static int launch_kind(int kind, const FusedArgs& fa, int xmode, hipStream_t st) {
   switch (kind) {
     case 0: return dpn_launch_k0(fa, xmode, st);
@@ -117,7 +141,19 @@ int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0
 // Fused node-side launch: convs[0..n) scatter onto the same node groups and their outputs add up (score_model_phore.py:703-710).
 // Allowed sequences: [LLPAIR][P2L][P2L] (any prefix / suffix of it that is not empty) or [L2P][L2P].  convs[0] names out / resid /
 // accumulate; kind, B, slices, scat_ptr, max_scatter and path_split must agree.
-int dp_tp_conv_node_fused(const DpConvArgs* convs, int32_t n, void* stream) {
+static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream);
+
+int dp_tp_conv_node_fused(const DpConvArgs* convs, int32_t n, void* stream) { return fused_launch(convs, n, 0, nullptr, 0, stream); }
+
+// The same sum with every conv on its OWN workgroups (grid x n) - for launches that cannot fill the chip: a workgroup runs one conv's
+// passes instead of all convs' back to back, the partial outputs meet in `part` and a second, tiny launch adds them up in a fixed order
+// (deterministic; equal to the fused launch to fp32 rounding).  Needs path_split = 1 and scat_ptr[0] == 0; n_nodes = scat_ptr[B].
+int dp_tp_conv_node_fused_split(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream) {
+  if (!convs || n < 2 || n_nodes <= 0 || !part || !convs[0].path_split) return DP_E_BADARG;
+  return fused_launch(convs, n, n_nodes, part, part_floats, stream);
+}
+
+static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream) {
   if (!convs || n < 1 || n > 3) return DP_E_BADARG;
   dpn::FusedArgs fa;
   memset(&fa, 0, sizeof(fa));
@@ -145,7 +181,23 @@ int dp_tp_conv_node_fused(const DpConvArgs* convs, int32_t n, void* stream) {
   for (int i = 0; i < n; ++i)
     if (!convs[i].no_tail) fa.lean = 0;
   if (!convs[0].out) return DP_E_BADARG;
-  return dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
+  if (part == nullptr) return dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
+  fa.conv_split = 1;
+  fa.part = part;
+  fa.part_stride = n_nodes * convs[0].out_stride;
+  fa.node0 = 0;
+  if ((int64_t)fa.part_stride * n > part_floats) return DP_E_TOOLARGE;
+  int rc = dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
+  if (rc) return rc;
+  static const int D_OUT[4] = {50, 80, 100, 100};
+  dpn::CombineArgs c;
+  c.part = part; c.n_conv = n; c.part_stride = fa.part_stride; c.n_nodes = n_nodes; c.d_out = D_OUT[convs[0].kind];
+  c.out = convs[0].out; c.out_stride = convs[0].out_stride; c.accumulate = convs[0].accumulate;
+  c.resid = convs[0].resid; c.resid_stride = convs[0].resid_stride; c.resid_width = convs[0].resid_width;
+  for (int i = 0; i < 3; ++i) c.shift[i] = convs[i < n ? i : 0].bn_shift;
+  const int total = n_nodes * c.d_out;
+  hipLaunchKernelGGL(dpn::conv_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c);
+  return (int)hipGetLastError();
 }
 
 // node-side launch of one layer conv (kinds 0-3); called by dp_tp_conv when DpConvArgs.algo asks for it

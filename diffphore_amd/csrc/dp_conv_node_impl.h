@@ -520,6 +520,13 @@ struct AccStore {
 struct FusedArgs {
   int32_t n_ll, n_x;
   int32_t lean;              // every conv of the launch carries DpConvArgs.no_tail: the instantiation without the half-pass variant
+  // conv split (small batches, with path_split): every conv of the launch gets its OWN workgroups (grid x n convs) and leaves the sum of its
+  // four k-partials in part[conv][node - node0][out_stride] - no shifts, no residual; dp_conv_node_combine adds the convs up in a fixed
+  // order.  One workgroup then runs one conv's passes instead of all convs' back to back: a latency-bound launch gets n x shorter.
+  int32_t conv_split;
+  float* part;
+  int32_t part_stride;       // floats per conv in `part`
+  int32_t node0;             // first scatter node of the launch (scat_ptr[0])
   DpConvArgs conv[3];
 };
 
@@ -533,6 +540,7 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_kernel(FusedArgs fa) {
   if (threadIdx.x == 1023) s_pad[threadIdx.x] = 0.f;
 #endif
   constexpr int SIDE = -1;
+  constexpr int cx_only = -1;
   const int bid = (int)blockIdx.x;
 #include "dp_conv_node_wg.h"
 }
@@ -545,7 +553,10 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_split_kernel(FusedArgs fa
   __shared__ __attribute__((aligned(16))) float s_T[4 * TSTRIDE + TDUMMY];
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];
   __shared__ float s_inv[NB];
-  const int bid = (int)(blockIdx.x >> 1);
+  const int groups = fa.conv[0].B * fa.conv[0].slices;
+  const int bid_all = (int)(blockIdx.x >> 1);
+  const int bid = fa.conv_split ? bid_all % groups : bid_all;
+  const int cx_only = fa.conv_split ? bid_all / groups : -1;          // conv split: the one conv this workgroup computes
   if (blockIdx.x & 1u) {
     constexpr int SIDE = 1;
 #include "dp_conv_node_wg.h"
@@ -559,7 +570,8 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_split_kernel(FusedArgs fa
 template <int KIND, bool HAS_LL, int XMODE> int launch_seq(const FusedArgs& fa, hipStream_t st) {
   const DpConvArgs& a = fa.conv[0];
   if (a.path_split) {
-    hipLaunchKernelGGL((tp_conv_node_split_kernel<KIND, HAS_LL, XMODE, true>), dim3((unsigned)(a.B * a.slices * 2)), dim3(256), 0, st, fa);
+    const int n_conv = fa.conv_split ? fa.n_ll + fa.n_x : 1;
+    hipLaunchKernelGGL((tp_conv_node_split_kernel<KIND, HAS_LL, XMODE, true>), dim3((unsigned)(a.B * a.slices * 2 * n_conv)), dim3(256), 0, st, fa);
   } else if (fa.lean && DP_NODE_HALF_PASS) {
     hipLaunchKernelGGL((tp_conv_node_kernel<KIND, HAS_LL, XMODE, false>), dim3((unsigned)(a.B * a.slices)), dim3(256), 0, st, fa);
   } else {

@@ -707,7 +707,14 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     auto timed_fused = [&](const DpConvArgs* cs, int n, int which_lo, int which_hi, hipStream_t s_) -> int {
       const bool prof = k->prof_start && k->prof_stop && k->prof_layer == l && k->prof_conv >= which_lo && k->prof_conv <= which_hi;
       if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
-      const int r = dp_tp_conv_node_fused(cs, n, s_);
+      // small batches (path split on): one conv per workgroup instead of all convs back to back in one (conv split); the two sides of a
+      // layer may run on two streams, so each has its own half of the scratch
+      const bool lig_side = which_lo < 3;
+      const int n_nodes = lig_side ? b->n_lig : b->n_ph;
+      const int64_t half = DP_CONV_PART_FLOATS / 2;
+      const bool csplit = n >= 2 && cs[0].path_split && k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)n * n_nodes * cs[0].out_stride <= half;
+      const int r = csplit ? dp_tp_conv_node_fused_split(cs, n, n_nodes, k->conv_part + (lig_side ? 0 : half), half, s_)
+                           : dp_tp_conv_node_fused(cs, n, s_);
       if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
       return r;
     };

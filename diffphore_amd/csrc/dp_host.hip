@@ -71,6 +71,7 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   w.t_q = c.take<float>(nt * 40);
   w.status = c.take<int32_t>(B);
   w.z_noise = c.take<float>(B * 6 + nt);
+  w.conv_part = c.take<float>(DP_CONV_PART_FLOATS);
   float* tr_ = c.take<float>(B * 3);
   float* rot_ = c.take<float>(B * 3);
   float* tor_ = c.take<float>(nt);

@@ -65,7 +65,7 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_x6", c_i32), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -540,7 +540,7 @@ class Engine:
         self.L.dp_resolve_conv_algo.argtypes = [c_i32, c_i32, c_i32]
         self.L.dp_resolve_conv_algo.restype = C.c_int
         self.conv_algo = {1: "edge", 2: "node"}[self.L.dp_resolve_conv_algo(CONV_ALGOS[conv_algo], model.struct.precision, pb.B)]
-        self.ws.struct.conv_fuse = {"1": 0, "0": 1, "pairs": 2}[os.environ.get("DIFFPHORE_CONV_FUSE", "1")]
+        self.ws.struct.conv_fuse = {"1": 0, "0": 1, "pairs": 2, "nosplit": 3}[os.environ.get("DIFFPHORE_CONV_FUSE", "1")]
         self.ws.struct.edge_x6 = 1 if os.environ.get("DIFFPHORE_EDGE_X6", "1") == "0" else 0
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         self._handles = None

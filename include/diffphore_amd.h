@@ -31,7 +31,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 7
+#define DP_ABI_VERSION 8
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -156,6 +156,12 @@ int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0
  * out / resid / accumulate; kind, B, slices, scat_ptr, max_scatter and path_split must agree.  One prologue, one reduction of the
  * k-partials, one epilogue and one write of `out` instead of one read-modify-write per conv. */
 int dp_tp_conv_node_fused(const DpConvArgs* convs, int32_t n, void* stream);
+/* The same sum for launches that cannot fill the chip (a single complex's 40 samples): every conv of the sequence runs on its OWN
+ * workgroups (grid x n, with path_split = 1 that is 2 n workgroups per node group), leaves the sum of its k-partials in
+ * part[conv][node][out_stride] (DEVICE scratch, part_floats >= n * n_nodes * out_stride) and a second, tiny launch adds the convs, their
+ * BatchNorm shifts and the residual / previous output up in a fixed order: deterministic, equal to dp_tp_conv_node_fused to fp32
+ * rounding, n x shorter when latency-bound.  Requires convs[0].path_split == 1, scat_ptr[0] == 0, n_nodes == scat_ptr[B], 2 <= n <= 3. */
+int dp_tp_conv_node_fused_split(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream);
 /* what DP_ALGO_AUTO resolves to for a batch of B poses at `precision` (returns DP_ALGO_EDGE or DP_ALGO_NODE) */
 int dp_resolve_conv_algo(int32_t algo, int32_t precision, int32_t B);
 
@@ -282,6 +288,7 @@ typedef struct DpWork {
   int32_t ll_node_max_atoms;        /* the ligand-ligand conv runs node-side (pair-dense) while the batch's largest ligand has at most this many
                                        atoms, edge-side (CSR) beyond; 0 = library default */
   int32_t edge_x6;                  /* 0 = edge-side convs of an fp32 model use DpConvW.w2x (bf16x6) when present (default), 1 = exact fp32 MFMA */
+  float* conv_part;                 /* [DP_CONV_PART_FLOATS] scratch of the conv-split launches of small batches (dp_tp_conv_node_fused_split) */
   float* z_noise;                   /* [6 B + n_tor] scratch of DP_NOISE_SEED: one step's z_tr | z_rot | z_tor */
   int32_t conv_fuse;                /* node-side convs of a layer that scatter onto the same nodes: 0 = one fused launch per side (default),
                                        1 = one launch per conv (A/B runs and tests) */
@@ -370,6 +377,7 @@ typedef struct DpSchedule {
   const int32_t* pose_uid;       /* DEVICE [B] or NULL */
   uint64_t seed;
 } DpSchedule;
+#define DP_CONV_PART_FLOATS (2 * 3 * 4096 * 100)   /* two sides (they may run on two streams) x 3 convs x 256 node groups x 16 nodes x row stride 100 */
 #define DP_NOISE_TABLES 0
 #define DP_NOISE_SEED 1
 #define DP_RNG_STEP_START 0xFFFFFFFFu    /* the `step` word of the start-randomisation draws */

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
             "dp_sample_graph_destroy", "dp_conformer_update", "dp_prepare", "dp_randomize_position", "dp_fit_overlap",
             "dp_pack_conv_weights", "dp_pack_conv_weights_node", "dp_pack_bn", "dp_work_bytes", "dp_work_bind", "dp_work_init",
             "dp_weights_segments", "dp_weights_blob_floats", "dp_weights_bind", "dp_resolve_conv_algo", "dp_abi_version",
-            "dp_struct_sizes", "dp_noise_normals", "dp_randomize_draws", "dp_philox4x32", "dp_forward_launch_of", "dp_tp_conv_node_fused"} <= names
+            "dp_struct_sizes", "dp_noise_normals", "dp_randomize_draws", "dp_philox4x32", "dp_forward_launch_of", "dp_tp_conv_node_fused", "dp_tp_conv_node_fused_split"} <= names
     L = _lib.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in the header but not exported"

@@ -525,6 +525,24 @@ def test_conv_node_fused_pair_equals_the_two_launches(kind, mode):
         assert torch.isfinite(got).all()
         assert (got - want).abs().max().item() / scale < TOL["f32"]
         assert (got - out_seq.cpu().double()).abs().max().item() / scale < 2e-6
+    # conv split (small batches): every conv on its own workgroups + a combine launch - the same sum to fp32 rounding, bit-identical reruns,
+    # residual stream and a previous output (accumulate) both honoured
+    part = torch.full((2 * n_out * dims["d_out"] + 64,), float("nan")).cuda()
+    runs = []
+    for acc_mode in (0, 1):
+        for _rep in range(2):
+            out_s = torch.full((n_out, dims["d_out"]), 0.25).cuda() if acc_mode else torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+            arr = (_lib.DpConvArgs * 2)(args(0, out_s, acc_mode, 1), args(1, out_s, 0, 1))
+            _lib.check(L.dp_tp_conv_node_fused_split(arr, 2, n_out, part.data_ptr(), part.numel(), st), "fused split")
+            torch.cuda.synchronize()
+            runs.append(out_s.cpu())
+        assert torch.equal(runs[-1], runs[-2])
+        want_s = want if not acc_mode else (refs[0] + refs[1] + 0.25)
+        assert (runs[-1].double() - want_s).abs().max().item() / scale < TOL["f32"]
+    arr = (_lib.DpConvArgs * 2)(args(0, out_seq, 0, 0), args(1, out_seq, 0, 0))
+    assert L.dp_tp_conv_node_fused_split(arr, 2, n_out, part.data_ptr(), part.numel(), st) == -1            # needs path_split
+    arr = (_lib.DpConvArgs * 2)(args(0, out_seq, 0, 1), args(1, out_seq, 0, 1))
+    assert L.dp_tp_conv_node_fused_split(arr, 2, n_out, part.data_ptr(), 10, st) == -3                        # scratch too small
     # sequences the kernel has no instantiation for are refused, not mis-run
     bad = (_lib.DpConvArgs * 2)(args(0, out_seq, 0), args(1, out_seq, 0))
     bad[1].mode = _lib.EDGES_L2P if mode == "p2l" else _lib.EDGES_P2L

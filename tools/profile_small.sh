@@ -5,7 +5,7 @@ P=${1:-40}
 cd "$(dirname "$0")/.." || exit 1
 export PYTHONPATH=. TMPDIR=/tmp
 mkdir -p gpurun_out; rm -rf /tmp/prof_small; mkdir -p /tmp/prof_small
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_small/trace -o t -- python $OLDPWD/bench.py --poses $P --steps 40 --warmup 5 --no-alt --no-e2e --no-cpu-baseline > /tmp/prof_small/trace.out 2>&1 < /dev/null)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_small/trace -o t -- python $OLDPWD/bench.py --poses $P --steps 40 --warmup 5 --no-alt --no-e2e --no-cpu-baseline --no-other ${CFG:+--config $CFG} > /tmp/prof_small/trace.out 2>&1 < /dev/null)
 T=$(find /tmp/prof_small/trace -name '*.db' | head -1)
 [ -n "$T" ] || { echo "no trace db"; tail -5 /tmp/prof_small/trace.out; exit 1; }
 python tools/summarize_prof.py gpurun_out/small${P} "$T" < /dev/null
