@@ -59,7 +59,8 @@ typedef int NProfT;
 #endif
 
 #ifndef DP_NABL    // ablation builds (tools/ablate_node.sh): 1 no sh factors / z arithmetic, 2 no T transpose through LDS, 3 no GEMM-B MFMAs,
-#define DP_NABL 0  // 4 no GEMM-B at all, 5 no GEMM-A MFMAs, 6 no GEMM1 MFMAs.  Results are wrong by construction; timing only.
+#define DP_NABL 0  // 4 no GEMM-B at all, 5 no GEMM-A MFMAs, 6 no GEMM1 MFMAs, 8 GEMM-B emulated on the bf16 pipe (consumer-side operand split +
+                   // 16x16x32 bf16 MFMAs: profiles/r3_experiments.md).  Results are wrong by construction; timing only.
 #endif
 #ifndef DP_NODE_PF
 #define DP_NODE_PF 4          // GEMM1: steps the edge operands are requested ahead
@@ -464,6 +465,38 @@ struct PathStage {
               if (ut + 1 < pc.mul_in / NU) load_x<KIND, MODE, HALF, P>(a, r, et, lane_l, ut + 1, xr);
               else load_x<KIND, MODE, HALF, PN>(a, r, et, lane_l, 0, xr);
             }
+#if DP_NABL == 8
+            // TIMING EMULATION of GEMM-B on the bf16 pipe (results are wrong by construction): the step's four T values are split into three
+            // bf16 parts each on the VALU (truncate, exact residual, truncate, exact residual, pack: what a consumer-side split costs), and the
+            // step issues 3 MT 16x16x32 bf16 MFMAs (6 MT per two in-channels) instead of 4 MT fp32 ones
+            {
+              typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) {
+                const unsigned b0 = __builtin_bit_cast(unsigned, tv[rr]) & 0xFFFF0000u;
+                const float r1 = tv[rr] - __builtin_bit_cast(float, b0);
+                const unsigned b1 = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+                const float r2 = r1 - __builtin_bit_cast(float, b1);
+                hb[rr] = b0; mb[rr] = b1; lb[rr] = __builtin_bit_cast(unsigned, r2);
+              }
+              const unsigned h01 = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), h23 = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+              const unsigned m01 = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), m23 = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+              const unsigned l01 = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), l23 = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+              const bf16x8_t B0 = __builtin_bit_cast(bf16x8_t, (u32x4){h01, h23, m01, m23});
+              const bf16x8_t B1 = __builtin_bit_cast(bf16x8_t, (u32x4){m01, m23, l01, l23});
+              const bf16x8_t B2 = __builtin_bit_cast(bf16x8_t, (u32x4){h01, h23, l01, l23});
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8_t A = __builtin_bit_cast(bf16x8_t, wf[mt]);
+                f32x4& d = acc[AB + grp * MT + mt];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B0, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B1, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B2, d, 0, 0, 0);
+              }
+            }
+#else
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -474,6 +507,7 @@ struct PathStage {
                 acc[AB + grp * MT + mt] = mfma16(wf[mt][rr], tv[rr], acc[AB + grp * MT + mt]);
 #endif
               }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             tv = tn;
             if (grp == NG - 1) {
