@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Kernel metadata (VGPR count, spilled registers, private segment, LDS) of the gfx950 code objects embedded in a hipcc host object:
+
+    python tools/kernel_meta.py diffphore_amd/csrc/dp_conv_node_k2.o
+
+Finds the ELF images inside the object's .hip_fatbin section and prints `llvm-readelf --notes` fields per kernel (DESIGN.md 5.3 quotes them)."""
 import re, subprocess, sys
 # find embedded ELF code objects inside the host object's .hip_fatbin section and print kernel metadata
 data = open(sys.argv[1], "rb").read()
