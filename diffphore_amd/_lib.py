@@ -13,12 +13,13 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 8
+DP_ABI_VERSION = 9
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
 PREC_BF16X9 = 4
-PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16x9": PREC_BF16X9}
+PREC_BF16 = 5          # plain bf16 operands, fp32 accumulate: node-side dp_conv_node_bf16_impl.h, edge-side the one-product split-bf16 kernel
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16x9": PREC_BF16X9, "bf16": PREC_BF16}
 EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER, EDGES_LLPAIR = range(5)
 ALGO_AUTO, ALGO_EDGE, ALGO_NODE = range(3)
 
@@ -36,8 +37,12 @@ class DpConvArgs(C.Structure):
         ("out", VOIDP), ("out_stride", c_i32), ("accumulate", c_i32),
         ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32), ("phase_split", c_i32),
         ("w1n", VOIDP), ("w2n", VOIDP), ("algo", c_i32), ("path_split", c_i32),
-        ("pair_a", VOIDP), ("pair_b", VOIDP), ("pair_ptr", VOIDP), ("no_tail", c_i32),
+        ("pair_a", VOIDP), ("pair_b", VOIDP), ("pair_ptr", VOIDP), ("edge_emb_bf", VOIDP), ("emb_flag_row", c_i32), ("no_tail", c_i32),
     ]
+
+
+class DpBuildInfo(C.Structure):
+    _fields_ = [("abi_version", c_i32), ("nabl", c_i32), ("ablate", c_i32), ("prof", c_i32), ("source_hash", C.c_char * 20)]
 
 
 class DiffPhoreLibraryError(RuntimeError):
@@ -60,8 +65,22 @@ def lib():
         if L.dp_abi_version() != DP_ABI_VERSION:
             raise DiffPhoreLibraryError(f"ABI mismatch: library {L.dp_abi_version()} != binding {DP_ABI_VERSION}")
         _declare(L)
+        info = DpBuildInfo()
+        if L.dp_build_info(C.byref(info)) != 0:
+            raise DiffPhoreLibraryError("dp_build_info failed")
+        if (info.nabl or info.ablate) and os.environ.get("DIFFPHORE_ALLOW_ABLATION") != "1":
+            # -DDP_NABL / -DDP_ABLATE builds replace parts of the kernels by stand-ins to TIME the rest: their numbers are wrong by design
+            raise DiffPhoreLibraryError(f"{LIB_PATH} is an ablation build (DP_NABL={info.nabl}, DP_ABLATE={info.ablate}): it computes wrong results "
+                                        "by construction; set DIFFPHORE_ALLOW_ABLATION=1 to load it for timing")
         _lib = L
     return _lib
+
+
+def build_info() -> dict:
+    """What the loaded library was built from: ABI version, ablation / profiling switches, hash of the kernel sources."""
+    info = DpBuildInfo()
+    check(lib().dp_build_info(C.byref(info)), "dp_build_info")
+    return dict(abi_version=info.abi_version, nabl=info.nabl, ablate=info.ablate, prof=info.prof, source_hash=info.source_hash.decode())
 
 
 def _declare(L):
@@ -88,6 +107,16 @@ def _declare(L):
     L.dp_pack_conv_weights_node.argtypes = [c_i32] + [VOIDP] * 7
     L.dp_pack_conv_weights_node.restype = C.c_int
     L.dp_conv_node_max_nodes.restype = C.c_int
+    L.dp_conv_w1b_floats.argtypes = [c_i32]
+    L.dp_conv_w1b_floats.restype = C.c_int
+    L.dp_conv_w2b_floats.argtypes = [c_i32]
+    L.dp_conv_w2b_floats.restype = C.c_int
+    L.dp_pack_conv_weights_node_bf16.argtypes = [c_i32] + [VOIDP] * 7
+    L.dp_pack_conv_weights_node_bf16.restype = C.c_int
+    L.dp_edge_emb_bf16.argtypes = [VOIDP, c_i32, VOIDP, VOIDP]
+    L.dp_edge_emb_bf16.restype = C.c_int
+    L.dp_build_info.argtypes = [C.POINTER(DpBuildInfo)]
+    L.dp_build_info.restype = C.c_int
 
 
 def check(rc: int, what: str):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Build libdiffphore_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  In-tree output so it ships with gpurun."""
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -11,8 +12,22 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h), first 16 hex digits: compiled into the library (dp_build_info) and
+    used to key committed PMC profiles to the sources they were measured on."""
+    h = hashlib.sha256()
+    root = os.path.normpath(os.path.join(HERE, "..", ".."))
+    for f in sorted(glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(root, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(objs_src):
     if not os.path.exists(OUT):
+        return True
+    stamp = os.path.join(HERE, "dp_host.o.hash")
+    if not os.path.exists(stamp) or open(stamp).read().strip() != source_hash():
         return True
     t = os.path.getmtime(OUT)
     deps = objs_src + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h"))
@@ -40,11 +55,15 @@ def build(force=False, verbose=True):
         return OUT
     objs = []
     procs = []
+    shash = source_hash()
+    stamp = os.path.join(HERE, "dp_host.o.hash")          # dp_host.o carries the source hash (dp_build_info): rebuilt whenever it changes
+    host_stale = not os.path.exists(stamp) or open(stamp).read().strip() != shash
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(d) for d in _deps(s)):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        is_host = os.path.basename(s) == "dp_host.hip"
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(d) for d in _deps(s)) or (is_host and host_stale):
+            cmd = [HIPCC] + FLAGS + ([f'-DDP_SOURCE_HASH="{shash}"'] if is_host else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))
@@ -55,6 +74,7 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    open(stamp, "w").write(shash + "\n")
     return OUT
 
 

@@ -745,11 +745,24 @@ __device__ __forceinline__ void lds_read_q(bf16x8& dst, unsigned addr, int off) 
 }
 template <int N> __device__ __forceinline__ void lds_landed(bf16x8& w) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(N)); }
 
+template <int NS> constexpr int WREGS = NS == 1 ? 2 : NS;      // operand registers of the pipe (NS = 1: two, so that one read stays in flight)
 template <int KIND, int NS, int B, bool FULL = false>      // FULL (NS == 3 only): all 9 cross products = exact fp32 products
 struct OperandPipe {
-  static __device__ __forceinline__ void run(unsigned la, bf16x8 (&W)[NS], const HidB<KIND, NS>& hb, f32x16& D) {
+  static __device__ __forceinline__ void run(unsigned la, bf16x8 (&W)[WREGS<NS>], const HidB<KIND, NS>& hb, f32x16& D) {
     constexpr int NB = NKB<KIND>;
-    if constexpr (B < NB) {
+    if constexpr (NS == 1) {
+      // DP_PREC_BF16: plain bf16 operands, one product per K block; blocks alternate between two registers, one read ahead
+      if constexpr (B < NB) {
+        if constexpr (B == 0) {
+          lds_read_q(W[0], la, 0);
+          if constexpr (NB > 1) lds_read_q(W[1], la, 1024);
+        }
+        lds_landed<(B + 1 < NB) ? 1 : 0>(W[B & 1]);
+        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[B & 1], hb.v[B][0], D, 0, 0, 0);
+        if constexpr (B + 2 < NB) lds_read_q(W[B & 1], la, (B + 2) * 1024);
+        OperandPipe<KIND, NS, B + 1, FULL>::run(la, W, hb, D);
+      }
+    } else if constexpr (B < NB) {
       constexpr bool more = B + 1 < NB;
       if constexpr (B == 0) {
 #pragma unroll
@@ -856,7 +869,7 @@ struct StageB {
         // A-operand fetches as raw ds_read_b128 + hand-counted lgkmcnt.  With ordinary LDS loads the compiler cannot prove that
         // they do not alias the LDS-DMA destinations and puts an s_waitcnt vmcnt(0) in front of the first read of every tile,
         // i.e. a full L2 round trip for the tile that was JUST requested (measured: 0.88 -> see profiles/r1_conv_ablation.md).
-        bf16x8 W[NS];
+        bf16x8 W[WREGS<NS>];
         const unsigned la = lds_w + (TILE % R) * NQ * 16;
         OperandPipe<KIND, NS, 0, FULL>::run(la, W, hb, D);
       }
@@ -952,6 +965,7 @@ template <int KIND> int launch(const DpConvArgs& a_in, hipStream_t st) {
   else if (a.precision == DP_PREC_BF16X6) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 3>), grid, dim3(WAVES_B * 64), 0, st, a);
   else if (a.precision == DP_PREC_BF16X3) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2>), grid, dim3(WAVES_B * 64), 0, st, a);
   else if (a.precision == DP_PREC_BF16X9) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 3, true>), grid, dim3(WAVES_B * 64), 0, st, a);
+  else if (a.precision == DP_PREC_BF16) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 1>), grid, dim3(WAVES_B * 64), 0, st, a);
   else return DP_E_BADARG;
   return (int)hipGetLastError();
 }
@@ -960,6 +974,7 @@ template <int KIND> int w2p_floats(int prec) {
   if (prec == DP_PREC_F32) return Geo<KIND>::W2P_FLOATS;
   if (prec == DP_PREC_BF16X6 || prec == DP_PREC_BF16X9) return Geo<KIND>::NT * TILE_QUADS<KIND, 3> * 4;
   if (prec == DP_PREC_BF16X3) return Geo<KIND>::NT * TILE_QUADS<KIND, 2> * 4;
+  if (prec == DP_PREC_BF16) return Geo<KIND>::NT * TILE_QUADS<KIND, 1> * 4;
   return DP_E_BADARG;
 }
 
@@ -1007,13 +1022,15 @@ int dp_conv_w2p_floats(int32_t kind, int32_t precision) {
 int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, const float* fc0_b, const float* fc3_w,
                          const float* fc3_b, float* w1p, float* w2p) {
   if (!fc0_w || !fc0_b || !fc3_w || !fc3_b || !w1p || !w2p) return DP_E_BADARG;
-  if (precision != DP_PREC_F32 && precision != DP_PREC_BF16X6 && precision != DP_PREC_BF16X3 && precision != DP_PREC_BF16X9) return DP_E_BADARG;
+  if (precision != DP_PREC_F32 && precision != DP_PREC_BF16X6 && precision != DP_PREC_BF16X3 && precision != DP_PREC_BF16X9 && precision != DP_PREC_BF16)
+    return DP_E_BADARG;
   switch (kind) {
 #define DP_CASE(K)                                                                                            \
   case K:                                                                                                     \
     dp::pack_w1<K>(fc0_w, fc0_b, w1p);                                                                        \
     if (precision == DP_PREC_F32) dp::pack_w2<K>(fc3_w, fc3_b, w2p);                                          \
     else if (precision == DP_PREC_BF16X6 || precision == DP_PREC_BF16X9) dp::pack_w2_bf16<K, 3>(fc3_w, fc3_b, (unsigned short*)w2p);         \
+    else if (precision == DP_PREC_BF16) dp::pack_w2_bf16<K, 1>(fc3_w, fc3_b, (unsigned short*)w2p);           \
     else dp::pack_w2_bf16<K, 2>(fc3_w, fc3_b, (unsigned short*)w2p);                                          \
     return DP_OK;
     DP_CASE(0) DP_CASE(1) DP_CASE(2) DP_CASE(3) DP_CASE(4) DP_CASE(5)
@@ -1023,11 +1040,12 @@ int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, co
 }
 
 int dp_resolve_conv_algo(int32_t algo, int32_t precision, int32_t B) {
-  // node-side: fp32 only; it needs >= ~256 workgroups of 16 nodes to fill the chip (small batches keep the edge-side kernel with
-  // its per-pose slicing and phase split)
-  if (algo == DP_ALGO_NODE) return precision == DP_PREC_F32 ? DP_ALGO_NODE : DP_ALGO_EDGE;
+  // node-side: exact fp32 (dp_conv_node_impl.h) or plain bf16 operands (dp_conv_node_bf16_impl.h); the split-bf16 precisions exist
+  // edge-side only
+  const bool has_node = precision == DP_PREC_F32 || precision == DP_PREC_BF16;
+  if (algo == DP_ALGO_NODE) return has_node ? DP_ALGO_NODE : DP_ALGO_EDGE;
   if (algo == DP_ALGO_EDGE) return DP_ALGO_EDGE;
-  return (precision == DP_PREC_F32 && B >= DP_NODE_AUTO_MIN_POSES) ? DP_ALGO_NODE : DP_ALGO_EDGE;
+  return (has_node && B >= DP_NODE_AUTO_MIN_POSES) ? DP_ALGO_NODE : DP_ALGO_EDGE;
 }
 
 int dp_tp_conv(const DpConvArgs* a, void* stream) {

@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#include "dp_conv_node_impl.h"
+#include "dp_conv_node_bf16_impl.h"
 
 #ifdef DP_PROF
 __device__ unsigned long long dpn_prof[16];
@@ -68,6 +68,82 @@ template <int KIND> void pack_w2n(const float* fc3_w, const float* fc3_b, const 
   }
 }
 
+// ---- DP_PREC_BF16 (dp_conv_node_bf16_impl.h): bf16 MFMA fragments ------------------------------------------------------------------
+static inline unsigned short bf16_rne(float x) {
+  unsigned int u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+// three B-operand images of the first layer per wave q: lane (k = 16 q + lane % 16, group g) holds features 8g..8g+7 of
+//   image 0: the edge-embedding block (fc.0 columns 0..19); feature 20 = -1e30: the row of the "edge does not exist" flag
+//   image 1 / 2: the attr1 / attr2 block (columns 20..39 / 40..59); feature 20 = fc.0's bias (1.0 for the constant-one unit 60 that carries
+//   fc.3's bias): only the SCATTER node's tile feeds a 1 there, so the bias enters once
+template <int KIND> void pack_w1b(const float* fc0_w, const float* fc0_b, unsigned short* w1b) {
+  using S = Spec<KIND>;
+  static_assert(S::HID == HIDN && S::N_ATTR == 60, "node-side kernel: layer convs only");
+  for (int img = 0; img < 3; ++img)
+    for (int q = 0; q < 4; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int g = lane >> 4, k = 16 * q + (lane & 15), f = 8 * g + j;
+          float v = 0.f;
+          if (f < 20) v = k < HIDN ? fc0_w[k * 60 + 20 * img + f] : 0.f;
+          else if (f == dpb::EMB_FLAG) v = img == 0 ? -1e30f : (k < HIDN ? fc0_b[k] : (k == HIDN ? 1.f : 0.f));
+          w1b[(((size_t)img * 4 + q) * 64 + lane) * 8 + j] = bf16_rne(v);
+        }
+}
+// second layer as GEMM-B A fragments [path][supertile][K chunk][M tile][wave q][lane][8]: lane (w = 16 mt + lane % 16, group g) holds
+// W2[(u, w)][k = 16 q + 4 g + (j & 3)] for the chunk's two in-channels u = 10 st + 2 ch + (j >> 2); path coefficient, CG norm and the
+// BatchNorm scale folded in as in pack_w2n, then rounded to bf16 once
+template <int KIND> void pack_w2b(const float* fc3_w, const float* fc3_b, const float* bn_scale, unsigned short* w2b) {
+  using S = Spec<KIND>;
+  for (int p = 0; p < S::NPATH; ++p) {
+    const PathC& pc = S::P[p];
+    const int dout = d_out_of(pc.ztype);
+    const double scale = __builtin_sqrt((double)(2 * (dout == 3 ? 1 : 0) + 1) / (double)pc.fan_in) * cg_const(pc.ztype);
+    const int MT = path_mt<KIND>(p);
+    for (int st = 0; st < dpb::st_count<KIND>(p); ++st)
+      for (int ch = 0; ch < dpb::SUPER_CH; ++ch)
+        for (int mt = 0; mt < MT; ++mt)
+          for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+              unsigned short* dst = w2b + ((size_t)dpb::w2b_path_off<KIND>(p) + (size_t)((st * dpb::SUPER_CH + ch) * MT + mt) * 256 + q * 64 + lane) * 8;
+              for (int j = 0; j < 8; ++j) {
+                const int g = lane >> 4, w = 16 * mt + (lane & 15);
+                const int u = dpb::SUPER_NU * st + 2 * ch + (j >> 2), k = 16 * q + 4 * g + (j & 3);
+                float v = 0.f;
+                if (w < pc.mul_out && k <= HIDN) {
+                  const int widx = pc.w_off + u * pc.mul_out + w;
+                  const double bn = bn_scale ? (double)bn_scale[pc.out_off + w * dout] : 1.0;
+                  v = (float)(scale * bn * (double)(k < HIDN ? fc3_w[widx * HIDN + k] : fc3_b[widx]));
+                }
+                dst[j] = bf16_rne(v);
+              }
+            }
+  }
+}
+
+// emb [n, 20] fp32 -> [n + 1, 32] bf16 rows (RNE) + the flag row; one thread per 8 features
+__global__ void edge_emb_bf16_kernel(const float* __restrict__ emb, int n_rows, uint16_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (n_rows + 1) * 4) return;
+  const int row = i >> 2, g = i & 3;
+  dpb::u32x4 v = {0u, 0u, 0u, 0u};
+  if (row < n_rows) {
+    if (g < 2) {
+      const float* p = emb + (size_t)row * 20 + 8 * g;
+      v = dpb::u32x4{dpb::pk2(p[0], p[1]), dpb::pk2(p[2], p[3]), dpb::pk2(p[4], p[5]), dpb::pk2(p[6], p[7])};
+    } else if (g == 2) {
+      const float* p = emb + (size_t)row * 20 + 16;
+      v = dpb::u32x4{dpb::pk2(p[0], p[1]), dpb::pk2(p[2], p[3]), 0u, 0u};
+    }
+  } else if (g == 2) {
+    v[2] = 0x3F80u;                                 // feature 20 = 1.0
+  }
+  *reinterpret_cast<dpb::u32x4*>(out + (size_t)row * dpb::EMB_ROW + 8 * g) = v;
+}
+
 // conv split: out = (previous out | residual stream | 0) + ((part[0] + part[1]) + part[2]) + the convs' BatchNorm shifts, in this fixed order
 struct CombineArgs {
   const float* part;
@@ -92,7 +168,17 @@ __global__ void conv_combine_kernel(CombineArgs c) {
   *o = base + (p + sh);
 }
 
+static int launch_kind_bf16(int kind, const FusedArgs& fa, int xmode, hipStream_t st) {
+  switch (kind) {
+    case 0: return dpb_launch_k0(fa, xmode, st);
+    case 1: return dpb_launch_k1(fa, xmode, st);
+    case 2: return dpb_launch_k2(fa, xmode, st);
+    default: return dpb_launch_k3(fa, xmode, st);
+  }
+}
+
 static int launch_kind(int kind, const FusedArgs& fa, int xmode, hipStream_t st) {
+  if (fa.conv[0].precision == DP_PREC_BF16) return launch_kind_bf16(kind, fa, xmode, st);
   switch (kind) {
     case 0: return dpn_launch_k0(fa, xmode, st);
     case 1: return dpn_launch_k1(fa, xmode, st);
@@ -108,6 +194,8 @@ static int check_conv(const DpConvArgs* a) {
   if (a->mode != DP_EDGES_P2L && a->mode != DP_EDGES_L2P && a->mode != DP_EDGES_LLPAIR) return DP_E_UNSUPPORTED;
   if (a->mode == DP_EDGES_LLPAIR ? (!a->pair_a || !a->pair_b || !a->pair_ptr || !a->rowptr || !a->rowend) : (!a->ph_ptr || !a->x_ptr)) return DP_E_BADARG;
   if (a->kind < 0 || a->kind > 3 || a->sh_stride < 9) return DP_E_UNSUPPORTED;
+  if (a->precision != DP_PREC_F32 && a->precision != DP_PREC_BF16) return DP_E_UNSUPPORTED;
+  if (a->precision == DP_PREC_BF16 && (!a->edge_emb_bf || a->emb_flag_row < 0)) return DP_E_BADARG;
   if (a->max_scatter <= 0) return DP_E_BADARG;
   if ((a->max_scatter + a->slices - 1) / a->slices > NB) return DP_E_TOOLARGE;
   return DP_OK;
@@ -125,6 +213,31 @@ int dp_conv_w2n_floats(int32_t kind) {
     case 2: return dpn::w2n_floats<2>(); case 3: return dpn::w2n_floats<3>();
     default: return DP_E_BADARG;
   }
+}
+
+int dp_conv_w1b_floats(int32_t kind) { return kind >= 0 && kind <= 3 ? dpb::W1B_QUADS * 4 : DP_E_BADARG; }
+int dp_conv_w2b_floats(int32_t kind) {
+  switch (kind) {
+    case 0: return dpb::w2b_quads<0>() * 4; case 1: return dpb::w2b_quads<1>() * 4;
+    case 2: return dpb::w2b_quads<2>() * 4; case 3: return dpb::w2b_quads<3>() * 4;
+    default: return DP_E_BADARG;
+  }
+}
+int dp_pack_conv_weights_node_bf16(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
+                                   const float* bn_scale, float* w1b, float* w2b) {
+  if (!fc0_w || !fc0_b || !fc3_w || !fc3_b || !w1b || !w2b) return DP_E_BADARG;
+  switch (kind) {
+#define DP_CASE(K) case K: dpn::pack_w1b<K>(fc0_w, fc0_b, (unsigned short*)w1b); dpn::pack_w2b<K>(fc3_w, fc3_b, bn_scale, (unsigned short*)w2b); return DP_OK;
+    DP_CASE(0) DP_CASE(1) DP_CASE(2) DP_CASE(3)
+#undef DP_CASE
+    default: return DP_E_UNSUPPORTED;
+  }
+}
+int dp_edge_emb_bf16(const float* emb, int32_t n_rows, uint16_t* out, void* stream) {
+  if (!emb || !out || n_rows < 0) return DP_E_BADARG;
+  const int total = (n_rows + 1) * 4;
+  hipLaunchKernelGGL(dpn::edge_emb_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, emb, n_rows, out);
+  return (int)hipGetLastError();
 }
 
 int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
@@ -163,7 +276,7 @@ static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, flo
     const int rc = dpn::check_conv(a);
     if (rc) return rc;
     if (a->kind != convs[0].kind || a->B != convs[0].B || a->slices != convs[0].slices || a->scat_ptr != convs[0].scat_ptr ||
-        a->max_scatter != convs[0].max_scatter || a->path_split != convs[0].path_split)
+        a->max_scatter != convs[0].max_scatter || a->path_split != convs[0].path_split || a->precision != convs[0].precision)
       return DP_E_BADARG;
     if (a->mode == DP_EDGES_LLPAIR) {
       if (i != 0) return DP_E_UNSUPPORTED;
@@ -181,6 +294,10 @@ static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, flo
   for (int i = 0; i < n; ++i)
     if (!convs[i].no_tail) fa.lean = 0;
   if (!convs[0].out) return DP_E_BADARG;
+  if (convs[0].precision == DP_PREC_BF16) {        // one instantiation: unsplit, with the half-pass variant
+    for (int i = 0; i < n; ++i) fa.conv[i].path_split = 0;
+    return dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
+  }
   if (part == nullptr) return dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
   fa.conv_split = 1;
   fa.part = part;

@@ -136,6 +136,21 @@ __global__ void static_pp_kernel(DpBatch b, DpWeights w, DpWork k) {
   store_row<NS>(k.pp_pre + (size_t)e * NS, pre);
 }
 
+// bf16 image of an embedded edge row for the DP_PREC_BF16 node-side conv (DpConvArgs.edge_emb_bf): 32 bf16 = features 0..19 | zeros; RNE
+__device__ __forceinline__ void store_row_bf16(uint16_t* __restrict__ dst, const float* v) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) d[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, bf2));
+#pragma unroll
+  for (int i = 10; i < 16; ++i) d[i] = 0u;
+}
+// the flag row ("this edge does not exist": feature 20 = 1.0) behind the table's last row
+__device__ __forceinline__ void store_flag_row_bf16(uint16_t* __restrict__ tab, int n_rows, int tid) {
+  if (tid < 32) tab[(size_t)n_rows * 32 + tid] = tid == 20 ? (uint16_t)0x3F80 : (uint16_t)0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // ligand graph per pose: radius graph (torch_cluster CUDA semantics) + bond edges, CSR by scatter node, edge embedding, SH
 //   build_lig_conv_graph :715-739 ; lig_edge_embedding :657
@@ -154,6 +169,7 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
   for (int i = tid; i < N * words; i += 256) s_adj[i] = 0u;
   const int pr0 = b.llp_ptr ? b.llp_ptr[p] : 0;
   const bool pairs = b.llp_ptr != nullptr && k.ll_pair_rad != nullptr && k.ll_pair_bond != nullptr;
+  if (k.ll_emb_bf && p == 0) store_flag_row_bf16(k.ll_emb_bf, b.ll_cap, tid);
   if (pairs)
     for (int i = tid; i < N * N; i += 256) { k.ll_pair_rad[pr0 + i] = -1; k.ll_pair_bond[pr0 + i] = -1; }
   if (tid < NS) {   // layer-0 bias + sigma-embedding part of the edge MLP (same for every edge of the pose)
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
     matvec_acc<NS, NS>(w.lig_edge.w0, 44, 24, g, h);
     mlp_tail20(w.lig_edge, h, out);
     store_row<NS>(k.ll_emb + (size_t)o * NS, out);
+    if (k.ll_emb_bf) store_row_bf16(k.ll_emb_bf + (size_t)o * 32, out);
   }
   if (pairs) {
     // every edge must own its table entry: a ligand graph that lists the same ordered bond twice would lose one here -> flag the pose
@@ -306,6 +323,7 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
   const int p = blockIdx.x, tid = threadIdx.x;
   const int l0 = b.lig_ptr[p], NL = b.lig_ptr[p + 1] - l0, p0 = b.ph_ptr[p], NP = b.ph_ptr[p + 1] - p0;
   const int x0 = b.x_ptr[p], E = NL * NP;
+  if (k.x_emb_bf && p == 0) store_flag_row_bf16(k.x_emb_bf, b.n_x, tid);
   if (tid < NS) {
     const float* se = k.tparams + (size_t)p * TP_STRIDE;
     float a = 0.f;
@@ -359,6 +377,7 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
       matvec_acc<NS, NS>(w.x_edge.w0, 73, 20, g, h);
       mlp_tail20(w.x_edge, h, out);
       store_row<NS>(k.x_emb + (size_t)(x0 + e) * NS, out);
+      if (k.x_emb_bf) store_row_bf16(k.x_emb_bf + (size_t)(x0 + e) * 32, out);
     }
     // sign rule (:813-816) and softmax weight (:839,:845-848)
     {
@@ -650,26 +669,33 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   // the three graph / embedding kernels only share their inputs (positions, time parameters): the ligand radius graph runs on the second
   // stream beside the node embeddings and the cross edges (each is one workgroup per pose and latency-bound on its own)
   if (aux) fork();
+  // the bf16 images of the edge embeddings are written only for the convs that read them (DP_PREC_BF16, node-side)
+  const bool bf_node = node_side && w->precision == DP_PREC_BF16;
+  if (bf_node && (!k->x_emb_bf || (node_ll && !k->ll_emb_bf))) return DP_E_BADARG;
+  DpWork kx = *k;
+  if (!bf_node) kx.x_emb_bf = kx.ll_emb_bf = nullptr;
+  if (!node_ll) kx.ll_emb_bf = nullptr;
   {
     // the N x N pair tables are filled (and verified: status bit 1) only when the node-side ligand-ligand conv will read them
-    DpWork kg = *k;
+    DpWork kg = kx;
     if (!node_ll) kg.ll_pair_rad = kg.ll_pair_bond = nullptr;
     hipLaunchKernelGGL(dp::lig_graph_kernel, dim3(B), dim3(256), 0, aux ? aux : st, *b, *w, kg);
   }
   hipLaunchKernelGGL(dp::node_embed_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
-  hipLaunchKernelGGL(dp::cross_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  hipLaunchKernelGGL(dp::cross_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, kx);
   if (aux) join();
   // workgroups per pose: keep <= 48 scatter nodes per workgroup and >= ~2 workgroups per CU in flight
+  const int prec_edge = w->precision;        // (DP_PREC_BF16: the convs that stay edge-side run the one-product form of the split-bf16 kernel)
   int slices = 1;
   {
     const int mx = b->max_nl > b->max_np ? b->max_nl : b->max_np;
-    while ((mx + slices - 1) / slices > dp_conv_max_nodes(w->precision)) ++slices;
+    while ((mx + slices - 1) / slices > dp_conv_max_nodes(prec_edge)) ++slices;
     while (B * slices < 512 && slices < 8) ++slices;
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
   // the convs that stay edge-side in an fp32 model (phore-phore, torsion bonds) take the bf16x6 form of their radial contraction when the
   // blob carries it (DpConvW.w2x): same tolerances, 16x the matrix rate per product
-  const bool edge_x6 = w->precision == DP_PREC_F32 && k->edge_x6 != 1;
+  const bool edge_x6 = w->precision == DP_PREC_F32 && k->edge_bf16x6 != 0;
   int slices_x6 = 1;
   {
     const int mx = b->max_nl > b->max_np ? b->max_nl : b->max_np;
@@ -696,7 +722,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     DpConvArgs a;
     // ligand side: lig_conv (+ residual stream), phore_to_lig, phore_to_lig_norm      (:678-689, :703-706)
     memset(&a, 0, sizeof(a));
-    a.kind = l; a.B = B; a.slices = slices; a.precision = w->precision; a.lig_ptr = b->lig_ptr; a.ph_ptr = b->ph_ptr; a.x_ptr = b->x_ptr;
+    a.kind = l; a.B = B; a.slices = slices; a.precision = prec_edge; a.lig_ptr = b->lig_ptr; a.ph_ptr = b->ph_ptr; a.x_ptr = b->x_ptr;
     a.phase_split = (B * slices < 512) ? 1 : 0;      // under-filled chip: one workgroup per accumulation phase (see DpConvArgs)
     a.sh_stride = 9; a.out_stride = 100; a.resid_stride = 100;
     a.gather_stride = a.attr1_stride = a.attr2_stride = 100;
@@ -729,6 +755,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       if (!node_ll && edge_x6 && w->lig_conv[l].w2x) { c.precision = DP_PREC_BF16X6; c.w2p = w->lig_conv[l].w2x; c.slices = slices_x6; c.phase_split = 0; }
       if (node_ll) {
         c.algo = DP_ALGO_NODE; c.mode = DP_EDGES_LLPAIR; c.w1n = w->lig_conv[l].w1n; c.w2n = w->lig_conv[l].w2n; c.slices = slices_pl; c.phase_split = 0;
+        c.precision = w->precision; c.edge_emb_bf = k->ll_emb_bf; c.emb_flag_row = b->ll_cap;
         c.no_tail = b->no_tail_nl;
         c.path_split = node_path_split(B, slices_pl);
         c.pair_a = k->ll_pair_rad; c.pair_b = k->ll_pair_bond; c.pair_ptr = b->llp_ptr;
@@ -742,7 +769,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
-      if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); c.no_tail = b->no_tail_np; }
+      if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); c.no_tail = b->no_tail_np;
+                       c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x; }
     }
     if (node_side && fuse && node_ll && k->conv_fuse != 2) {
       // one launch: the three convs scatter onto the same atoms and their outputs add up (:703-706)
@@ -776,7 +804,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_emb = k->x_emb; c.edge_sh = nv ? k->x_nsh : k->x_sh;
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
-        if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); c.no_tail = b->no_tail_nl; }
+        if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); c.no_tail = b->no_tail_nl;
+                         c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x; }
       }
       if (node_side && fuse) {
         if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);
@@ -796,7 +825,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   {
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
-    c.kind = DP_CONV_FINAL; c.mode = DP_EDGES_CENTER; c.B = B; c.slices = 1; c.precision = w->precision; c.max_scatter = 1; c.scat_ptr = b->pose_ptr; c.lig_ptr = b->lig_ptr;
+    c.kind = DP_CONV_FINAL; c.mode = DP_EDGES_CENTER; c.B = B; c.slices = 1; c.precision = prec_edge; c.max_scatter = 1; c.scat_ptr = b->pose_ptr; c.lig_ptr = b->lig_ptr;
     c.gather_tab = hl; c.gather_stride = 100; c.attr1_tab = hl; c.attr1_stride = 100;
     c.edge_emb = k->c_emb; c.edge_sh = k->c_sh; c.sh_stride = 9;
     c.w1p = w->final_conv.w1p; c.w2p = w->final_conv.w2p; c.bn_scale = w->final_conv.bn_scale; c.bn_shift = w->final_conv.bn_shift;
@@ -810,9 +839,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, s2, *b, *w, *k, hl);
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
-    c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr; c.precision = w->precision; c.max_scatter = b->max_t > 0 ? b->max_t : 1;
+    c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr; c.precision = prec_edge; c.max_scatter = b->max_t > 0 ? b->max_t : 1;
     c.slices = 1;
-    while ((b->max_t + c.slices - 1) / c.slices > dp_conv_max_nodes(w->precision)) ++c.slices;
+    while ((b->max_t + c.slices - 1) / c.slices > dp_conv_max_nodes(prec_edge)) ++c.slices;
     c.rowptr = k->t_rowptr; c.rowend = k->t_rowend; c.nbr = k->t_nbr; c.edge_scat = k->t_src;
     c.gather_tab = hl; c.gather_stride = 100; c.attr1_tab = hl; c.attr1_stride = 100; c.attr2_tab = k->t_hb; c.attr2_stride = 20;
     c.attr_swap = 1; c.edge_emb = k->t_emb; c.edge_sh = k->t_sh; c.sh_stride = 7;

@@ -54,6 +54,8 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   w.x_sh = c.take<float>(nx * 9);
   w.x_nsh = c.take<float>(nx * 9);
   w.x_ew = c.take<float>(nx);
+  w.x_emb_bf = c.take<uint16_t>((nx + 1) * 32);
+  w.ll_emb_bf = c.take<uint16_t>((cap + 1) * 32);
   w.h_l[0] = c.take<float>(nl * 100);
   w.h_l[1] = c.take<float>(nl * 100);
   w.h_p[0] = c.take<float>(np * 100);
@@ -75,6 +77,7 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   float* tr_ = c.take<float>(B * 3);
   float* rot_ = c.take<float>(B * 3);
   float* tor_ = c.take<float>(nt);
+  w.edge_bf16x6 = 1;                                  // default: the edge-side convs of an fp32 model on the bf16 pipe (fp32-grade split)
   if (k) *k = w;
   if (tr) *tr = tr_;
   if (rot) *rot = rot_;
@@ -132,6 +135,10 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
         snprintf(nm, sizeof(nm), "%s.%d.w1n", FAMS[f], l); s.add(nm, dp_conv_w1n_floats(l));
         snprintf(nm, sizeof(nm), "%s.%d.w2n", FAMS[f], l); s.add(nm, dp_conv_w2n_floats(l));
       }
+      if (f != 1 && precision == DP_PREC_BF16) {      // the same families as bf16 MFMA fragments (dp_pack_conv_weights_node_bf16)
+        snprintf(nm, sizeof(nm), "%s.%d.w1n", FAMS[f], l); s.add(nm, dp_conv_w1b_floats(l));
+        snprintf(nm, sizeof(nm), "%s.%d.w2n", FAMS[f], l); s.add(nm, dp_conv_w2b_floats(l));
+      }
       if (((f == 1 && l < 3) || f == 0) && precision == DP_PREC_F32) {     // phore-phore stays edge-side, ligand-ligand goes edge-side for large
                                                                             // ligands: their second layer for the bf16 pipe as well (DpConvW.w2x)
         snprintf(nm, sizeof(nm), "%s.%d.w2x", FAMS[f], l); s.add(nm, dp_conv_w2p_floats(l, DP_PREC_BF16X6));
@@ -185,6 +192,28 @@ int dp_work_init(const DpBatch* b, DpWork* k, void* stream) {
   }
   if (hipMemsetAsync(k->tparams, 0, (size_t)b->B * dp::TP_STRIDE * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
   if (hipMemsetAsync(k->status, 0, (size_t)b->B * sizeof(int32_t), st) != hipSuccess) return (int)hipGetLastError();
+  return DP_OK;
+}
+
+#ifndef DP_SOURCE_HASH
+#define DP_SOURCE_HASH "unknown"
+#endif
+#ifndef DP_NABL
+#define DP_NABL 0
+#endif
+#ifndef DP_ABLATE
+#define DP_ABLATE 0
+#endif
+int dp_build_info(DpBuildInfo* out) {
+  if (!out) return DP_E_BADARG;
+  memset(out, 0, sizeof(*out));
+  out->abi_version = DP_ABI_VERSION;
+  out->nabl = DP_NABL;
+  out->ablate = DP_ABLATE;
+#ifdef DP_PROF
+  out->prof = 1;
+#endif
+  snprintf(out->source_hash, sizeof(out->source_hash), "%s", DP_SOURCE_HASH);
   return DP_OK;
 }
 

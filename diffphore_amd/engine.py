@@ -60,12 +60,12 @@ class DpWeights(C.Structure):
 class DpWork(C.Structure):
     _fields_ = ([(n, VOIDP) for n in ("lig_x_emb", "ph_x_emb", "pair_pre", "pair_fm", "pp_pre", "pp_sh", "tparams",
                                       "ll_rowptr", "ll_rowend", "ll_nbr", "ll_src", "ll_emb", "ll_sh", "ll_pair_rad", "ll_pair_bond", "pp_emb", "x_emb", "x_sh",
-                                      "x_nsh", "x_ew")]
+                                      "x_nsh", "x_ew", "x_emb_bf", "ll_emb_bf")]
                 + [("h_l", VOIDP * 2), ("h_p", VOIDP * 2)]
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -186,9 +186,10 @@ class DeviceModel:
         for name, fam in fams.items():
             for l in range(4):
                 node = name != "ph_conv" and prec == _lib.PREC_F32
+                node_bf = name != "ph_conv" and prec == _lib.PREC_BF16
                 # edge-side in an fp32 model (phore-phore always, ligand-ligand for large ligands): bf16x6 second layer as well
                 x6 = ((name == "ph_conv" and l < 3) or name == "lig_conv") and prec == _lib.PREC_F32
-                for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6).items():
+                for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6, node_bf16=node_bf).items():
                     H[f"{name}.{l}.{part}"] = t
         for part, t in packing.pack_conv(sd, "final_conv", _lib.CONV_FINAL, prec).items():
             H[f"final_conv.{part}"] = t
@@ -521,6 +522,7 @@ class _HipHandles:
 
 
 CONV_ALGOS = {"auto": 0, "edge": 1, "node": 2}
+CONV_FUSE = {"1": 0, "0": 1, "pairs": 2, "nosplit": 3}        # DIFFPHORE_CONV_FUSE -> DpWork.conv_fuse
 TWO_STREAM_MAX_POSES = 256        # below this a single conv launch leaves CUs idle
 
 
@@ -540,8 +542,15 @@ class Engine:
         self.L.dp_resolve_conv_algo.argtypes = [c_i32, c_i32, c_i32]
         self.L.dp_resolve_conv_algo.restype = C.c_int
         self.conv_algo = {1: "edge", 2: "node"}[self.L.dp_resolve_conv_algo(CONV_ALGOS[conv_algo], model.struct.precision, pb.B)]
-        self.ws.struct.conv_fuse = {"1": 0, "0": 1, "pairs": 2, "nosplit": 3}[os.environ.get("DIFFPHORE_CONV_FUSE", "1")]
-        self.ws.struct.edge_x6 = 1 if os.environ.get("DIFFPHORE_EDGE_X6", "1") == "0" else 0
+        fuse = os.environ.get("DIFFPHORE_CONV_FUSE", "1")
+        if fuse not in CONV_FUSE:
+            raise ValueError(f"DIFFPHORE_CONV_FUSE must be one of {sorted(CONV_FUSE)} (got {fuse!r})")
+        self.ws.struct.conv_fuse = CONV_FUSE[fuse]
+        x6 = os.environ.get("DIFFPHORE_EDGE_X6", "1")
+        if x6 not in ("0", "1"):
+            raise ValueError(f"DIFFPHORE_EDGE_X6 must be 0 or 1 (got {x6!r})")
+        self.ws.struct.edge_bf16x6 = int(x6)         # 1 (default): edge-side convs of an fp32 model as a bf16x6 split; 0: exact fp32 MFMA everywhere
+        self.edge_side_convs = ("bf16x6" if x6 == "1" else "f32") if model.precision == "f32" else model.precision
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         self._handles = None
         self._graph = None

@@ -31,7 +31,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 8
+#define DP_ABI_VERSION 9
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -58,10 +58,15 @@ enum DpPrecision {
   DP_PREC_F32 = 0,      /* exact fp32 MFMA (edge-side kernel: v_mfma_f32_32x32x2_f32; node-side kernel: v_mfma_f32_16x16x4_f32) */
   DP_PREC_BF16X6 = 3,   /* 3-way bf16 operand split, 6 cross products, fp32 accumulate: ~2^-24 relative, fp32-grade */
   DP_PREC_BF16X3 = 2,   /* 2-way bf16 split, 3 cross products: ~2^-17 relative */
-  DP_PREC_BF16X9 = 4    /* 3-way split, all 9 cross products: every fp32 x fp32 product exact (3 x 8 significand bits), fp32 accumulate */
+  DP_PREC_BF16X9 = 4,   /* 3-way split, all 9 cross products: every fp32 x fp32 product exact (3 x 8 significand bits), fp32 accumulate */
+  DP_PREC_BF16 = 5      /* plain bf16 OPERANDS, fp32 accumulate ("bf16 mixed precision", BASELINE.json configs[4]): radial MLP weights and
+                           activations, the tensor-product operand and the node-side intermediate T are rounded to bf16 once (2^-9
+                           relative each); geometry, spherical harmonics, edge-embedding MLPs, accumulation, BatchNorm shift and the
+                           residual stream stay fp32.  Node-side kernel: dp_conv_node_bf16_impl.h (one v_mfma_f32_16x16x32_bf16 per node,
+                           column tile and pass).  Edge-side kernel: the bf16x3 arithmetic (its weights are packed as for DP_PREC_BF16X3). */
 };
 
-/* formulation of the fused conv: per-edge radial GEMM, or node-side contraction (dense cross edge sets, fp32 only) */
+/* formulation of the fused conv: per-edge radial GEMM, or node-side contraction (dense cross edge sets; DP_PREC_F32 or DP_PREC_BF16) */
 enum DpConvAlgo {
   DP_ALGO_AUTO = 0,     /* library's choice by precision and batch size (dp_resolve_conv_algo) */
   DP_ALGO_EDGE = 1,     /* dp_conv.hip: w[e] = W2 hid[e] on the matrix pipe per edge, CG contraction on the VALU, segmented mean */
@@ -115,8 +120,9 @@ typedef struct DpConvArgs {
                                 conv's latency when B*slices cannot fill the chip; results are bit-identical.  fp32-MFMA kernel only
                                 (ignored otherwise and for kinds with a single phase) */
   /* node-side formulation (DP_ALGO_NODE): weights in the layout of dp_pack_conv_weights_node; `slices` = node groups per pose with
-   * ceil(max_scatter / slices) <= dp_conv_node_max_nodes().  Kinds 0-3, DP_PREC_F32 only; modes P2L / L2P (dense cross edges) and
-   * LLPAIR (ligand-ligand edges through the per-pose pair tables below).
+   * ceil(max_scatter / slices) <= dp_conv_node_max_nodes().  Kinds 0-3; DP_PREC_F32 (weights from dp_pack_conv_weights_node) or
+   * DP_PREC_BF16 (weights from dp_pack_conv_weights_node_bf16, plus edge_emb_bf below; no path_split / conv split variants: such
+   * launches run unsplit); modes P2L / L2P (dense cross edges) and LLPAIR (ligand-ligand edges through the per-pose pair tables below).
    * PRECONDITION on edge_sh: component 0 of every row is exactly 1.0 - true for e3nn's 'component'-normalised spherical harmonics
    * (Y_0 = 1, score_model_phore.py:737,754,891-894), which is all dp_forward ever passes.  The node-side kernel never reads sh[0]:
    * the l=0 paths use the gathered input itself as the GEMM-A operand.  A caller of dp_tp_conv with other edge_sh[:,0] values must
@@ -129,6 +135,11 @@ typedef struct DpConvArgs {
   /* DP_EDGES_LLPAIR: per pose a [N_l x N_l] table at pair_ptr[pose]; entry (i, j) = edge slot (row of edge_emb / edge_sh, CSR order)
    * of the radius edge scatter i <- gather j (pair_a) / of the bond edge (pair_b), -1 if absent.  rowptr / rowend give the degree. */
   const int32_t *pair_a, *pair_b, *pair_ptr;
+  /* DP_PREC_BF16 node-side kernel only: the edge embedding once more as bf16 rows of 32 (64 bytes: features 0..19 | 0 ... ), plus ONE
+   * flag row (all zero but feature 20 = 1.0) at row index emb_flag_row that stands for "this edge does not exist" (dp_forward: written by
+   * the edge-embedding kernels beside edge_emb; standalone callers: dp_edge_emb_bf16) */
+  const uint16_t* edge_emb_bf;
+  int32_t emb_flag_row;
   int32_t no_tail;           /* node-side only, a HINT: 1 = the caller guarantees that no pose of the batch ends on a pass of <= 16 edge slots
                                 (edges per node mod 32 is 0 or > 16 for every pose), so the launch may use the instantiation without the
                                 half-pass variant (half the code, ~40 % fewer spilled registers, ~2 % faster).  0 = unknown: the general
@@ -146,6 +157,14 @@ int dp_conv_w2n_floats(int32_t kind);
 /* HOST pointers: the same reference tensors as dp_pack_conv_weights, re-ordered for the node-side kernel */
 int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
                               const float* bn_scale, float* w1n, float* w2n);
+/* the same for the DP_PREC_BF16 node-side kernel: bf16 MFMA fragments (sizes in FLOATS of the blob, i.e. 2 bf16 each); DpConvArgs.w1n / w2n
+ * point at these images when DpConvArgs.precision == DP_PREC_BF16 */
+int dp_conv_w1b_floats(int32_t kind);
+int dp_conv_w2b_floats(int32_t kind);
+int dp_pack_conv_weights_node_bf16(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
+                                   const float* bn_scale, float* w1b, float* w2b);
+/* DEVICE: emb [n_rows, 20] fp32 -> out [(n_rows + 1), 32] bf16 (round to nearest even), row n_rows = the flag row (DpConvArgs.edge_emb_bf) */
+int dp_edge_emb_bf16(const float* emb, int32_t n_rows, uint16_t* out, void* stream);
 /* `bn_scale` (HOST, [D_out], the `scale` output of dp_pack_bn; NULL = ones) is folded into the packed second layer: the node-side
  * kernel applies the scatter mean and the BatchNorm scale inside its operands and only ADDS bn_shift in its epilogue, which is what lets
  * several convs share one set of accumulators (below).  DpConvArgs.bn_scale is therefore ignored by the node-side kernel. */
@@ -217,7 +236,7 @@ typedef struct DpConvW {
   const float* w2x;           /* the second layer packed for DP_PREC_BF16X6 beside an fp32 `w2p`, or NULL: the convs that stay on the edge-side
                                  kernel in an fp32 model (phore-phore: low degree; torsion bonds) then run their radial contraction as a 3-way
                                  bf16 split with 6 cross products on the bf16 pipe (16x the fp32 MFMA rate) - ~2^-24 relative per product, fp32
-                                 accumulate, held to the same tolerances as the fp32 kernel (DpWork.edge_x6 = 1 turns it off) */
+                                 accumulate, held to the same tolerances as the fp32 kernel (DpWork.edge_bf16x6 = 0 turns it off) */
 } DpConvW;
 
 /* Device pointers into the uploaded parameter blob.  Reference names: score_model_phore.py:248-291, 524-641. */
@@ -264,6 +283,8 @@ typedef struct DpWork {
   float* pp_emb;                    /* [n_pp,20] */
   float *x_emb, *x_sh, *x_nsh;      /* [n_x,20], [n_x,9], [n_x,9] */
   float* x_ew;                      /* [n_x] exp(total_weight) */
+  uint16_t *x_emb_bf, *ll_emb_bf;   /* [(n_x + 1), 32], [(ll_cap + 1), 32] bf16 images of x_emb / ll_emb + flag row (DpConvArgs.edge_emb_bf): written
+                                       by the edge-embedding kernels when the model's precision is DP_PREC_BF16, untouched otherwise */
   float *h_l[2], *h_p[2];           /* [n_lig,100], [n_ph,100] ping-pong */
   float *c_emb, *c_sh;              /* [n_lig,20], [n_lig,9] centre edges */
   float* gpred;                     /* [B,12] */
@@ -287,11 +308,14 @@ typedef struct DpWork {
                                        1 = the ligand radius graph only (large homogeneous batches: two matrix-bound convs side by side lose) */
   int32_t ll_node_max_atoms;        /* the ligand-ligand conv runs node-side (pair-dense) while the batch's largest ligand has at most this many
                                        atoms, edge-side (CSR) beyond; 0 = library default */
-  int32_t edge_x6;                  /* 0 = edge-side convs of an fp32 model use DpConvW.w2x (bf16x6) when present (default), 1 = exact fp32 MFMA */
+  int32_t edge_bf16x6;              /* 1 = the edge-side convs of an fp32 model (phore-phore, torsion bonds, ligand-ligand above the pair cap) use
+                                       DpConvW.w2x when present: 3-way bf16 split, 6 cross products, fp32-grade (the default dp_work_bind sets);
+                                       0 = exact fp32 MFMA everywhere */
   float* conv_part;                 /* [DP_CONV_PART_FLOATS] scratch of the conv-split launches of small batches (dp_tp_conv_node_fused_split) */
   float* z_noise;                   /* [6 B + n_tor] scratch of DP_NOISE_SEED: one step's z_tr | z_rot | z_tor */
   int32_t conv_fuse;                /* node-side convs of a layer that scatter onto the same nodes: 0 = one fused launch per side (default),
-                                       1 = one launch per conv (A/B runs and tests) */
+                                       1 = one launch per conv, 2 = the two cross convs fused but the ligand-ligand conv on its own launch,
+                                       3 = fused launches but never the conv split of small batches (1-3: A/B runs and tests) */
 } DpWork;
 
 typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */
@@ -409,6 +433,19 @@ int dp_aux_destroy(void* aux_stream, void* ev_fork, void* ev_join);
 int dp_struct_sizes(int32_t* out, int32_t n);
 
 int dp_abi_version(void);
+
+/* What this build of the library is: compile-time switches that change what the kernels compute or time (all 0 in a product build) and a
+ * hash of the kernel sources it was compiled from.  A host should refuse a library whose nabl / ablate are non-zero unless it asked for an
+ * ablation build (those kernels compute wrong numbers by design). */
+typedef struct DpBuildInfo {
+  int32_t abi_version;
+  int32_t nabl;        /* -DDP_NABL   (node-side kernel ablations) */
+  int32_t ablate;      /* -DDP_ABLATE (edge-side kernel ablations) */
+  int32_t prof;        /* -DDP_PROF   (cycle stamps)               */
+  char source_hash[20];   /* first 16 hex digits of sha256 over the .hip / .h files of csrc/ and include/ (bench.kernel_source_hash), NUL-terminated;
+                             "unknown" when built without the build script */
+} DpBuildInfo;
+int dp_build_info(DpBuildInfo* out);
 
 #ifdef __cplusplus
 }

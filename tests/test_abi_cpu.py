@@ -18,10 +18,56 @@ def test_library_exports_every_declared_symbol():
             "dp_sample_graph_destroy", "dp_conformer_update", "dp_prepare", "dp_randomize_position", "dp_fit_overlap",
             "dp_pack_conv_weights", "dp_pack_conv_weights_node", "dp_pack_bn", "dp_work_bytes", "dp_work_bind", "dp_work_init",
             "dp_weights_segments", "dp_weights_blob_floats", "dp_weights_bind", "dp_resolve_conv_algo", "dp_abi_version",
-            "dp_struct_sizes", "dp_noise_normals", "dp_randomize_draws", "dp_philox4x32", "dp_forward_launch_of", "dp_tp_conv_node_fused", "dp_tp_conv_node_fused_split"} <= names
+            "dp_struct_sizes", "dp_noise_normals", "dp_randomize_draws", "dp_philox4x32", "dp_forward_launch_of", "dp_tp_conv_node_fused", "dp_tp_conv_node_fused_split",
+            "dp_build_info", "dp_pack_conv_weights_node_bf16", "dp_conv_w1b_floats", "dp_conv_w2b_floats", "dp_edge_emb_bf16"} <= names
     L = _lib.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in the header but not exported"
+
+
+def test_build_identity_and_ablation_builds_are_refused(monkeypatch):
+    """dp_build_info: the product build carries no ablation / profiling switch and the hash of the sources it was compiled from (the hash
+    bench.py keys PMC profiles with); `_lib.lib()` refuses a library that reports an ablation switch unless DIFFPHORE_ALLOW_ABLATION=1."""
+    from diffphore_amd.csrc import build
+    info = _lib.build_info()
+    assert info["abi_version"] == _lib.DP_ABI_VERSION and info["nabl"] == 0 and info["ablate"] == 0 and info["prof"] == 0
+    assert info["source_hash"] == build.source_hash(), "libdiffphore_hip.so is stale: rebuild with python diffphore_amd/csrc/build.py"
+    L = _lib.lib()
+
+    class FakeInfo:
+        argtypes = restype = None
+
+        def __call__(self, ref):
+            L.dp_build_info(ref)
+            ref._obj.nabl = 8
+            return 0
+
+    class Fake:
+        """the real library with a dp_build_info that reports -DDP_NABL=8"""
+        dp_build_info = FakeInfo()
+
+        def __getattr__(self, n):
+            return getattr(L, n)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(C, "CDLL", lambda path: Fake())
+    monkeypatch.delenv("DIFFPHORE_ALLOW_ABLATION", raising=False)
+    with pytest.raises(_lib.DiffPhoreLibraryError, match="ablation build"):
+        _lib.lib()
+    monkeypatch.setenv("DIFFPHORE_ALLOW_ABLATION", "1")
+    assert _lib.lib() is not None
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_workspace_defaults_are_positive_sense():
+    """dp_work_bind initialises DpWork.edge_bf16x6 = 1 (ABI 9: 1 = the fp32-grade bf16x6 split on the edge-side convs of an fp32 model, 0 = exact fp32)"""
+    L = engine._declare()
+    b = engine.DpBatch()
+    b.B, b.n_lig, b.n_ph, b.n_bond, b.n_tor, b.n_pp, b.n_x, b.ll_cap = 2, 10, 12, 20, 4, 30, 120, 300
+    n = L.dp_work_bytes(C.byref(b))
+    w = engine.DpWork()
+    ptrs = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+    assert L.dp_work_bind(C.byref(b), 1 << 20, n, C.byref(w), *[C.byref(p) for p in ptrs]) == 0
+    assert w.edge_bf16x6 == 1 and w.conv_fuse == 0 and w.aux_mode == 0
 
 
 def test_struct_layouts_match_the_compiler():
@@ -47,7 +93,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
     base = 1 << 20                                                            # a fake (aligned) device address: bind touches no memory
     assert L.dp_work_bind(C.byref(b), base, n1, C.byref(w), *[C.byref(p) for p in ptrs]) == 0
     fields = [getattr(w, n) for n, _ in engine.DpWork._fields_ if n not in ("h_l", "h_p", "prof_start", "prof_stop", "prof_layer",
-                                                                            "prof_conv", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "edge_x6", "ll_node_max_atoms", "aux_mode")]
+                                                                            "prof_conv", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "edge_bf16x6", "ll_node_max_atoms", "aux_mode")]
     fields += list(w.h_l) + list(w.h_p) + [p.value for p in ptrs]
     assert all(f is not None and base <= f < base + n1 and f % 256 == 0 for f in fields) and len(set(fields)) == len(fields)
     assert L.dp_work_bind(C.byref(b), base, n1 - 1, C.byref(w), *[C.byref(p) for p in ptrs]) == -3
@@ -64,7 +110,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
             end = sg.offset + sg.numel
         assert L.dp_weights_blob_floats(prec) >= end
         names = [sg.name.decode() for sg in segs]
-        assert len(set(names)) == n and "p2l_conv.3.w2p" in names and ("p2l_conv.3.w2n" in names) == (prec == _lib.PREC_F32)
+        assert len(set(names)) == n and "p2l_conv.3.w2p" in names and ("p2l_conv.3.w2n" in names) == (prec in (_lib.PREC_F32, _lib.PREC_BF16))
         assert ("ph_conv.0.w2x" in names) == ("tor_conv.w2x" in names) == (prec == _lib.PREC_F32) and "ph_conv.3.w2x" not in names
 
 

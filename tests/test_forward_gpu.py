@@ -107,7 +107,7 @@ def test_edge_side_convs_on_the_bf16_pipe_vs_exact_fp32(algo, monkeypatch):
         tr, rot, tor = m(batch)
         torch.cuda.synchronize()
         ws = m._engine.ws
-        assert ws.struct.edge_x6 == (0 if x6 == "1" else 1)
+        assert ws.struct.edge_bf16x6 == int(x6)
         errs = dict(h_l4=_rel(ws.t["h_l0"][:, :100], om.debug["h_l4"]), h_p3=_rel(ws.t["h_p1"][:, :100], om.debug["h_p3"]), tr=_rel(tr, tr_o),
                     rot=_rel(rot, rot_o), tor=_rel(tor, tor_o))
         print(algo, "edge_x6 =", x6, {k: f"{v:.1e}" for k, v in errs.items()})

@@ -122,3 +122,38 @@ def test_node_side_packing_reproduces_the_conv(kind):
     out = out + pk["bn_shift"].numpy().astype(np.float64)              # the BatchNorm scale is folded into the packed second layer
     err = np.abs(out - ref).max() / np.abs(ref).max()
     assert err < 1e-6, err
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", ["p2l", "l2p"])
+def test_bf16_node_packing_and_model_vs_oracle(kind, mode):
+    """DP_PREC_BF16: the packed bf16 fragments (dp_pack_conv_weights_node_bf16) un-permuted with the kernel's index formulas and the conv
+    evaluated with bf16 roundings where the kernel rounds (tests/bf16_model.py) stay within bf16-grade distance of the fp64 oracle:
+    <= 2e-2 of the output's largest magnitude (measured 2-6e-3: ~2^-9 per operand, averaged over 32-edge / 640-term sums)."""
+    from bf16_model import node_conv_bf16
+    L = _lib.lib()
+    sd = weights.init_state_dict(11)
+    fam = "phore_to_lig_conv_layers" if mode == "p2l" else "lig_to_phore_conv_layers"
+    prefix = f"encoder.{fam}.{kind}"
+    pk = packing.pack_conv(sd, prefix, kind, _lib.PREC_BF16, node_bf16=True)
+    assert pk["w1n"].numel() == L.dp_conv_w1b_floats(kind) and pk["w2n"].numel() == L.dp_conv_w2b_floats(kind)
+    dims = _lib.conv_dims(kind)
+    g = torch.Generator().manual_seed(50 + kind)
+    NL, NP = 5, 37
+    hl, hp = torch.randn(NL, dims["d_in"], generator=g), torch.randn(NP, dims["d_in"], generator=g)
+    E = NL * NP
+    emb, sh = torch.randn(E, 20, generator=g), torch.randn(E, 9, generator=g)
+    sh[:, 0] = 1.0
+    src, dst = torch.arange(NL).repeat_interleave(NP), torch.arange(NP).repeat(NL)
+    attr = torch.cat([emb, hl[src, :20], hp[dst, :20]], 1)
+    if mode == "p2l":
+        ref = _oracle_conv(sd, prefix, kind, hp[dst], attr, sh, src, NL).numpy()
+        got = node_conv_bf16(kind, pk["w1n"].numpy(), pk["w2n"].numpy(), pk["bn_shift"].numpy(), emb.numpy(), hl[src, :20].numpy(), hp[dst, :20].numpy(),
+                             hp[dst].numpy(), sh.numpy(), src.numpy(), NL, s_img=1)
+    else:
+        ref = _oracle_conv(sd, prefix, kind, hl[src], attr, sh, dst, NP).numpy()
+        got = node_conv_bf16(kind, pk["w1n"].numpy(), pk["w2n"].numpy(), pk["bn_shift"].numpy(), emb.numpy(), hp[dst, :20].numpy(), hl[src, :20].numpy(),
+                             hl[src].numpy(), sh.numpy(), dst.numpy(), NP, s_img=2)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print(f"kind {kind} {mode}: bf16 model vs fp64 oracle {err:.2e}")
+    assert err < 2e-2, err

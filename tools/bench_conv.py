@@ -32,7 +32,8 @@ def main():
         _lib.LIB_PATH = a.lib
     dims = _lib.conv_dims(a.kind)
     sd = weights.init_state_dict(1)
-    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PRECISIONS[a.prec], node_side=a.algo == "node")
+    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PRECISIONS[a.prec], node_side=a.algo == "node" and a.prec == "f32",
+                           node_bf16=a.algo == "node" and a.prec == "bf16")
     B, NL, NP = a.B, a.nl, a.np
     dev = "cuda"
     lig_ptr = torch.arange(B + 1, dtype=torch.int32) * NL
@@ -60,6 +61,10 @@ def main():
     args.attr1_tab, args.attr1_stride = hl.data_ptr(), dims["d_in"]
     args.attr2_tab, args.attr2_stride = hp.data_ptr(), dims["d_in"]
     args.edge_emb, args.edge_sh, args.sh_stride = emb.data_ptr(), sh.data_ptr(), 9
+    if a.prec == "bf16":
+        emb_bf = torch.zeros((E + 1) * 32, dtype=torch.int16, device=dev)
+        _lib.check(_lib.lib().dp_edge_emb_bf16(emb.data_ptr(), E, emb_bf.data_ptr(), torch.cuda.current_stream().cuda_stream), "dp_edge_emb_bf16")
+        args.edge_emb_bf, args.emb_flag_row = emb_bf.data_ptr(), E
     args.w1p, args.w2p = keep["w1p"].data_ptr(), keep["w2p"].data_ptr()
     if a.algo == "node":
         nb = _lib.lib().dp_conv_node_max_nodes()
