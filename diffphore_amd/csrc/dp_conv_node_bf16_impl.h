@@ -27,6 +27,13 @@
 #pragma once
 #include "dp_conv_node_impl.h"
 
+#ifndef DP_BABL     // timing ablations of THIS kernel (tools/build_variant.sh; results are wrong by construction): 1 no gathered-operand loads,
+#define DP_BABL 0   // 2 no SH-factor reads, 3 no z arithmetic, 4 no GEMM-A MFMAs, 5 no T stores, 6 no T reads, 7 no GEMM-B MFMAs, 8 no W2 loads,
+#endif              // 9 no edge-embedding loads (GEMM1), 10 one workgroup per CU
+#ifdef DP_PROF     // cycle stamps (tools/build_variant.sh prof "-DDP_PROF" dp_conv_node_bf16_k3.hip): per translation unit, read through dp_debug_prof_node
+static __device__ unsigned long long dpb_prof[16];
+#endif
+
 namespace dpb {
 using namespace dpn;
 
@@ -35,6 +42,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef u32x2 __attribute__((address_space(3))) lds_u32x2;
 __device__ __forceinline__ lds_u32x2* lds_ptr(unsigned a) { return (lds_u32x2*)(__UINTPTR_TYPE__)a; }      // LDS byte address -> pointer
@@ -43,7 +51,12 @@ constexpr int SUPER_NU = 10;          // in-channels per supertile
 constexpr int SUPER_CH = 5;           // GEMM-B K chunks (two in-channels x 16 hidden rows) per supertile
 constexpr int EMB_ROW = 32;           // bf16 per row of the bf16 edge-embedding table (20 features | flag | padding) = 64 bytes
 constexpr int EMB_FLAG = 20;          // feature slot of the "edge does not exist" flag
-constexpr int COLB = 512;             // bytes per T column: 4 k quads x 16 nodes x 4 bf16
+constexpr int COLB = 520;             // bytes per T column: 4 k quads x 16 nodes x 4 bf16 = 512, + 8: the 16 lanes of a ds_write_b64 (one column each,
+                                      // same node, same k quad) then fall into 16 different 8-byte bank units - no swizzle arithmetic per store
+constexpr int TIMG_B = 15616;         // bytes per wave-private T image: 30 columns x 520, rounded up to 64
+constexpr int TIMG_F = TIMG_B / 4;
+constexpr int TDUM_B = 640;           // where the lanes without a column store (4 x 128 + 15 x 8 bytes are touched)
+static_assert(2 * TCOLS * COLB <= TIMG_B && TIMG_B % 64 == 0, "T image holds a supertile");
 
 template <int KIND> constexpr int st_count(int p) { return Spec<KIND>::P[p].mul_in / SUPER_NU; }
 template <int KIND> constexpr int w2b_path_off(int p) {             // in 16-byte quads
@@ -67,47 +80,77 @@ __device__ __forceinline__ unsigned pk2(float lo, float hi) {       // v_cvt_pk_
 __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-// column of in-channel `ul` (0..9 inside the supertile), component m, in the wave's T image; `xkey` = the lane (column of its tile) that wrote it
+// column of in-channel `ul` (0..9 inside the supertile), component m, in the wave's T image
 template <bool VEC> constexpr int t_col(int ul, int m) { return VEC ? (ul / 5) * TCOLS + m * 5 + (ul % 5) : ul; }
-template <bool VEC> constexpr int t_key(int ul, int m) { return VEC ? m * 5 + (ul % 5) : ul; }
 
-// gathered operands of supertile (path P, st) for this lane's 8 (HALF: 4) edges, both tiles; masking and sign are applied when the
-// supertile starts, so that the loads can travel during the previous supertile's GEMM-B
+template <int ZT> constexpr int term_sign(int t) { return (ZT == Z111 && t == 1) ? -1 : 1; }        // (term_of(t, m).sign, which does not depend on m)
+
+// the gathered-feature table as a buffer resource: one VGPR offset per (lane, tile), the eight edges of a lane through SGPR offsets, rows past
+// the table's end read as 0 (no clamping arithmetic, no 64-bit addresses)
+struct XSrc {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned voff_row;       // byte offset of the row gathered by this lane group's first edge slot of the pass
+  unsigned soff[8];        // byte offsets of the lane's other edge slots relative to it (wave-uniform)
+};
+// (base and size are wave-uniform, but they come out of a dynamically indexed kernel-argument array, i.e. through VGPRs: readfirstlane makes the
+// descriptor provably scalar - without it every buffer load is wrapped in a waterfall loop)
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)(__UINTPTR_TYPE__)base;
+  const unsigned long long pu = ((unsigned long long)uni((unsigned)(p >> 32)) << 32) | uni((unsigned)p);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(__UINTPTR_TYPE__)pu, 0, (int)uni(bytes), 0x00020000);
+}
+
+// gathered operands of supertile (path P, st) for this lane's 8 (HALF: 4) edges, both tiles, as pairs of consecutive edge slots (the operand
+// layout of v_pk_*_f32); requested during the previous supertile's GEMM-B.  No masking: an edge slot that does not exist has a zero hidden
+// vector and a lane without a column stores to the dummy column, so whatever (finite) value arrives there is never seen.
 template <int KIND, int MODE, bool HALF, int P>
-__device__ __forceinline__ void load_x2(const DpConvArgs& a, const Wg& r, int et, int lane_l, int st, float (&xr)[2][3][8]) {
+__device__ __forceinline__ void load_x2(const XSrc& xs, int lane_l, int st, f32x2 (&xr)[2][3][4]) {
   using S = Spec<KIND>;
+  (void)MODE;
   if constexpr (P < S::NPATH) {
     constexpr PathC pc = S::P[P];
     constexpr int ZT = pc.ztype;
     constexpr bool VEC = d_out_of(ZT) == 3;
-    constexpr int DIN = d_in_of(ZT), NTERM = n_terms<ZT>(), NTILE = VEC ? 2 : 1;
-    const int g = lane_l >> 4, c = lane_l & 15;
+    constexpr int DIN = d_in_of(ZT), NTERM = n_terms<ZT>(), NTILE = VEC ? 2 : 1, NJ = HALF ? 4 : 8;
+    // (scalar dword loads only: with this toolchain a raw_buffer_load_b64 / b96 / b128 whose result is read element by element is narrowed to ONE
+    //  dword - the other components come back undefined; the three components of a 3-term path therefore travel as three loads with
+    //  immediate offsets, which cost no address arithmetic either)
+    const int c = lane_l & 15;
     const int m = VEC ? (c >= 10 ? 2 : (c >= 5 ? 1 : 0)) : 0;
     const int ul = VEC ? c - 5 * m : c;
     const bool colv = VEC ? c < 15 : c < 10;
-    const float* __restrict__ base = a.gather_tab;
 #pragma unroll
     for (int tl = 0; tl < NTILE; ++tl) {
       const int u = colv ? SUPER_NU * st + 5 * tl + ul : 0;
-      unsigned coff[NTERM];
+      const unsigned voff = xs.voff_row + (unsigned)((pc.in_off + u * DIN) * 4);
+      float v[3][8];
+      unsigned vt[NTERM];
 #pragma unroll
-      for (int t = 0; t < NTERM; ++t) coff[t] = (unsigned)(pc.in_off + u * DIN + term_of<ZT>(t, m).xcomp);
+      for (int t = 0; t < NTERM; ++t) vt[t] = voff + (unsigned)(term_of<ZT>(t, m).xcomp * 4);       // (xcomp = t for the dot / l=2 paths: an immediate)
 #pragma unroll
-      for (int j = 0; j < (HALF ? 4 : 8); ++j) {
-        const int e = 32 * et + 16 * (j >> 2) + 4 * g + (j & 3);
-        const unsigned roff = (unsigned)gather_row<MODE>(r, e < r.En ? e : 0) * (unsigned)a.gather_stride;
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int t = 0; t < NTERM; ++t) xr[tl][t][j] = base[roff + coff[t]];
-      }
+        for (int t = 0; t < NTERM; ++t) {
+#if DP_BABL == 1
+          v[t][j] = __builtin_bit_cast(float, vt[t] + xs.soff[j]);
+#else
+          v[t][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xs.rs, vt[t], xs.soff[j], 0));
+#endif
+        }
+#pragma unroll
+      for (int t = 0; t < NTERM; ++t)
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; ++jp) xr[tl][t][jp] = f32x2{v[t][2 * jp], v[t][2 * jp + 1]};
     }
   }
 }
 
 template <int KIND, int MODE, bool HALF, int P>
 struct StageB {
-  static __device__ __forceinline__ void run(const DpConvArgs& a, const Wg& r, int et, int q, int lane, const u32x4 (&hid)[NB],
+  static __device__ __forceinline__ void run(const DpConvArgs& a, const XSrc& xs, int q, int lane, const u32x4 (&hid)[NB],
                                              unsigned tl_base, unsigned dummy_base, const float* sS, f32x4 (&acc)[n_acc4<KIND>()],
-                                             float (&xr)[2][3][8]) {
+                                             f32x2 (&xr)[2][3][4], NProfT& prof_prev) {
     using S = Spec<KIND>;
     if constexpr (P < S::NPATH) {
       constexpr PathC pc = S::P[P];
@@ -122,26 +165,51 @@ struct StageB {
         const int g = lane_l >> 4, c = lane_l & 15;
         const int m = VEC ? (c >= 10 ? 2 : (c >= 5 ? 1 : 0)) : 0;
         const bool colv = VEC ? c < 15 : c < 10;
-        // ---- gathered operand of the lane's column in both tiles (the same rows for every node of the group) --------------------
-        float xa[NTILE][NTERM][NJ];
+        // ---- gathered operand of the lane's column in both tiles (the same rows for every node of the group), as edge-slot pairs ------
+        f32x2 xa[NTILE][NTERM][NJ / 2];
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl)
 #pragma unroll
-          for (int t = 0; t < NTERM; ++t) {
-            const Term tm = term_of<ZT>(t, m);
+          for (int t = 0; t < NTERM; ++t)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-              const int e = 32 * et + 16 * (j >> 2) + 4 * g + (j & 3);
-              xa[tl][t][j] = (colv && e < r.En) ? tm.sign * xr[tl][t][j] : 0.f;
-            }
-          }
-        // T image: byte address of (column, k quad g, node nn) = column * 512 + g * 128 + ((nn ^ key) << 3), key = the writing lane's c
+            for (int jp = 0; jp < NJ / 2; ++jp) xa[tl][t][jp] = xr[tl][t][jp];
+        // T image: byte address of (column, k quad g, node nn) = column * 520 + g * 128 + nn * 8: the node is an immediate offset
         unsigned twr[NTILE];
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl)
-          twr[tl] = (colv ? tl_base + (unsigned)((tl * TCOLS + c) * COLB) : dummy_base) + (unsigned)(g * 128 + c * 8);
+          twr[tl] = (colv ? tl_base + (unsigned)((tl * TCOLS + c) * COLB) : dummy_base + (unsigned)(c * 8)) + (unsigned)(g * 128);
+        // the supertile's W2 fragments (GEMM-B's A operands, 5 K chunks x MT) are requested NOW: a chunk is only 3-6 MFMAs of 16 cycles long, an L2
+        // round trip under load several hundred cycles - requested inside GEMM-B they would stall every chunk; GEMM-A hides them
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w2n) + w2b_path_off<KIND>(P) + (size_t)(st * SUPER_CH * MT) * 256 + q * 64 + lane_l;
+        u32x4 wall[SUPER_CH][MT];
+#pragma unroll
+        for (int ch = 0; ch < SUPER_CH; ++ch)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+#if DP_BABL == 8
+            wall[ch][mt] = u32x4{(unsigned)(size_t)wsrc, (unsigned)ch, (unsigned)mt, 5u};
+#else
+            wall[ch][mt] = wsrc[(ch * MT + mt) * 256];
+#endif
+          }
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM-A: one MFMA per (node, tile); T leaves as bf16 ----------------------------------------------------------------
+        // Software pipeline over the nodes: node nn's MFMAs are issued into a ring of two accumulator sets and their results are
+        // converted / stored one node LATER (behind the next node's z arithmetic), so no VALU instruction waits on the MFMA it follows;
+        // the SH factors of node nn + 1 are requested before node nn's arithmetic.  sched_barrier keeps the nodes apart (hoisting every
+        // LDS read to the top spills).
+        f32x4 Dq[2][NTILE];
+        auto store_t = [&](int nn) {
+#pragma unroll
+          for (int tl = 0; tl < NTILE; ++tl) {
+            const f32x4 D = Dq[nn & 1][tl];
+#if DP_BABL == 5
+            asm volatile("" ::"v"(pk2(D[0], D[1])), "v"(pk2(D[2], D[3])), "v"(twr[tl] + (unsigned)(nn << 3)));
+#else
+            *lds_ptr(twr[tl] + (unsigned)(nn << 3)) = u32x2{pk2(D[0], D[1]), pk2(D[2], D[3])};
+#endif
+          }
+        };
         if constexpr (needs_s<ZT>()) {
           const char* sbase = reinterpret_cast<const char*>(sS);
           int soff[NTERM];
@@ -152,98 +220,144 @@ struct StageB {
             for (int t = 0; t < NTERM; ++t)
 #pragma unroll
               for (int t2 = 0; t2 < NT2; ++t2)
+#if DP_BABL == 2
+                sv[t][t2] = f32x4{(float)soff[t], (float)nn, 1.f, 2.f};
+#else
                 sv[t][t2] = *reinterpret_cast<const f32x4*>(sbase + (2 * nn + t2) * (SCOMP * 64) + soff[t]);
+#endif
           };
-          f32x4 sv[2][NTERM][NT2];
+          // factor registers: double-buffered (node nn + 1 requested before node nn's arithmetic) except for the three-term vector paths,
+          // where the second set would not fit beside the two tiles' gathered operands: there the next node's factors are requested as
+          // soon as this node's z values exist
+          constexpr int SD = (VEC && NTERM == 3) ? 1 : 2;
+          f32x4 sv[SD][NTERM][NT2];
           loadS(0, sv[0]);
 #pragma unroll
           for (int nn = 0; nn < NB; ++nn) {
-            if (nn + 1 < NB) loadS(nn + 1, sv[(nn + 1) & 1]);
+            const int cur = SD == 2 ? (nn & 1) : 0;
+            if constexpr (SD == 2) {
+              if (nn + 1 < NB) loadS(nn + 1, sv[(nn + 1) & 1]);
+            }
+            u32x4 zb[NTILE];
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl) {
-              float z[NJ];
+              f32x2 z[NJ / 2];
 #pragma unroll
-              for (int j = 0; j < NJ; ++j) {
-                float zz = xa[tl][0][j] * sv[nn & 1][0][j >> 2][j & 3];
+              for (int jp = 0; jp < NJ / 2; ++jp) {
+#if DP_BABL == 3
+                z[jp] = xa[tl][0][jp];
+                if (jp == 0) asm volatile("" ::"v"(sv[cur][NTERM - 1][0]), "v"(sv[cur][0][NT2 - 1]));
+                continue;
+#endif
+                // edge slots 2 jp, 2 jp + 1 of the lane = components (2 jp & 3, + 1) of the factor quad of 16-edge tile jp >> 1
+                auto spair = [&](int t) { const f32x4 q4 = sv[cur][t][jp >> 1]; return (jp & 1) ? f32x2{q4[2], q4[3]} : f32x2{q4[0], q4[1]}; };
+                f32x2 zz = xa[tl][0][jp] * spair(0);
 #pragma unroll
-                for (int t = 1; t < NTERM; ++t) zz = fmaf(xa[tl][t][j], sv[nn & 1][t][j >> 2][j & 3], zz);
-                z[j] = zz;
+                for (int t = 1; t < NTERM; ++t) {
+                  if (term_sign<ZT>(t) < 0) zz = __builtin_elementwise_fma(-xa[tl][t][jp], spair(t), zz);
+                  else zz = __builtin_elementwise_fma(xa[tl][t][jp], spair(t), zz);
+                }
+                z[jp] = zz;
               }
-              u32x4 zb = {pk2(z[0], z[1]), pk2(z[2], z[3]), 0u, 0u};
-              if constexpr (!HALF) { zb[2] = pk2(z[NJ - 4], z[NJ - 3]); zb[3] = pk2(z[NJ - 2], z[NJ - 1]); }
-              const f32x4 D = mfma_bf(as_bf(hid[nn]), as_bf(zb), f32x4{0.f, 0.f, 0.f, 0.f});
-              *lds_ptr(twr[tl] ^ (unsigned)(nn << 3)) = u32x2{pk2(D[0], D[1]), pk2(D[2], D[3])};
+              zb[tl] = u32x4{pk2(z[0][0], z[0][1]), pk2(z[1][0], z[1][1]), 0u, 0u};
+              if constexpr (!HALF) { zb[tl][2] = pk2(z[NJ / 2 - 2][0], z[NJ / 2 - 2][1]); zb[tl][3] = pk2(z[NJ / 2 - 1][0], z[NJ / 2 - 1][1]); }
             }
+            if constexpr (SD == 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (nn + 1 < NB) loadS(nn + 1, sv[0]);
+            }
+#pragma unroll
+            for (int tl = 0; tl < NTILE; ++tl) {
+#if DP_BABL == 4
+              asm volatile("" ::"v"(hid[nn]), "v"(zb[tl]));
+              Dq[nn & 1][tl] = f32x4{__builtin_bit_cast(float, zb[tl][0]), 1.f, 2.f, 3.f};
+#else
+              Dq[nn & 1][tl] = mfma_bf(as_bf(hid[nn]), as_bf(zb[tl]), f32x4{0.f, 0.f, 0.f, 0.f});
+#endif
+            }
+            if (nn > 0) store_t(nn - 1);
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
           // z is the gathered input itself (sh_0 = 1): the B operand is the same for every node
           u32x4 zb[NTILE];
 #pragma unroll
-          for (int tl = 0; tl < NTILE; ++tl)
-          {
-            zb[tl] = u32x4{pk2(xa[tl][0][0], xa[tl][0][1]), pk2(xa[tl][0][2], xa[tl][0][3]), 0u, 0u};
-            if constexpr (!HALF) { zb[tl][2] = pk2(xa[tl][0][NJ - 4], xa[tl][0][NJ - 3]); zb[tl][3] = pk2(xa[tl][0][NJ - 2], xa[tl][0][NJ - 1]); }
+          for (int tl = 0; tl < NTILE; ++tl) {
+            zb[tl] = u32x4{pk2(xa[tl][0][0][0], xa[tl][0][0][1]), pk2(xa[tl][0][1][0], xa[tl][0][1][1]), 0u, 0u};
+            if constexpr (!HALF) { zb[tl][2] = pk2(xa[tl][0][NJ / 2 - 2][0], xa[tl][0][NJ / 2 - 2][1]); zb[tl][3] = pk2(xa[tl][0][NJ / 2 - 1][0], xa[tl][0][NJ / 2 - 1][1]); }
           }
 #pragma unroll
           for (int nn = 0; nn < NB; ++nn) {
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl) {
-              const f32x4 D = mfma_bf(as_bf(hid[nn]), as_bf(zb[tl]), f32x4{0.f, 0.f, 0.f, 0.f});
-              *lds_ptr(twr[tl] ^ (unsigned)(nn << 3)) = u32x2{pk2(D[0], D[1]), pk2(D[2], D[3])};
+#if DP_BABL == 4
+              asm volatile("" ::"v"(hid[nn]), "v"(zb[tl]));
+              Dq[nn & 1][tl] = f32x4{__builtin_bit_cast(float, zb[tl][0]), 1.f, 2.f, 3.f};
+#else
+              Dq[nn & 1][tl] = mfma_bf(as_bf(hid[nn]), as_bf(zb[tl]), f32x4{0.f, 0.f, 0.f, 0.f});
+#endif
             }
+            if (nn > 0) store_t(nn - 1);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
+        store_t(NB - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        NPROF(2);
         // ---- GEMM-B: out[w][node] += W2[w][(u,k)] T[(u,k)][node], K = (two in-channels) x (the wave's 16 hidden rows) -----------------
+        // chunk ch + 1's T fragments are read from LDS while chunk ch's MFMAs run; the next supertile's gathered operands are requested
+        // at the start (they are consumed when that supertile begins: behind the W2 fragments already in flight, vector-memory returns are in order)
         {
           constexpr int PN = P + 1;
-          const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w2n) + w2b_path_off<KIND>(P) + (size_t)(st * SUPER_CH * MT) * 256 + q * 64 + lane_l;
-          const unsigned rbase = tl_base + (unsigned)(g * 128 + c * 8);          // GEMM-B view: node c, k quad g
-          u32x4 wf[MT], wn[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) wf[mt] = wsrc[mt * 256];
-#pragma unroll
-          for (int ch = 0; ch < SUPER_CH; ++ch) {
-            if (ch + 1 < SUPER_CH) {
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) wn[mt] = wsrc[((ch + 1) * MT + mt) * 256];
-            }
-            if (ch == SUPER_CH - 2) {
-              // the next supertile's gathered operands travel behind the last W2 request of this one
-              if (st + 1 < st_count<KIND>(P)) load_x2<KIND, MODE, HALF, P>(a, r, et, lane_l, st + 1, xr);
-              else load_x2<KIND, MODE, HALF, PN>(a, r, et, lane_l, 0, xr);
-            }
+          const unsigned rbase = tl_base + (unsigned)(g * 128 + c * 8);          // GEMM-B view: node c, k quad g; the column is an immediate offset
+          auto readT = [&](int ch, u32x4 (&tb)[NG]) {
 #pragma unroll
             for (int grp = 0; grp < NG; ++grp) {
-              const u32x2 lo = *lds_ptr((rbase ^ (unsigned)(t_key<VEC>(2 * ch, grp) << 3)) + (unsigned)(t_col<VEC>(2 * ch, grp) * COLB));
-              const u32x2 hi = *lds_ptr((rbase ^ (unsigned)(t_key<VEC>(2 * ch + 1, grp) << 3)) + (unsigned)(t_col<VEC>(2 * ch + 1, grp) * COLB));
-              const u32x4 tb = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) acc[AB + grp * MT + mt] = mfma_bf(as_bf(wf[mt]), as_bf(tb), acc[AB + grp * MT + mt]);
+#if DP_BABL == 6
+              const u32x2 lo = {rbase + ch, (unsigned)grp}, hi = {rbase, 7u};
+#else
+              const u32x2 lo = *lds_ptr(rbase + (unsigned)(t_col<VEC>(2 * ch, grp) * COLB));
+              const u32x2 hi = *lds_ptr(rbase + (unsigned)(t_col<VEC>(2 * ch + 1, grp) * COLB));
+#endif
+              tb[grp] = u32x4{lo.x, lo.y, hi.x, hi.y};
             }
+          };
+          u32x4 tb[2][NG];
+          readT(0, tb[0]);
+          if (st + 1 < st_count<KIND>(P)) load_x2<KIND, MODE, HALF, P>(xs, lane_l, st + 1, xr);
+          else load_x2<KIND, MODE, HALF, PN>(xs, lane_l, 0, xr);
+#pragma unroll
+          for (int ch = 0; ch < SUPER_CH; ++ch) {
+            if (ch + 1 < SUPER_CH) readT(ch + 1, tb[(ch + 1) & 1]);
+#pragma unroll
+            for (int grp = 0; grp < NG; ++grp)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+#if DP_BABL == 7
+                asm volatile("" ::"v"(wall[ch][mt]), "v"(tb[ch & 1][grp]));
+#else
+                acc[AB + grp * MT + mt] = mfma_bf(as_bf(wall[ch][mt]), as_bf(tb[ch & 1][grp]), acc[AB + grp * MT + mt]);
+#endif
+              }
             __builtin_amdgcn_sched_barrier(0);
-            if (ch + 1 < SUPER_CH) {
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt) wf[mt] = wn[mt];
-            }
           }
         }
+        NPROF(3);
       }
-      StageB<KIND, MODE, HALF, P + 1>::run(a, r, et, q, lane, hid, tl_base, dummy_base, sS, acc, xr);
+      StageB<KIND, MODE, HALF, P + 1>::run(a, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr, prof_prev);
     }
   }
 };
 
 // one pass (32 edge slots per node; HALF: 16) of one conv: stage the SH factors, GEMM1 -> hid (bf16 A fragments), then the path stages
 template <int KIND, int MODE, bool HALF>
-__device__ __forceinline__ void pass_bf16(const DpConvArgs& a, const Grp& grp, const Wg& r, int et, int tid, float* s_T, float* s_S,
-                                          const float* s_inv, f32x4 (&acc)[n_acc4<KIND>()]) {
+__device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t ers, const Grp& grp, const Wg& r, int et, int tid,
+                                          float* s_T, float* s_S, const float* s_inv, f32x4 (&acc)[n_acc4<KIND>()], NProfT& prof_prev) {
   const int lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
   constexpr int NT2 = HALF ? 1 : 2;
   constexpr int NSTEP = NB * NT2;
-  float* sT = s_T + q * TSTRIDE;
-  int* const s_pair = reinterpret_cast<int*>(s_T + TSTRIDE - 2 * NB * 32);     // LL mode: [2][NB][32] edge slots of the pass's pairs
+  float* sT = s_T + q * TIMG_F;
+  int* const s_pair = reinterpret_cast<int*>(s_T + TIMG_F - 2 * NB * 32);     // LL mode: [2][NB][32] edge slots of the pass's pairs
   (void)s_pair;
   __syncthreads();                               // readers of the previous pass's factors (and of s_pair / the T images) are done
   // ---- operands that do not depend on the staging: the wave's three W1 images and the pass's node rows ---------------------------
@@ -303,6 +417,7 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, const Grp& grp, c
     for (int i = 0; i < SCOMP; ++i) s_S[((nn * 2 + (el >> 4)) * SCOMP + i) * 16 + (el & 15)] = v[i];
   }
   __syncthreads();
+  NPROF(0);
 
   // ---- GEMM1: pre[e][k] = W1_emb emb[e] + u_s[scatter node] + u_g[gather node]; hid = relu(pre) / degree, as bf16 A fragments -----------
   f32x4 ug[NT2];
@@ -313,7 +428,6 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, const Grp& grp, c
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) sT[(4 * g + rr) * 16 + c] = us[rr];             // [node][k]: read back as a broadcast over rows
   }
-  const unsigned short* embb = reinterpret_cast<const unsigned short*>(a.edge_emb_bf);
   // A fragment of (node nn, 16-edge tile t2): 16 bytes of the edge's bf16 embedding row; the flag row for an edge that does not exist
   auto load_a = [&](int step, int which) {
     int nn_o = HALF ? step : step >> 1;
@@ -327,7 +441,11 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, const Grp& grp, c
       frow = (nn_o < grp.n_loc && e0 < r.En) ? feat_row<MODE>(r, grp.n_lo + nn_o, e0) : -1;
     }
     if (frow < 0) frow = a.emb_flag_row;
-    return *reinterpret_cast<const u4u*>(embb + (size_t)frow * EMB_ROW + 8 * g);
+#if DP_BABL == 9
+    return u32x4{(unsigned)frow, 0u, 0u, 7u};
+#else
+    return __builtin_amdgcn_raw_buffer_load_b128(ers, (unsigned)frow * (unsigned)(EMB_ROW * 2) + (unsigned)(16 * g), 0, 0);
+#endif
   };
   constexpr int PF = 4;
   u32x4 ea[PF + 1], eb[PF + 1];
@@ -338,51 +456,71 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, const Grp& grp, c
     if constexpr (MODE == LL) eb[s0] = load_a(s0, 1);
   }
   u32x4 hid[NB];
-  float xr0[2][3][8];
-  float us_cur = sT[c], us_nxt = 0.f, inv_cur = s_inv[0], inv_nxt = 0.f;
-  float hf[8];
+  f32x2 xr0[2][3][4];
+  XSrc xs;
+  xs.rs = xrs;
+  const unsigned gstride4 = uni((unsigned)a.gather_stride * 4u);
+  xs.voff_row = (unsigned)gather_row<MODE>(r, 32 * et + 4 * g) * gstride4;
 #pragma unroll
-  for (int step = 0; step < NSTEP; ++step) {
+  for (int j = 0; j < 8; ++j) xs.soff[j] = (unsigned)(16 * (j >> 2) + (j & 3)) * gstride4;
+  float hf[8];
+  // step = (node, 16-edge tile).  The MFMA of step s is issued into a ring of two accumulators and its activation (ReLU, mean, bf16 pack)
+  // happens one step later, so the VALU never waits on the MFMA it follows.
+  f32x4 Dg[2], Dg2[2];
+  bool has2[2] = {false, false};
+  (void)Dg2; (void)has2;
+  auto finish = [&](int step) {
     const int nn = HALF ? step : step >> 1, t2 = HALF ? 0 : step & 1;
-    const bool last_of_node = HALF || t2 == 1;
-    if (step + PF < NSTEP) {
-      ea[(step + PF) % (PF + 1)] = load_a(step + PF, 0);
-      if constexpr (MODE == LL) eb[(step + PF) % (PF + 1)] = load_a(step + PF, 1);
-    }
-    if (t2 == 0 && nn + 1 < NB) { us_nxt = sT[(nn + 1) * 16 + c]; inv_nxt = s_inv[nn + 1]; }
-    if (step == NSTEP - 3) load_x2<KIND, MODE, HALF, 0>(a, r, et, lane, 0, xr0);          // first supertile's operands: behind the last emb request
-    const f32x4 init = {us_cur + ug[t2][0], us_cur + ug[t2][1], us_cur + ug[t2][2], us_cur + ug[t2][3]};
-    const f32x4 D = mfma_bf(as_bf(ea[step % (PF + 1)]), as_bf(Wemb), init);
+    const f32x4 D = Dg[step & 1];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) hf[4 * t2 + rr] = fmaxf(D[rr], 0.f);
     if constexpr (MODE == LL) {
-      // the bond edges of the same pairs (1-4 per atom): second layer-1 evaluation over the same u_s + u_g, skipped per 16-pair tile when
-      // none of them is bonded; the pair's two hidden vectors add (same geometry, same gathered row)
-      const u32x4 b4 = eb[step % (PF + 1)];
-      // an absent bond edge reads the flag row: its slot 20 (lane group 2, third dword, low half) is 1.0
-      if (__builtin_amdgcn_ballot_w64(g == 2 && (b4[2] & 0xFFFFu) == 0u) != 0) {
-        const f32x4 D2 = mfma_bf(as_bf(b4), as_bf(Wemb), init);
+      if (has2[step & 1]) {
+        const f32x4 D2 = Dg2[step & 1];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) hf[4 * t2 + rr] += fmaxf(D2[rr], 0.f);
       }
     }
-    if (last_of_node) {
-      hid[nn] = u32x4{pk2(hf[0] * inv_cur, hf[1] * inv_cur), pk2(hf[2] * inv_cur, hf[3] * inv_cur), HALF ? 0u : pk2(hf[4] * inv_cur, hf[5] * inv_cur),
-                      HALF ? 0u : pk2(hf[6] * inv_cur, hf[7] * inv_cur)};
-      us_cur = us_nxt; inv_cur = inv_nxt;
+    if (HALF || t2 == 1) {
+      const float inv = s_inv[nn];               // scatter MEAN (1 / degree) applied to the hidden vectors: T and the output are linear in them
+      hid[nn] = u32x4{pk2(hf[0] * inv, hf[1] * inv), pk2(hf[2] * inv, hf[3] * inv), 0u, 0u};
+      if constexpr (!HALF) { hid[nn][2] = pk2(hf[4] * inv, hf[5] * inv); hid[nn][3] = pk2(hf[6] * inv, hf[7] * inv); }
     }
+  };
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    const int nn = HALF ? step : step >> 1, t2 = HALF ? 0 : step & 1;
+    if (step + PF < NSTEP) {
+      ea[(step + PF) % (PF + 1)] = load_a(step + PF, 0);
+      if constexpr (MODE == LL) eb[(step + PF) % (PF + 1)] = load_a(step + PF, 1);
+    }
+    if (step == NSTEP - 3) load_x2<KIND, MODE, HALF, 0>(xs, lane, 0, xr0);          // first supertile's operands: behind the last emb request
+    const float us_n = sT[nn * 16 + c];
+    const f32x4 init = {us_n + ug[t2][0], us_n + ug[t2][1], us_n + ug[t2][2], us_n + ug[t2][3]};
+    Dg[step & 1] = mfma_bf(as_bf(ea[step % (PF + 1)]), as_bf(Wemb), init);
+    if constexpr (MODE == LL) {
+      // the bond edges of the same pairs (1-4 per atom): second layer-1 evaluation over the same u_s + u_g, skipped per 16-pair tile when
+      // none of them is bonded; the pair's two hidden vectors add (same geometry, same gathered row).  An absent bond edge reads the
+      // flag row: its slot 20 (lane group 2, third dword, low half) is 1.0
+      const u32x4 b4 = eb[step % (PF + 1)];
+      has2[step & 1] = __builtin_amdgcn_ballot_w64(g == 2 && (b4[2] & 0xFFFFu) == 0u) != 0;
+      if (has2[step & 1]) Dg2[step & 1] = mfma_bf(as_bf(b4), as_bf(Wemb), init);
+    }
+    if (step > 0) finish(step - 1);
     __builtin_amdgcn_sched_barrier(0);
   }
+  finish(NSTEP - 1);
   if constexpr (MODE == LL) __syncthreads();      // s_pair lives in wave 0's T image: every wave is done reading it before T tiles land there
-  const unsigned tl_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(q * TSTRIDE * 4);
-  const unsigned dummy_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(4 * TSTRIDE * 4);
-  StageB<KIND, MODE, HALF, 0>::run(a, r, et, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0);
+  const unsigned tl_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(q * TIMG_B);
+  const unsigned dummy_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(4 * TIMG_B);
+  NPROF(1);
+  StageB<KIND, MODE, HALF, 0>::run(a, xs, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0, prof_prev);
 }
 
 // every pass of one conv of the (possibly fused) launch
 template <int KIND, int MODE>
 __device__ __forceinline__ void conv_bf16(const DpConvArgs& a, const Grp& grp, int tid, float* s_T, float* s_S, float* s_inv,
-                                          f32x4 (&acc)[n_acc4<KIND>()]) {
+                                          f32x4 (&acc)[n_acc4<KIND>()], NProfT& prof_prev) {
   const Wg r = wg_of<MODE>(a, grp.pose);
   __syncthreads();                                 // the previous conv's GEMM1 is done with s_inv
   if (tid < NB) {
@@ -391,29 +529,41 @@ __device__ __forceinline__ void conv_bf16(const DpConvArgs& a, const Grp& grp, i
     s_inv[tid] = 1.f / (float)max(deg, 1);         // scatter MEAN (torch_scatter: / max(count, 1)), applied to the hidden vectors
   }
   const int n_et = (r.En + 31) >> 5;
+  // buffer resources of the gathered-feature table (rows: pharmacophore nodes for phore->ligand, ligand atoms otherwise) and of the bf16
+  // edge-embedding image (+ its flag row)
+  const int g_rows = MODE == DP_EDGES_P2L ? a.ph_ptr[a.B] : a.lig_ptr[a.B];
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.gather_tab, (unsigned)g_rows * (unsigned)a.gather_stride * 4u);
+  const __amdgpu_buffer_rsrc_t ers = make_rsrc(a.edge_emb_bf, (unsigned)(a.emb_flag_row + 1) * (unsigned)(EMB_ROW * 2));
 #pragma unroll 1
   for (int et = 0; et < n_et; ++et) {
-    if (r.En - 32 * et <= 16) pass_bf16<KIND, MODE, true>(a, grp, r, et, tid, s_T, s_S, s_inv, acc);
-    else pass_bf16<KIND, MODE, false>(a, grp, r, et, tid, s_T, s_S, s_inv, acc);
+    if (r.En - 32 * et <= 16) pass_bf16<KIND, MODE, true>(a, xrs, ers, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev);
+    else pass_bf16<KIND, MODE, false>(a, xrs, ers, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev);
   }
 }
 
 template <int KIND, bool HAS_LL, int XMODE>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_bf16_kernel(FusedArgs fa) {
-  __shared__ __attribute__((aligned(128))) float s_T[4 * TSTRIDE + TDUMMY];   // wave-private T images (bf16) + the dummy column; reused for the reduction
+  __shared__ __attribute__((aligned(128))) float s_T[4 * TIMG_F + TDUM_B / 4];   // wave-private T images (bf16) + the dummy column; reused for the reduction
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];         // per-edge sh factors of the current pass (fp32)
   __shared__ float s_inv[NB];
+#if DP_BABL == 10
+  __shared__ float s_pad[2048];
+  if (threadIdx.x == 1023) s_pad[threadIdx.x] = 0.f;
+#endif
   using S = Spec<KIND>;
-  static_assert(4 * NB * S::D_OUT <= 4 * TSTRIDE, "reduction scratch fits in the T images");
+  static_assert(4 * NB * S::D_OUT <= 4 * TIMG_F, "reduction scratch fits in the T images");
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   const Grp grp = grp_of(fa.conv[0], (int)blockIdx.x);
   if (grp.n_loc <= 0) return;
   f32x4 acc[n_acc4<KIND>()];
 #pragma unroll
   for (int i = 0; i < n_acc4<KIND>(); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (HAS_LL) conv_bf16<KIND, LL>(fa.conv[0], grp, tid, s_T, s_S, s_inv, acc);
+  NProfT prof_prev{};
+  (void)prof_prev;
+  NPROF(-1);
+  if constexpr (HAS_LL) conv_bf16<KIND, LL>(fa.conv[0], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
 #pragma unroll 1
-  for (int cx = 0; cx < fa.n_x; ++cx) conv_bf16<KIND, XMODE>(fa.conv[(HAS_LL ? 1 : 0) + cx], grp, tid, s_T, s_S, s_inv, acc);
+  for (int cx = 0; cx < fa.n_x; ++cx) conv_bf16<KIND, XMODE>(fa.conv[(HAS_LL ? 1 : 0) + cx], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
   // ---- sum the four k-partials, BatchNorm shift, residual stream (mean and BatchNorm scale are inside the operands) -----------------
   {
     const DpConvArgs& a = fa.conv[0];
@@ -445,6 +595,11 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_bf16_kernel(FusedArgs fa)
       a.out[(size_t)(grp.n_lo + n) * a.out_stride + ch] = er[it] + (part + eb[it]);
     }
   }
+  NPROF(4);
+#ifdef DP_PROF
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&dpb_prof[i], prof_prev.acc[i]);
+#endif
 }
 
 template <int KIND> int launch_bf16(const FusedArgs& fa, int xmode, hipStream_t st) {

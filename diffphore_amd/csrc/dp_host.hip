@@ -204,11 +204,14 @@ int dp_work_init(const DpBatch* b, DpWork* k, void* stream) {
 #ifndef DP_ABLATE
 #define DP_ABLATE 0
 #endif
+#ifndef DP_BABL
+#define DP_BABL 0
+#endif
 int dp_build_info(DpBuildInfo* out) {
   if (!out) return DP_E_BADARG;
   memset(out, 0, sizeof(*out));
   out->abi_version = DP_ABI_VERSION;
-  out->nabl = DP_NABL;
+  out->nabl = DP_NABL ? DP_NABL : (DP_BABL ? 100 + DP_BABL : 0);      // (bf16 node-kernel ablations are reported as 100 + n)
   out->ablate = DP_ABLATE;
 #ifdef DP_PROF
   out->prof = 1;
