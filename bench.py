@@ -12,15 +12,16 @@ BASELINE configs (diffphore_amd/workloads.py).  Poses are independent: with --gp
 Timed region: W warm-up steps (untimed), state reset to the randomised start poses, then EXACTLY K steps walking the
 schedule 0..S-1 (state reset at every wrap), bracketed by barrier + synchronize; MAX over ranks.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused TP conv, the layer-2 ligand-side launch: node-side it
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fused TP conv, the layer-3 ligand-side launch: node-side it
 carries ligand-ligand + phore->ligand + phore->ligand(normals) in one launch): algorithmic flops / bytes per launch (summed over
-its convs) / mean launch duration measured with HIP events recorded inside dp_forward on the launch stream during the timed steps.  `cpu_baseline` = this repo's CPU oracle (reference-style
-torch-CPU restatement, fp32) on a bounded sample of the same workload (rank 0, N=1 only).
+its convs) / mean launch duration measured with HIP events recorded inside dp_forward on the launch stream during the timed steps;
+`roofline.step_weighted` = the same ratio over ALL node-side launches of a step (a short extra pass that brackets every launch).
+`cpu_baseline` = this repo's CPU oracle (reference-style torch-CPU restatement, fp32) on a bounded sample of the same workload
+(rank 0, N=1 only).  `config.edge_side_convs` says what the convs that stay on the edge-side kernel in an fp32 model run (bf16x6 split
+by default, fp32-grade; `alt_runs` carries the exact-fp32-everywhere arm).
 """
 import argparse
 import ctypes as C
-import hashlib
-import glob
 import json
 import os
 import socket
@@ -42,20 +43,22 @@ NODE_COLS = {0: 80, 1: 180, 2: 280, 3: 360}
 NODE_W = {0: 1000, 1: 2100, 2: 3200, 3: 4200}
 # MFMAs issued per wave per 32-edge pass: radial layer 1 (32 edge tiles x 6 + three node tiles = 16) + GEMM-A (128 per column tile) + GEMM-B
 NODE_MFMA_PER_WAVE = {0: 208 + 6 * 128 + 400, 1: 208 + 13 * 128 + 840, 2: 208 + 20 * 128 + 1280, 3: 208 + 26 * 128 + 1680}
+# the bf16-operand kernel (dp_conv_node_bf16_impl.h): GEMM1 32 edge tiles + 3 node tiles, GEMM-A ONE 16x16x32 MFMA per (node, column tile), GEMM-B
+# 5 K chunks x M tiles x m components per supertile
+NODE_MFMA_PER_WAVE_BF16 = {0: 35 + 16 * 6 + 50, 1: 35 + 16 * 13 + 105, 2: 35 + 16 * 20 + 160, 3: 35 + 16 * 26 + 210}
 MFMA_F32_PEAK_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0                                    # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
-PROF_LAYER, PROF_CONV = 2, 1                                     # layer-2 phore->ligand conv: dense cross edge set
+PREC_OF_CONFIG = {5: "bf16"}                                      # configs[4] is "bf16 mixed precision"; every other config fp32
+PROF_LAYER, PROF_CONV = 3, 1                                     # layer-3 phore->ligand conv: the launch that carries it is the step's longest
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the kernel sources: a PMC traffic figure is only quoted for the sources it was measured on."""
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "diffphore_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "diffphore_amd", "csrc", "*.h"))
-                    + glob.glob(os.path.join(ROOT, "include", "*.h"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """The hash of the kernel sources the LOADED library was compiled from (dp_build_info): a PMC traffic figure is only quoted for the
+    build it was measured on."""
+    from diffphore_amd import _lib
+    return _lib.build_info()["source_hash"]
 
 
 def measured_traffic(config, poses, precision, conv_algo):
@@ -98,6 +101,11 @@ class HipEvents:
         out = C.c_float()
         rc = self.hip.hipEventElapsedTime(C.byref(out), a, b)
         return out.value if rc == 0 else float("nan")
+
+    def elapsed(self, a, b):
+        self.hip.hipEventSynchronize(b)
+        out = C.c_float()
+        return out.value if self.hip.hipEventElapsedTime(C.byref(out), a, b) == 0 else float("nan")
 
     def destroy(self):
         for e in self.ev:
@@ -173,8 +181,9 @@ def main():
     ap.add_argument("--poses", type=int, default=None, help="configs 1-3: poses per GPU (default 512/512/256)")
     ap.add_argument("--units", type=int, default=None, help="configs 4/5: ligands / pharmacophores per GPU (x40 samples each; default 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=None, choices=["f32", "bf16x6", "bf16x9", "bf16x3"],
-                    help="arithmetic of the radial-MLP contraction (default: f32; bf16x3 for config 5, BASELINE's 'bf16 mixed precision')")
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x6", "bf16x9", "bf16x3", "bf16"],
+                    help="arithmetic of the radial-MLP contraction (default: f32; bf16 = plain bf16 operands with fp32 accumulate for config 5, "
+                         "BASELINE's 'bf16 mixed precision')")
     ap.add_argument("--conv-algo", default=None, choices=["edge", "node"], help="fused conv formulation (default: library default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the informational passes at other precisions / formulations")
     ap.add_argument("--no-e2e", action="store_true", help="skip the drop-in sampling_phore() end-to-end pass")
@@ -220,17 +229,22 @@ def main():
     margs = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
                                                                   "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
     units = (a.poses if a.config in (1, 2, 3) else a.units) or workloads.DEFAULT_UNITS[a.config]
-    precision = a.precision or ("bf16x3" if a.config == 5 else "f32")
+    precision = a.precision or (PREC_OF_CONFIG.get(a.config, "f32"))
     sd = weights.init_state_dict()
     models = {}
+
+    bcast_ms = {}
 
     def model_for(prec):
         if prec not in models:
             models[prec] = DeviceModel(sd, cfg, dev, precision=prec)
             if world > 1:
                 # the only collective of the job: weights from rank 0 to every GPU over xGMI
+                torch.cuda.synchronize()
+                t_b = time.perf_counter()
                 dist.broadcast(models[prec].blob, src=0)
                 torch.cuda.synchronize()
+                bcast_ms[prec] = (time.perf_counter() - t_b) * 1e3
         return models[prec]
 
     class Workload:
@@ -256,9 +270,21 @@ def main():
             self.sps = [_step_params(t, S, self.sched, self.sched, self.sched, t2s, margs, False, False) for t in range(S)]
             self.T_dev = torch.tensor([[float(self.sched[t])] * 3 for t in range(S)], dtype=torch.float32, device=dev)   # diffusion times, resident
 
-        def timed_run(self, mdl, conv_algo, steps, warmup, prof=True):
+        def timed_run(self, mdl, conv_algo, steps, warmup, prof=True, edge_x6=None, table_steps=0):
+            """-> dict.  `edge_x6`: "0" forces exact fp32 on the edge-side convs of an fp32 model (DIFFPHORE_EDGE_X6); `table_steps` > 0 adds an
+            untimed pass that brackets EVERY tensor-product launch of the interaction layers (DpWork.prof_events) for the per-launch table."""
             pb, B, S_total, zs, sps, nT = self.pb, self.B, self.S_total, self.zs, self.sps, self.nT
-            eng = Engine(mdl, pb, conv_algo=conv_algo)
+            keep = os.environ.get("DIFFPHORE_EDGE_X6")
+            if edge_x6 is not None:
+                os.environ["DIFFPHORE_EDGE_X6"] = edge_x6
+            try:
+                eng = Engine(mdl, pb, conv_algo=conv_algo)
+            finally:
+                if edge_x6 is not None:
+                    if keep is None:
+                        os.environ.pop("DIFFPHORE_EDGE_X6", None)
+                    else:
+                        os.environ["DIFFPHORE_EDGE_X6"] = keep
             ev = HipEvents(steps if prof else 0)
 
             def reset():
@@ -290,14 +316,22 @@ def main():
             for i in range(steps):
                 step(i, prof_idx=i if prof else None)
             torch.cuda.synchronize()
+            el_own = time.perf_counter() - t0                       # this rank's own time (before it waits for the others)
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+            rank_s = [el_own]
             if dist is not None:
                 te = torch.tensor([el], device=dev, dtype=torch.float64)
                 dist.all_reduce(te, op=dist.ReduceOp.MAX)
                 el = float(te.item())
+                allr = [torch.zeros(2, device=dev, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(allr, torch.tensor([el_own, float(B)], device=dev, dtype=torch.float64))
+                rank_s = [float(x[0].item()) for x in allr]
+                self.rank_poses = [int(x[1].item()) for x in allr]
+            else:
+                self.rank_poses = [B]
             nbad = int((eng.ws.t["status"] != 0).sum().item())
             fin = bool(torch.isfinite(pb.pos).all().item())
             kms = float(np.nanmean([ev.ms(i) for i in range(steps)])) if prof else float("nan")
@@ -308,7 +342,33 @@ def main():
                                 "ll": int((t["ll_rowend"] - t["ll_rowptr"]).sum().item()),
                                 "tor": int((t["t_rowend"] - t["t_rowptr"])[:max(nT, 0)].sum().item()) if nT else 0}
             self.prof_launch = eng.launch_of(PROF_LAYER, PROF_CONV)      # (first conv, count, node-side) of the launch the events bracket
-            return el, kms, nbad, fin, eng.conv_algo
+            table = None
+            if table_steps > 0:
+                # per-launch time table: every TP launch of the four interaction layers bracketed, one step at a time (not part of `value`)
+                launches = {}
+                for layer in range(4):
+                    for conv in range(6 if layer < 3 else 3):
+                        f, n, ns = eng.launch_of(layer, conv)
+                        launches[(layer, f)] = (n, ns)
+                te_ = HipEvents(24)
+                arr = (C.c_void_p * 48)()
+                for (layer, f) in launches:
+                    e0, e1 = te_.pair(layer * 6 + f)
+                    arr[(layer * 6 + f) * 2], arr[(layer * 6 + f) * 2 + 1] = e0, e1
+                w = eng.ws.struct
+                w.prof_events = C.cast(arr, C.c_void_p)
+                acc = {k_: [] for k_ in launches}
+                for i in range(table_steps):
+                    step(i)
+                    torch.cuda.synchronize()
+                    for (layer, f) in launches:
+                        acc[(layer, f)].append(te_.ms(layer * 6 + f))
+                w.prof_events = None
+                te_.destroy()
+                table = [{"layer": layer, "first_conv": f, "convs": n, "node_side": bool(ns), "ms": float(np.nanmean(acc[(layer, f)]))}
+                         for (layer, f), (n, ns) in sorted(launches.items())]
+            return dict(elapsed=el, kernel_ms=kms, bad=nbad, finite=fin, algo=eng.conv_algo, edge_side_convs=eng.edge_side_convs,
+                        rank_seconds=rank_s, launch_table=table)
 
     t2s = t_to_sigma_fn(margs)
     wl = Workload(a.config, units)
@@ -316,11 +376,10 @@ def main():
     sched = wl.sched
     model = model_for(precision)
 
-    def timed_run(mdl, conv_algo=None):
-        return wl.timed_run(mdl, conv_algo, a.steps, a.warmup)
-
-    elapsed, kern_ms, bad, finite, algo_used = timed_run(model, a.conv_algo)
+    main = wl.timed_run(model, a.conv_algo, a.steps, a.warmup, table_steps=min(a.steps, 10))
+    elapsed, kern_ms, bad, finite, algo_used = main["elapsed"], main["kernel_ms"], main["bad"], main["finite"], main["algo"]
     prof_launch, edge_counts = wl.prof_launch, dict(wl.edge_counts)
+    rank_poses = list(wl.rank_poses)
     pb = pb0
     totals = torch.tensor([B, int(pb.x_ptr[-1])], device=dev, dtype=torch.float64)
     if dist is not None:
@@ -331,17 +390,20 @@ def main():
     if not a.no_alt and a.config == 2 and a.precision is None and a.conv_algo is None:
         # informational passes (never the headline `value`): other precisions / the other conv formulation, same workload
         alt = []
-        for prec, algo, what in (
-                ("f32", "edge" if algo_used != "edge" else "node", "exact fp32 MFMA, the other conv formulation"),
-                ("bf16x9", None, "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
-                ("bf16x6", None, "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances")):
+        for prec, algo, x6, what in (
+                ("f32", None, "0", "exact fp32 MFMA EVERYWHERE (DIFFPHORE_EDGE_X6=0: the edge-side convs - phore-phore, torsion bonds - on the fp32 pipe too)"),
+                ("f32", "edge" if algo_used != "edge" else "node", None, "fp32 model, the other conv formulation"),
+                ("bf16x9", None, None, "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
+                ("bf16x6", None, None, "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances"),
+                ("bf16", None, None, "plain bf16 operands, fp32 accumulate (configs[4]'s precision) on the configs[1] batch: bf16-grade, 2^-9 per operand")):
             try:
-                el2, k2, bad2, fin2, algo2 = timed_run(model_for(prec), algo)
+                r2 = wl.timed_run(model_for(prec), algo, a.steps, a.warmup, edge_x6=x6)
             except Exception as e:      # noqa: BLE001 - an informational pass must never sink the headline line
                 alt.append({"precision": prec, "conv_algo": algo, "error": str(e)[:200]})
                 continue
-            alt.append({"precision": f"{prec} ({what})", "conv_algo": algo2, "value": total_poses * a.steps / el2,
-                        "ms_per_step": el2 / a.steps * 1e3, "kernel_ms": k2, "finite": fin2, "kabsch_flagged_poses": bad2})
+            alt.append({"precision": f"{prec} ({what})", "conv_algo": r2["algo"], "edge_side_convs": r2["edge_side_convs"],
+                        "value": total_poses * a.steps / r2["elapsed"], "ms_per_step": r2["elapsed"] / a.steps * 1e3, "kernel_ms": r2["kernel_ms"],
+                        "finite": r2["finite"], "kabsch_flagged_poses": r2["bad"]})
 
     e2e = None
     if not a.no_e2e and world == 1:
@@ -395,7 +457,7 @@ def main():
         c = a.config if a.config in (4, 5) else 4
         n_lib = 6 * (units if a.config in (4, 5) else workloads.DEFAULT_UNITS[c])     # 6 device batches: the pipeline's fill / drain is a sixth of the run
         lib = synthetic.ScreenLibrary(c, n_lib)
-        prec_c = "bf16x3" if c == 5 else "f32"
+        prec_c = PREC_OF_CONFIG.get(c, "f32")
         m = TensorProductScoreModel(device=dev, precision=prec_c)
         m.load_state_dict(sd)
         sargs = types.SimpleNamespace(**vars(margs), inference_steps=workloads.steps_of(c) if c == 4 else 20)
@@ -425,6 +487,51 @@ def main():
 
     n_x = int(pb.x_ptr[-1])
 
+    def launch_work(pbx, ecounts, layer, convs, prec):
+        """Work of ONE launch of interaction layer `layer` that carries `convs` (numbering of DpWork.prof_conv): node-form algorithmic flops
+        (DESIGN.md 5.1), SURVEY.md 8d's edge-side flops and operator-boundary bytes, and the MFMA flops the node-side kernel issues."""
+        nl_, np__ = [int(x) for x in pbx.nl], [int(x) for x in pbx.np_]
+        nB = len(nl_)
+        n_x_, n_ll_ = int(pbx.x_ptr[-1]), ecounts["ll"]
+        lig_side = convs[0] < 3
+        n_scat = sum(nl_) if lig_side else sum(np__)
+        edges = {c: (n_ll_ if c == 0 else n_x_) for c in convs}
+        gather = {c: (sum(nl_) if c in (0, 4, 5) else sum(np__)) for c in convs}
+        n_edges = sum(edges.values())
+        node_flops = sum(edges[c] * 2 * 61 * (20 + NODE_COLS[layer]) + n_scat * 2 * 61 * (21 + NODE_W[layer]) + gather[c] * 2 * 61 * 20 for c in convs)
+        bf = prec == "bf16"
+
+        def pass_units(n_slots):      # 32-slot passes of a node; fp32 kernel: a last pass of <= 16 slots is half a pass (bf16: GEMM-A / GEMM-B MFMAs are not halved)
+            full, rem = divmod(n_slots, 32)
+            return full + (0 if rem == 0 else (0.5 if (rem <= 16 and not bf) else 1.0))
+        scat_i = nl_ if lig_side else np__
+        slots = {c: (nl_ if (c == 0 or not lig_side) else np__) for c in convs}
+        passes = sum(((scat_i[i] + 15) // 16) * pass_units(slots[c][i]) for c in convs for i in range(nB))
+        per_wave = (NODE_MFMA_PER_WAVE_BF16 if bf else NODE_MFMA_PER_WAVE)[layer]
+        issued = passes * 4 * per_wave * (16384.0 if bf else 2048.0)
+        return dict(edges=n_edges, node_flops=node_flops, edge_flops=ALG_FLOPS_PER_EDGE[layer] * n_edges, alg_bytes=ALG_BYTES_PER_EDGE[layer] * n_edges,
+                    issued_flops=issued, workgroups=int(sum((n + 15) // 16 for n in scat_i)))
+
+    def step_weighted(pbx, ecounts, table, prec, peak):
+        """sum of node-form flops / sum of launch time over every NODE-SIDE launch of a step (from the per-launch table)"""
+        if not table:
+            return None
+        fl = tm = iss = 0.0
+        rows = []
+        for r_ in table:
+            if not r_["node_side"] or not (r_["ms"] > 0):
+                continue
+            cv = list(range(r_["first_conv"], r_["first_conv"] + r_["convs"]))
+            wk = launch_work(pbx, ecounts, r_["layer"], cv, prec)
+            fl += wk["node_flops"]; tm += r_["ms"]; iss += wk["issued_flops"]
+            rows.append({"layer": r_["layer"], "convs": cv, "ms": round(r_["ms"], 4), "TFLOPs": wk["node_flops"] / (r_["ms"] * 1e-3) / 1e12})
+        if tm <= 0:
+            return None
+        return {"achieved": fl / (tm * 1e-3) / 1e12, "frac": fl / (tm * 1e-3) / 1e12 / peak, "issued_frac": iss / (tm * 1e-3) / 1e12 / peak,
+                "node_launch_ms_per_step": tm, "launches": rows,
+                "note": "sum of node-form algorithmic flops / sum of launch times over every node-side launch of a step; launch times from an untimed "
+                        "extra pass that brackets each launch with HIP events (DpWork.prof_events), one step at a time"}
+
     other = None
     if not a.no_other and a.config == 2 and a.precision is None and a.conv_algo is None and a.poses is None:
         # every other BASELINE config in the same driver-run line (never the headline `value`): one short pass each at its default
@@ -435,54 +542,54 @@ def main():
             try:
                 t_b = time.perf_counter()
                 w2 = Workload(c, workloads.DEFAULT_UNITS[c])
-                prec_c = "bf16x3" if c == 5 else "f32"
+                prec_c = PREC_OF_CONFIG.get(c, "f32")
                 n_steps = min(w2.S_total, 20)
-                el2, _k, bad2, fin2, algo2 = w2.timed_run(model_for(prec_c), None, n_steps, 3, prof=False)
+                r2 = w2.timed_run(model_for(prec_c), None, n_steps, 3, prof=(c == 5), table_steps=(5 if c == 5 else 0))
                 tot = torch.tensor([w2.B], device=dev, dtype=torch.float64)
                 if dist is not None:
                     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-                other.append({"config": f"configs[{c - 1}]", "workload": workloads.describe(c, w2.units), "poses_per_gpu": w2.B,
-                              "poses_total": int(tot.item()), "precision": prec_c, "conv_algo": algo2, "steps": n_steps,
-                              "ms_per_step": el2 / n_steps * 1e3, "value": float(tot.item()) * n_steps / el2, "unit": "pose-steps/s",
-                              "finite": fin2, "kabsch_flagged_poses": bad2, "edge_counts": w2.edge_counts,
-                              "build_and_run_s": round(time.perf_counter() - t_b, 2)})
+                rec = {"config": f"configs[{c - 1}]", "workload": workloads.describe(c, w2.units), "poses_per_gpu": w2.B,
+                       "poses_total": int(tot.item()), "precision": prec_c, "conv_algo": r2["algo"], "edge_side_convs": r2["edge_side_convs"], "steps": n_steps,
+                       "ms_per_step": r2["elapsed"] / n_steps * 1e3, "value": float(tot.item()) * n_steps / r2["elapsed"], "unit": "pose-steps/s",
+                       "finite": r2["finite"], "kabsch_flagged_poses": r2["bad"], "edge_counts": w2.edge_counts,
+                       "build_and_run_s": round(time.perf_counter() - t_b, 2)}
+                if c == 5 and r2["kernel_ms"] > 0:
+                    # configs[4]'s own roofline: the bf16-operand node-side kernel against the dense bf16 MFMA peak
+                    f5, n5, ns5 = w2.prof_launch
+                    wk = launch_work(w2.pb, w2.edge_counts, PROF_LAYER, list(range(f5, f5 + n5)), prec_c)
+                    km = r2["kernel_ms"]
+                    rec["roofline"] = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel_ms": km,
+                                       "kernel": f"layer-{PROF_LAYER} ligand-side launch ({n5} conv(s)), bf16 operands / fp32 accumulate, node-side={bool(ns5)}",
+                                       "achieved": wk["node_flops"] / (km * 1e-3) / 1e12, "frac": wk["node_flops"] / (km * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                       "issued_frac": wk["issued_flops"] / (km * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                       "step_weighted": step_weighted(w2.pb, w2.edge_counts, r2["launch_table"], prec_c, MFMA_BF16_PEAK_TFLOPS),
+                                       "note": "this kernel is bound by VALU issue (the tensor-product operand z is built per node on the VALU) and LDS, not by "
+                                               "the matrix pipe: SQ counters in profiles/r4_bf16_node_pmc.csv (DESIGN.md 5.4)"}
+                other.append(rec)
                 del w2
             except Exception as e:      # noqa: BLE001 - an informational pass must never sink the headline line
                 other.append({"config": f"configs[{c - 1}]", "error": str(e)[:200]})
-    # The profiled launch: the one that carries layer-2 phore->ligand.  Node-side it is a FUSED launch (dp_tp_conv_node_fused): the
-    # ligand-ligand conv + phore->ligand + phore->ligand(normals) of the layer back to back into one set of accumulators, so the
-    # algorithmic work of the launch is the sum over its convs.  Edge-side it is the single conv.
+    # The profiled launch: the one that carries layer-3 phore->ligand, the longest launch of a step.  Node-side it is a FUSED launch
+    # (dp_tp_conv_node_fused): the ligand-ligand conv + phore->ligand + phore->ligand(normals) of the layer back to back into one set of
+    # accumulators, so the algorithmic work of the launch is the sum over its convs.  Edge-side it is the single conv.
     first, count, launch_node = prof_launch
     convs = list(range(first, first + count))
-    n_ll = edge_counts["ll"]
-    conv_edges = {0: n_ll, 1: n_x, 2: n_x}
-    launch_edges = sum(conv_edges[c] for c in convs)
-    alg_bytes = ALG_BYTES_PER_EDGE[PROF_LAYER] * launch_edges
-    flops = ALG_FLOPS_PER_EDGE[PROF_LAYER] * launch_edges
+    wk = launch_work(pb, edge_counts, PROF_LAYER, convs, precision)
+    launch_edges, alg_bytes, flops = wk["edges"], wk["alg_bytes"], wk["edge_flops"]
     conv_names = {0: "ligand-ligand", 1: "phore->ligand", 2: "phore->ligand(normals)"}
-    kernel_name = (f"layer-2 ligand-side launch = {' + '.join(conv_names[c] for c in convs)}"
+    kernel_name = (f"layer-{PROF_LAYER} ligand-side launch = {' + '.join(conv_names[c] for c in convs)}"
                    + (" fused into one node-side launch" if count > 1 else "") + f", conv_algo={algo_used}, precision={precision}")
+    peak = MFMA_BF16_PEAK_TFLOPS if precision != "f32" else MFMA_F32_PEAK_TFLOPS
     if launch_node:
-        n_nodes = int(pb.lig_ptr[-1])                      # scatter nodes of every conv of the launch = ligand atoms
-        n_gather = {0: int(pb.lig_ptr[-1]), 1: int(pb.ph_ptr[-1]), 2: int(pb.ph_ptr[-1])}      # gather nodes: atoms (lig-lig) / pharmacophore nodes
-        rf_flops = sum(conv_edges[c] * 2 * 61 * (20 + NODE_COLS[PROF_LAYER]) + n_nodes * 2 * 61 * (21 + NODE_W[PROF_LAYER])
-                       + n_gather[c] * 2 * 61 * 20 for c in convs)
-        rf_note = (f"node-side formulation, summed over the {count} conv(s) of the launch: 2*61*(20+280) flop per edge (edge part of radial layer 1 + "
-                   "GEMM-A) + 2*61*(21+3200) flop per scatter node (its layer-1 block + GEMM-B) + 2*61*20 per gather node, DESIGN.md 5.1; "
+        rf_flops = wk["node_flops"]
+        rf_note = (f"node-side formulation, summed over the {count} conv(s) of the launch: 2*61*(20+{NODE_COLS[PROF_LAYER]}) flop per edge (edge part of radial layer 1 + "
+                   f"GEMM-A) + 2*61*(21+{NODE_W[PROF_LAYER]}) flop per scatter node (its layer-1 block + GEMM-B) + 2*61*20 per gather node, DESIGN.md 5.1; "
                    "the edge-side count of SURVEY.md 8d is reported beside it")
-        nl_, np__ = [int(x) for x in pb.nl], [int(x) for x in pb.np_]
-        groups = int(sum((n + 15) // 16 for n in nl_))       # workgroups: 16-node groups
-
-        def pass_units(n_slots):                             # 32-slot passes of a node, a last pass of <= 16 slots counted as half a pass
-            full, rem = divmod(n_slots, 32)
-            return full + (0 if rem == 0 else (0.5 if rem <= 16 else 1.0))
-        slots = {0: nl_, 1: np__, 2: np__}                   # edge slots per scatter node: pair-dense lig-lig = atoms of the pose
-        passes = sum(((nl_[i] + 15) // 16) * pass_units(slots[c][i]) for c in convs for i in range(B))
-        issued = passes * 4 * NODE_MFMA_PER_WAVE[PROF_LAYER] * 2048.0
+        issued = wk["issued_flops"]
         rf_issue = {"executed_flops_per_launch": issued, "achieved": issued / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
-                    "frac": issued / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None, "workgroups": groups,
-                    "note": "fp32 MFMA flops actually issued (v_mfma_f32_16x16x4_f32, padding included; a half pass counted as half of a "
-                            "32-slot pass, the lig-lig conv's second layer-1 sweep over bond edges not counted) / launch time = matrix-pipe occupancy"}
+                    "frac": issued / (kern_ms * 1e-3) / 1e12 / peak if kern_ms > 0 else None, "workgroups": wk["workgroups"],
+                    "note": "MFMA flops actually issued (padding included; fp32 kernel: a half pass counted as half of a 32-slot pass, the lig-lig "
+                            "conv's second layer-1 sweep over bond edges not counted) / launch time = matrix-pipe occupancy"}
     else:
         rf_flops, rf_note, rf_issue = flops, "SURVEY.md 8d: 2*(60*60+60*numel)+TP flop per edge-conv (edge-side formulation)", None
     traffic, traffic_src = measured_traffic(a.config, B, precision, algo_used) if world == 1 else (None, None)
@@ -490,7 +597,11 @@ def main():
 
     if rank == 0:
         dtype = {"f32": "f32", "bf16x9": "f32 (bf16x9 split, exact products, fp32 accumulate)",
-                 "bf16x6": "f32 (bf16x6 split, ~2^-24 products, fp32 accumulate)", "bf16x3": "bf16x3 split (~2^-17 products), fp32 accumulate"}[precision]
+                 "bf16x6": "f32 (bf16x6 split, ~2^-24 products, fp32 accumulate)", "bf16x3": "bf16x3 split (~2^-17 products), fp32 accumulate",
+                 "bf16": "bf16 operands, fp32 accumulate"}[precision]
+        if precision == "f32" and main["edge_side_convs"] != "f32":
+            dtype = "f32 (node-side convs: exact fp32 MFMA; edge-side convs = phore-phore, torsion bonds [, ligand-ligand above 32 atoms]: bf16x6 split, ~2^-24 products, fp32 accumulate)"
+        rank_rate = [p_ * a.steps / t_ for p_, t_ in zip(rank_poses, main["rank_seconds"])]
         out = {
             "metric": "poses/sec (samples x steps) on the reverse-diffusion hot path",
             "value": total_poses * a.steps / elapsed,
@@ -504,18 +615,27 @@ def main():
                        "poses_per_gpu": B, "poses_total": total_poses, f"poses_per_sec_at_{S_total}_steps": total_poses * a.steps / elapsed / S_total,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
                        "kabsch_flagged_poses": bad, "finite": finite, "precision": precision, "conv_algo": algo_used,
+                       "edge_side_convs": main["edge_side_convs"],
+                       "edge_side_convs_note": "what the convs that stay on the edge-side kernel (phore-phore, torsion bonds; ligand-ligand above 32 atoms) run: "
+                                               "'bf16x6' = 3-way bf16 operand split, 6 cross products, fp32 accumulate (fp32-grade: same parity tolerances; the "
+                                               "library default, DpWork.edge_bf16x6 = 1), 'f32' = exact fp32 MFMA (alt_runs[0] times that arm)",
+                       "library": dict(_build_info()),
+                       "ranks": {"pose_steps_per_s": rank_rate, "seconds": main["rank_seconds"], "poses": rank_poses,
+                                 "imbalance_max_over_mean": (max(main["rank_seconds"]) / (sum(main["rank_seconds"]) / len(main["rank_seconds"]))),
+                                 "weight_broadcast_ms": bcast_ms.get(precision)},
                        "edge_counts": edge_counts, "alt_runs": alt, "e2e": e2e, "e2e_screen": e2e_screen, "other_configs": other},
             # The dominant kernel generates the per-edge TP weights on the matrix pipe in registers (they never reach HBM), so it is
-            # bound by the fp32 matrix pipe; SURVEY.md 8d asks for both views when the radial MLP is fused into the TP kernel.
-            # alg_flops_per_edge is the EDGE-SIDE count of SURVEY.md 8d (radial GEMM per edge); the node-side formulation computes
+            # bound by the matrix pipe (fp32 model) or by VALU issue (bf16 model); SURVEY.md 8d asks for both views when the radial MLP is fused into
+            # the TP kernel.  alg_flops_per_edge is the EDGE-SIDE count of SURVEY.md 8d (radial GEMM per edge); the node-side formulation computes
             # the same result with fewer flops, so its `frac` under this count can exceed what the pipe could
-            # deliver for the edge-side form - `executed_flops_per_edge` is what that launch really issues.
+            # deliver for the edge-side form - `mfma_issue` is what that launch really issues.
             "roofline": {"bound": "mfma", "achieved": rf_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
-                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": rf_flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None,
+                         "peak": peak, "unit": "TFLOP/s",
+                         "frac": rf_flops / (kern_ms * 1e-3) / 1e12 / peak if kern_ms > 0 else None,
                          "alg_flops_per_launch": rf_flops, "flop_count": rf_note,
+                         "step_weighted": step_weighted(pb, edge_counts, main["launch_table"], precision, peak),
                          "edge_side_count": {"achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
-                                             "frac": flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if kern_ms > 0 else None,
+                                             "frac": flops / (kern_ms * 1e-3) / 1e12 / peak if kern_ms > 0 else None,
                                              "note": "SURVEY.md 8d's per-edge count (radial GEMM per edge) x edges / launch time: what an edge-side "
                                                      "kernel would have to sustain for this launch time; > 1 is possible for the node-side form"},
                          "mfma_issue": rf_issue,
@@ -528,13 +648,18 @@ def main():
                                                     "HBM input, SURVEY.md 8d) / launch time; the metric's 'fused TP-scatter HBM GB/s'"},
                          "traffic_note": (f"HBM bytes per launch from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), {traffic_src}, "
                                           f"kernel sources {kernel_source_hash()}") if traffic is not None else
-                                         "null: no committed PMC profile matches these kernel sources / workload (profiles/conv_hbm_traffic.json)"},
+                                         "null: no committed PMC profile matches this library build / workload (profiles/conv_hbm_traffic.json)"},
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(graphs, sd, cfg, margs, a.cpu_poses, a.cpu_steps, S_total)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _build_info():
+    from diffphore_amd import _lib
+    return _lib.build_info()
 
 
 if __name__ == "__main__":

@@ -706,10 +706,15 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   const int slices_pl = (b->max_nl + nb - 1) / nb, slices_lp = (b->max_np + nb - 1) / nb;
   int cur = 0;
   static const int D[5] = {20, 50, 80, 100, 100};
+  auto ev_all = [&](int layer, int which, int side) -> hipEvent_t {      // DpWork.prof_events[layer][conv][start / stop]
+    return k->prof_events ? (hipEvent_t)k->prof_events[(layer * 6 + which) * 2 + side] : nullptr;
+  };
   auto timed = [&](const DpConvArgs& c, int layer, int which, hipStream_t s_) -> int {
     const bool prof = k->prof_start && k->prof_stop && k->prof_layer == layer && k->prof_conv == which;
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
+    if (ev_all(layer, which, 0)) note(hipEventRecord(ev_all(layer, which, 0), s_));
     const int r = dp_tp_conv(&c, s_);
+    if (ev_all(layer, which, 1)) note(hipEventRecord(ev_all(layer, which, 1), s_));
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
     return r;
   };
@@ -733,6 +738,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     auto timed_fused = [&](const DpConvArgs* cs, int n, int which_lo, int which_hi, hipStream_t s_) -> int {
       const bool prof = k->prof_start && k->prof_stop && k->prof_layer == l && k->prof_conv >= which_lo && k->prof_conv <= which_hi;
       if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
+      if (ev_all(l, which_lo, 0)) note(hipEventRecord(ev_all(l, which_lo, 0), s_));
       // small batches (path split on): one conv per workgroup instead of all convs back to back in one (conv split); the two sides of a
       // layer may run on two streams, so each has its own half of the scratch
       const bool lig_side = which_lo < 3;
@@ -741,6 +747,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       const bool csplit = n >= 2 && cs[0].path_split && k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)n * n_nodes * cs[0].out_stride <= half;
       const int r = csplit ? dp_tp_conv_node_fused_split(cs, n, n_nodes, k->conv_part + (lig_side ? 0 : half), half, s_)
                            : dp_tp_conv_node_fused(cs, n, s_);
+      if (ev_all(l, which_lo, 1)) note(hipEventRecord(ev_all(l, which_lo, 1), s_));
       if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
       return r;
     };

@@ -64,7 +64,7 @@ class DpWork(C.Structure):
                 + [("h_l", VOIDP * 2), ("h_p", VOIDP * 2)]
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
-                + [("prof_layer", c_i32), ("prof_conv", c_i32), ("conv_algo", c_i32)]
+                + [("prof_layer", c_i32), ("prof_conv", c_i32), ("prof_events", VOIDP), ("conv_algo", c_i32)]
                 + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
 
 

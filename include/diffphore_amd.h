@@ -299,6 +299,11 @@ typedef struct DpWork {
    * 2 phore->lig (normals), 3 phore-phore, 4 lig->phore, 5 lig->phore (normals). */
   void *prof_start, *prof_stop;
   int32_t prof_layer, prof_conv;
+  /* optional: HOST array of 4 x 6 x 2 hipEvent_t handles, [layer][conv][start, stop] in the numbering above; dp_forward brackets EVERY
+   * tensor-product launch of the interaction layers with the pair of the first conv it carries (a fused launch: its first conv; NULL
+   * handles are skipped).  For per-launch time tables (bench.py roofline.step_weighted); the events are recorded on the stream the launch
+   * runs on. */
+  void** prof_events;
   int32_t conv_algo;                /* DpConvAlgo for the dense cross convs of dp_forward */
   /* optional second stream + two hipEvent_t handles (all three or none): dp_forward then runs the pharmacophore-side convs of a
    * layer (and the torsion head) on `aux_stream`, forked from / joined back to the launch stream with the events.  Results are

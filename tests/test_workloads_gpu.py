@@ -46,7 +46,7 @@ def _start_and_noise(poses, keys, S):
                 tor=torch.from_numpy(np.concatenate(ztor, 1)))
 
 
-@pytest.mark.parametrize("cfg_id,precision,tol", [(4, "f32", 1e-4), (5, "bf16x3", 5e-3), (5, "bf16", 5e-2)])
+@pytest.mark.parametrize("cfg_id,precision,tol", [(4, "f32", 1e-4), (5, "bf16x3", 5e-3), (5, "bf16", 1e-2)])
 def test_config_workload_matches_oracle(cfg_id, precision, tol, monkeypatch):
     """2 complexes x 40 samples of the configs[3] / configs[4] generators, first steps of their schedules (20 / 100 steps), HIP vs the
     fp64 oracle on a sample of the poses; configs[4] runs BASELINE's 'bf16 mixed precision': `bf16` = plain bf16 operands with fp32
@@ -120,7 +120,7 @@ def test_configs4_full_100_step_schedule_vs_oracle(precision):
     growth = np.asarray(growth)
     print(f"configs[4] {precision}: RMSD (A) from the fp64 oracle after 20 / 40 / 60 / 80 / 100 steps, per pose:")
     for k, row in enumerate(growth):
-        print(f"   after {20 * (k + 1):3d} steps: max {row.max():.2e}  median {np.median(row):.2e}  ", np.array2string(row, precision=2))
+        print(f"   after {20 * (k + 1):3d} steps: max {row.max():.2e}  median {np.median(row):.2e}  ", " ".join(f"{v:.1e}" for v in row))
     assert np.isfinite(growth).all()
     b20, b100 = FULL_RUN_BOUNDS[precision]
     assert (growth[0] < b20).all(), (precision, growth[0])
@@ -222,4 +222,10 @@ def test_bench_self_launches_two_ranks(cfg_id, extra):
     per = {2: 24, 4: 40, 5: 40}[cfg_id]
     assert d["config"]["poses_total"] == 2 * per
     assert f"configs[{cfg_id - 1}]" in d["config"]["workload"]
-    assert d["dtype"].startswith("bf16x3" if cfg_id == 5 else "f32")
+    assert d["dtype"].startswith("bf16 operands" if cfg_id == 5 else "f32")
+    # scaling-readiness fields: per-rank rates, load imbalance of the LPT shards, the one collective's time
+    rk = d["config"]["ranks"]
+    assert len(rk["pose_steps_per_s"]) == 2 and len(rk["seconds"]) == 2 and sum(rk["poses"]) == d["config"]["poses_total"]
+    assert rk["imbalance_max_over_mean"] >= 1.0 and rk["weight_broadcast_ms"] is not None and rk["weight_broadcast_ms"] > 0
+    assert d["config"]["library"]["nabl"] == 0 and len(d["config"]["library"]["source_hash"]) == 16
+    assert d["config"]["edge_side_convs"] == ("bf16" if cfg_id == 5 else "bf16x6")
