@@ -213,7 +213,7 @@ def test_node_side_above_the_ligand_ligand_cap():
         print("node-side above the lig-lig cap, per-pose relative error vs fp64 oracle:", " ".join(f"{x:.1e}" for x in e_node))
         bad = np.nonzero(~(e_node < 1e-5))[0]
         print("poses beyond 1e-5:", bad.tolist(), "their smallest decision margin:", [float(margin[i]) for i in bad])
-        assert np.isfinite(e_node).all() and bad.size <= 2 and all(margin[i] < MARGIN_FP32 for i in bad), (e_node, margin)
+        assert np.isfinite(e_node).all() and bad.size <= max(1, len(e_node) // 8) and all(margin[i] < MARGIN_FP32 for i in bad), (e_node, margin)
         assert (e_node < 1e-5).sum() >= 18
         # and the edge-side formulation agrees with it on the same batch, tie poses included (both take the same branch)
         os.environ["DIFFPHORE_CONV_ALGO"] = "edge"

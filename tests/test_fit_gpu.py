@@ -299,7 +299,9 @@ def test_sample_step_and_fitscore_sampler_match_reference_code(golden_dir):
         res, _ = sampling_phore_with_fitscore(gs, m, S, sched, sched, sched, "cuda", t_to_sigma_fn(a2), a2, batch_size=3, **kw)
         pos = np.stack([g["ligand"].pos.numpy() for g in res])
         r = np.sqrt(((pos - G[f"{name}_pos"]) ** 2).sum(-1).mean(-1))
-        assert np.median(r) < 1e-4 and r.max() < 1e-3, (name, r)
+        # every pose within 1e-3 A of the reference's own run, and at most one of the six beyond 1e-4 (the reference itself runs in fp32:
+        # a pose that passes a discontinuous decision within fp32 resolution lands on either side - tests/test_forward_gpu.py)
+        assert (r < 1e-3).all() and int((r >= 1e-4).sum()) <= 1, (name, r)
 
 
 def test_fit_driver_matches_reference_fit(golden_dir, tmp_path):

@@ -242,13 +242,14 @@ MARGIN_FP32 = 1e-5      # a decision whose relative margin is below this cannot 
 def _assert_poses_or_decision_flip(r, margin, which, what, bound=1e-4):
     """Every pose within `bound` of the fp64 oracle.  The reference algorithm contains discontinuous decisions; a trajectory that passes
     one within fp32 resolution lands on either side depending on rounding.  A pose beyond the bound is accepted ONLY if the fp64 oracle
-    recorded such a near-tie for THAT pose (relative margin < 1e-5, named in the message), and never more than a quarter of the poses.
+    recorded such a near-tie for THAT pose (relative margin < 1e-5, named in the message), and never more than an eighth of the poses
+    (at least one; the suite has seen exactly one such pose per batch).
     (Teacher-forced single steps agree to <= 3e-6 A everywhere, and both conv formulations flip identically: tools/diag_traj*.py.)"""
     bad = np.nonzero(~(r < bound))[0]
     if bad.size == 0:
         return
     print(what, "poses beyond the bound:", bad.tolist(), "RMSD:", r[bad], "closest decision:", [(which[i], float(margin[i])) for i in bad])
-    assert np.isfinite(r).all() and bad.size <= max(1, len(r) // 4), (what, r)
+    assert np.isfinite(r).all() and bad.size <= max(1, len(r) // 8), (what, r)
     assert all(margin[i] < MARGIN_FP32 for i in bad), (what, "HIP leaves the fp64 trajectory at a pose with no near-tie decision", r, margin)
 
 

@@ -69,13 +69,32 @@ def test_full_size_equivariance():
         g["phore"].pos = g["phore"].pos @ R.T + shift
         g["phore"].norm = g["phore"].norm @ R.T
     tr2, rot2, tor2, _ = _scores(model, Engine, PackedBatch, gs2)
-    # fp32 positions are re-rounded by the rotation and a few poses sit on a discontinuity (d < 5 A, <= k A thresholds):
-    # bound the typical pose tightly and the worst few loosely
+    # fp32 positions are re-rounded by the rotation, so a pose that sits on a discontinuous decision of the reference algorithm (d < 5 A radius
+    # cuts, d_min <= k thresholds, sign of the direction MLP, |d2| < |d1|) may take the other branch after the rotation.  Every pose must be
+    # equivariant to EQ_TOL unless the fp64 oracle recorded such a decision within EQ_MARGIN for THAT pose (oracle/model.py track_margins),
+    # and never more than an eighth of the batch.
+    EQ_TOL, EQ_MARGIN = 2e-3, 1e-4
     etr = ((tr2 - tr @ R.T).norm(dim=1) / tr.norm(dim=1).clamp_min(1e-6)).numpy()
     erot = ((rot2 - rot @ R.T).norm(dim=1) / rot.norm(dim=1).clamp_min(1e-6)).numpy()
-    etor = ((tor2 - tor).abs() / tor.abs().clamp_min(1e-3)).numpy()
-    assert np.median(etr) < 1e-3 and np.median(erot) < 1e-3 and np.median(etor) < 1e-3, (np.median(etr), np.median(erot), np.median(etor))
-    assert np.quantile(etr, 0.9) < 5e-2 and np.quantile(erot, 0.9) < 5e-2
+    tor_ptr = np.concatenate([[0], np.cumsum([int(g["ligand"].edge_mask.sum()) for g in gs])])
+    etor_all = ((tor2 - tor).abs() / tor.abs().clamp_min(1e-3)).numpy()
+    etor = np.asarray([etor_all[tor_ptr[i]:tor_ptr[i + 1]].max() if tor_ptr[i + 1] > tor_ptr[i] else 0.0 for i in range(len(gs))])
+    err = np.maximum(np.maximum(etr, erot), etor)
+    bad = np.nonzero(~(err < EQ_TOL))[0]
+    print("equivariance: median", np.median(err), "max", err.max(), "poses beyond", EQ_TOL, ":", bad.tolist())
+    assert np.isfinite(err).all() and bad.size <= len(gs) // 8, (bad.size, err[bad])
+    if bad.size:
+        from oracle import sampler as osampler
+        from oracle.model import OracleScoreModel
+        from oracle.tables import load_tables
+        om = OracleScoreModel(weights.init_state_dict(), config.ModelConfig(), dtype=torch.float64, tables=load_tables())
+        om.track_margins = True
+        b = Batch.from_data_list([gs[i] for i in bad])
+        osampler.set_time_phore(b, 0.6, 0.6, 0.6, len(bad))
+        om(b)
+        margin = np.min(np.stack([v.numpy() for v in om.margins.values()]), 0)
+        print("   decision margins of those poses:", margin)
+        assert (margin < EQ_MARGIN).all(), ("a pose without a near-tie decision is not equivariant", err[bad], margin)
 
 
 def test_conformer_update_rigid_round_trip_full_size():
@@ -112,13 +131,16 @@ def test_conformer_update_rigid_round_trip_full_size():
     assert int(st.sum()) == 0
 
 
-def test_kernel_limits_large_pose():
-    """One pose near the per-pose limits (128 atoms x 128 phore nodes, 40 torsions): several workgroup slices, cap-bound radius graph."""
+@pytest.mark.parametrize("nl,nt,npn", [(128, 40, 128), (256, 128, 256)])
+def test_kernel_limits_large_pose(nl, nt, npn):
+    """One pose near / AT the per-pose kernel limits (256 atoms x 256 phore nodes x 128 torsions, engine.PackedBatch): many workgroup slices, a
+    cap-bound radius graph, eight edge passes per node - scores through dp_forward and one reverse step through dp_conformer_update vs the oracle."""
     from diffphore_amd.score_model import TensorProductScoreModel
     from oracle import sampler as osampler
     from oracle.model import OracleScoreModel
     from oracle.tables import load_tables
-    gs = synthetic.synthetic_pairs(77, 1, 128, 40, 128)
+    gs = synthetic.synthetic_pairs(77, 1, nl, nt, npn)
+    assert gs[0]["ligand"].pos.shape[0] == nl and gs[0]["phore"].pos.shape[0] == npn and int(gs[0]["ligand"].edge_mask.sum()) == nt
     sd = weights.init_state_dict()
     om = OracleScoreModel(sd, config.ModelConfig(), dtype=torch.float64, tables=load_tables())
     b = Batch.from_data_list(gs)
@@ -129,3 +151,19 @@ def test_kernel_limits_large_pose():
         tr, rot, tor = m(b)
         rel = lambda a, c: ((a.double().cpu() - c).abs().max() / c.abs().max()).item()      # noqa: E731
         assert rel(tr, tr_o) < 3e-4 and rel(rot, rot_o) < 3e-4 and rel(tor, tor_o) < 3e-4, (prec, rel(tr, tr_o), rel(rot, rot_o), rel(tor, tor_o))
+    # one reverse step on top: score model + SDE perturbation + modify_conformer with all `nt` sequential torsion rotations and the Kabsch
+    # re-alignment over `nl` atoms (dp_conformer_update) vs the fp64 oracle, same start pose and noise
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.sampling import sampling_phore
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    sched = get_t_schedule(20)[:3]
+    gen = torch.Generator().manual_seed(5)
+    noise = dict(tr=torch.randn(2, 1, 3, generator=gen), rot=torch.randn(2, 1, 3, generator=gen), tor=torch.randn(2, nt, generator=gen))
+    a, _ = osampler.sampling_phore(copy.deepcopy(gs), om, 2, sched, sched, sched, t_to_sigma_fn(args), args, batch_size=1, noise=noise)
+    m = TensorProductScoreModel(device="cuda", precision="f32").load_state_dict(sd)
+    bb, _ = sampling_phore(copy.deepcopy(gs), m, 2, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise)
+    r = float(np.sqrt(((a[0]["ligand"].pos.numpy() - bb[0]["ligand"].pos.numpy()) ** 2).sum(-1).mean()))
+    print(f"{nl} atoms x {npn} phore nodes x {nt} torsions: RMSD after two reverse steps vs the fp64 oracle {r:.2e} A")
+    assert r < 2e-4, r
