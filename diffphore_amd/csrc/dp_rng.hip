@@ -13,7 +13,7 @@
 //   stream 2  start randomisation: block 0 -> rotation (4 normals -> unit quaternion, uniform on SO(3) like scipy's Rotation.random),
 //             block 1 -> translation (3 normals); the start step is numbered DP_RNG_STEP_START
 //   stream 3  start randomisation, torsion angles: torsion j -> block j / 4, lane j % 4 (uniform in (-pi, pi))
-// Normals: Box-Muller on the (0, 1) uniforms (x >> 8 + 0.5) * 2^-24 of a block's four words (two pairs -> four normals).
+// Normals: Box-Muller on the (0, 1) uniforms ((x >> 9) + 0.5) * 2^-23 of a block's four words (two pairs -> four normals).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -37,7 +37,10 @@ __host__ __device__ inline U4 philox4x32(U4 ctr, uint32_t k0, uint32_t k1) {
   return ctr;
 }
 
-__device__ inline float unit_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }     // in (0, 1), exact in fp32
+// uniform in the OPEN interval (0, 1) from the top 23 bits of a word: (k + 1/2) 2^-23, k < 2^23 - every value is exactly representable in fp32
+// (24 significand bits hold 2 k + 1), the smallest is 2^-24 and the largest 1 - 2^-24, so log() never sees 0 and the angle never reaches 2 pi.
+// (ABI 8 used the top 24 bits, (k + 1/2) 2^-24: for k >= 2^23 the sum rounds to even - a half-ulp bias on half of the draws, and 1.0 for k = 2^24 - 1.)
+__device__ inline float unit_open(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 struct F4 { float v[4]; };
 

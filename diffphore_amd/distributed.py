@@ -6,7 +6,7 @@ The reference has no distributed code; poses are independent th
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import Optional, List, Sequence, Tuple
 
 import torch
 
@@ -117,8 +117,25 @@ def screen_plan(n_units: int, costs, rank: int, world: int, samples_per_complex:
     return [mine[lo:lo + per] for lo in range(0, len(mine), per)]
 
 
+LIMITS = dict(atoms=256, phore_nodes=256, torsions=128)       # per-pose kernel limits (engine.PackedBatch)
+
+
+def _unit_problem(g) -> Optional[str]:
+    """Why a complex cannot go on the device (None = fine): the checks `PackedBatch` would fail the WHOLE device batch with."""
+    try:
+        nl, npn = int(g["ligand"].pos.shape[0]), int(g["phore"].pos.shape[0])
+        nt = int(torch.as_tensor(g["ligand"].edge_mask).sum())
+    except Exception as e:      # noqa: BLE001 - a malformed unit is the caller's data problem, not the run's
+        return f"malformed complex: {type(e).__name__}: {e}"
+    if nl < 1 or npn < 1:
+        return "empty ligand or pharmacophore"
+    if nl > LIMITS["atoms"] or npn > LIMITS["phore_nodes"] or nt > LIMITS["torsions"]:
+        return f"over the kernel limits ({nl} atoms / {npn} pharmacophore nodes / {nt} torsions; limits {LIMITS})"
+    return None
+
+
 def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None, samples_per_complex: int = 40, device="cuda",
-           max_poses: int = 8192, seed: int = 0, on_result=None):
+           max_poses: int = 8192, seed: int = 0, on_result=None, failed: Optional[list] = None, retries: int = 2):
     """Streaming form of `fit_complexes` for library-scale screening (BASELINE configs[3] / configs[4]: 10^4-10^5 complexes x 40 samples
     per GPU).  `load_unit(i)` builds complex i on demand (featurisation, parsing, ... stay with the caller); `costs[i]` (optional, cheap:
     e.g. atoms x pharmacophore nodes) drives the LPT shard, otherwise units are dealt round-robin.  This rank
@@ -126,10 +143,16 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
         * takes ITS indices only (no rank ever builds or holds another rank's units),
         * walks them in device batches of <= max_poses poses (whole complexes), building batch k+1 - `load_unit` calls included - on the
           host while the GPU samples batch k (`sampling_phore_stream`),
-        * draws start randomisation and step noise on the device from (`seed`, pose uid = unit * samples + sample): results do not
-          depend on the world size, the batch size or the order of the stream,
+        * draws start randomisation and step noise on the device from (`seed`, pose uid = unit * samples + sample): the NOISE of a pose does
+          not depend on the world size, the batch size or the order of the stream; its trajectory is reproduced to fp32 rounding (the conv
+          formulation and workgroup slicing follow the batch a pose lands in: <= 2e-5 A, so near-tie rankings may differ between layouts),
         * hands each finished complex to `on_result(i, poses [samples, n_atoms, 3] float32)` and drops it; with on_result=None the arrays
-          are collected and returned (only sensible for small runs).
+          are collected and returned (only sensible for small runs),
+        * isolates failures per complex, as the reference's loop does with its try / except and SVD retries (src/inference.py:200-219): a
+          `load_unit` exception, a complex over the kernel limits or a sample whose Kabsch alignment fails never ends the run.  A
+          Kabsch-flagged complex is re-sampled up to `retries` times with a fresh noise key (the reference re-draws and retries up to five
+          times); what still fails is reported as `on_result(i, None)` (or a None entry of the returned list) and, when the caller passes
+          a list as `failed`, appended to it as (i, reason).
 
     Returns (indices owned by this rank in processing order - heaviest first when `costs` is given -, list of pose arrays or None).  Peak host memory: two device batches of
     pose objects, whatever the library size."""
@@ -144,29 +167,88 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
     steps = int(getattr(args, "inference_steps", 20))
     sched = get_t_schedule(steps)
 
-    def parts():
-        for bt in batches:
-            poses, uids = [], []
+    bad: dict = {}                                   # unit -> reason (never reached the device, or still flagged after the retries)
+
+    def parts_of(batch_list, loaded):
+        for bt in batch_list:
+            poses, uids, units = [], [], []
             for i in bt:
-                g = load_unit(i)
+                try:
+                    g = load_unit(i)
+                    why = _unit_problem(g)
+                except Exception as e:      # noqa: BLE001 - isolate the unit, keep streaming
+                    g, why = None, f"load_unit raised {type(e).__name__}: {e}"
+                if why is not None:
+                    bad[i] = why
+                    continue
+                units.append(i)
                 for s_ in range(samples_per_complex):
                     poses.append(g.sample_copy() if hasattr(g, "sample_copy") else __import__("copy").deepcopy(g))
                     uids.append(i * samples_per_complex + s_)
-            yield poses, uids
+            loaded.append(units)
+            if poses:
+                yield poses, uids
 
-    collected = [] if on_result is None else None
-    done = 0
-    stream = sampling_phore_stream(parts(), model, steps, sched, sched, sched, device, t_to_sigma_fn(args), args, seed=seed,
-                                   no_random=getattr(args, "no_random", False), ode=getattr(args, "ode", False),
-                                   no_final_step_noise=getattr(args, "no_final_step_noise", False),
-                                   randomize=dict(no_torsion=getattr(args, "no_torsion", False), no_random=False, tr_sigma_max=args.tr_sigma_max))
-    for part in stream:
-        for c in range(len(part) // samples_per_complex):
-            arr = torch.stack([p["ligand"].pos for p in part[c * samples_per_complex:(c + 1) * samples_per_complex]]).numpy()
-            i = mine[done]
-            done += 1
-            if on_result is not None:
-                on_result(i, arr)
+    kept = {} if on_result is None else None         # on_result=None: arrays are collected (small runs) and returned in processing order
+
+    def deliver(i, arr):
+        """a settled unit: its poses, or None (reason in `bad`)"""
+        if arr is None and failed is not None:
+            failed.append((i, bad[i]))
+        if on_result is not None:
+            on_result(i, arr)
+        else:
+            kept[i] = arr
+
+    def settle(res_of_batch, final):
+        """hand over what finished; return the units that were flagged (Kabsch) - they are failures only when `final`"""
+        flagged = []
+        for i, arr in res_of_batch:
+            if arr is not None:
+                deliver(i, arr)
+            elif final:
+                bad[i] = "Kabsch alignment failed to converge (every attempt)"
+                done_bad.add(i)
+                deliver(i, None)
             else:
-                collected.append(arr)
+                flagged.append(i)
+        return flagged
+
+    def run(batch_list, run_seed, final):
+        """stream `batch_list`; every finished complex is handed over at once, units that never reach the device are failures; -> flagged units"""
+        loaded, flagged = [], []
+        stream = sampling_phore_stream(parts_of(batch_list, loaded), model, steps, sched, sched, sched, device, t_to_sigma_fn(args), args, seed=run_seed,
+                                       no_random=getattr(args, "no_random", False), ode=getattr(args, "ode", False),
+                                       no_final_step_noise=getattr(args, "no_final_step_noise", False), isolate=True,
+                                       randomize=dict(no_torsion=getattr(args, "no_torsion", False), no_random=False, tr_sigma_max=args.tr_sigma_max))
+        k = 0
+
+        def report_bad():                             # units that never reached the device (load failure, over the limits)
+            for i in list(bad):
+                if i not in done_bad:
+                    done_bad.add(i)
+                    deliver(i, None)
+        for part, status in stream:
+            while not loaded[k]:                      # a batch whose units all failed to load produces no device batch
+                k += 1
+            out = []
+            for c, i in enumerate(loaded[k]):
+                lo, hi = c * samples_per_complex, (c + 1) * samples_per_complex
+                out.append((i, None if any(status[lo:hi]) else torch.stack([p["ligand"].pos for p in part[lo:hi]]).numpy()))
+            k += 1
+            flagged += settle(out, final)
+            report_bad()
+        report_bad()
+        return flagged
+
+    done_bad: set = set()
+    retry = run(batches, int(seed) & 0xFFFFFFFFFFFFFFFF, retries <= 0)
+    # retries of the Kabsch-flagged complexes with a fresh noise key each (the pose uids stay: only the seed changes)
+    per = max(1, max_poses // samples_per_complex)
+    for attempt in range(1, retries + 1):
+        if not retry:
+            break
+        retry = run([retry[lo:lo + per] for lo in range(0, len(retry), per)], (int(seed) + 0x9E3779B97F4A7C15 * attempt) & 0xFFFFFFFFFFFFFFFF,
+                    attempt == retries)
+    collected = None if kept is None else [kept.get(i) for i in mine]
     return mine, collected

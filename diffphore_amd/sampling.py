@@ -176,20 +176,25 @@ def _check_status(eng, synced=False):
         raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status & 1).flatten().tolist()}")
 
 
-def _finish_run(eng, part, done=None):
+def _finish_run(eng, part, done=None, raise_on_status=True):
     """Wait for the batch's loop (`done`: an event recorded behind it; None = the whole launch stream) and write the final state back.
-    The downloads run on the copy stream: on the launch stream they would queue behind the NEXT batch's loop."""
+    The downloads run on the copy stream: on the launch stream they would queue behind the NEXT batch's loop.  Returns the per-pose status
+    words (0 = ok, bit 0 = Kabsch / SVD failure, bit 1 = unrepresentable ligand multigraph); with `raise_on_status` a non-zero one raises
+    the exception the reference's callers expect for the WHOLE batch, without it the caller sorts the poses out (library screens)."""
     pb = eng.pb
     if done is not None:
         done.synchronize()
     else:
         torch.cuda.current_stream(pb.device).synchronize()
-    _check_status(eng, synced=True)
+    if raise_on_status:
+        _check_status(eng, synced=True)
+    status = d2h(eng.ws.t["status"]).tolist()
     pos, norm = d2h(pb.pos), d2h(pb.norm)
     for i, g in enumerate(part):
         lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
         g["ligand"].pos = pos[lo:hi].clone()
         g["ligand"].norm = norm[lo:hi].clone()
+    return status
 
 
 def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
@@ -260,11 +265,12 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
 
 
 def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, batch_size,
-               visualization_list, randomize, seed, write_back, timing=None):
+               visualization_list, randomize, seed, write_back, timing=None, isolate=False):
     """The device-batch pipeline behind `sampling_phore` and `sampling_phore_stream`.  `parts_iter` yields
     (pose list, noise tables | None, pre-drawn start randomisation | None, pose uids); the NEXT item is pulled - whatever lazy loading
     the iterator does included - and host-staged while the GPU runs the current batch (the step loop is enqueued without any host
-    synchronisation), so at most two batches of host objects are alive.  Yields each pose list once its results are written back."""
+    synchronisation), so at most two batches of host objects are alive.  Yields each pose list once its results are written back; with
+    `isolate` it yields (pose list, per-pose status words) and a flagged pose does not raise (the caller drops or retries its complex)."""
     import time as _time
     on_dev = seed is not None
     _t0 = _time.time()
@@ -312,27 +318,30 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
             done.synchronize()
             timing["loop_s"] = _time.time() - _t0
             _t0 = _time.time()
+        status = None
         if write_back:
-            _finish_run(eng, part, done)
+            status = _finish_run(eng, part, done, raise_on_status=not isolate)
         if timing is not None and nxt is None:
             timing["write_back_s"] = _time.time() - _t0
-        yield part
+        yield (part, status) if isolate else part
         cur = nxt
 
 
 def sampling_phore_stream(parts, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args, *, seed: int,
-                          no_random=False, ode=False, no_final_step_noise=False, randomize: Optional[dict] = None, write_back=True):
+                          no_random=False, ode=False, no_final_step_noise=False, randomize: Optional[dict] = None, write_back=True,
+                          isolate=False):
     """`sampling_phore` over a STREAM of device batches for library-scale runs (virtual screening shards 10^5 ligands x 40
     samples per GPU; the reference's loop is `for graph in dataset: [deepcopy(graph) x N] -> randomize -> sample`, inference.py:139-228).
     `parts` is an iterable (typically a generator that builds its poses lazily) of `(pose_list, pose_uids)`; each pose list is one device
     batch.  Noise - and with `randomize=` the start randomisation - is drawn on the device from (`seed`, pose uid), so nothing depends on
     how the stream is cut into batches or ranks.  A generator: yields each pose list after its final positions are written back
-    (`g['ligand'].pos`); the caller consumes and drops it, the pipeline keeps at most two batches of host objects alive."""
+    (`g['ligand'].pos`); the caller consumes and drops it, the pipeline keeps at most two batches of host objects alive.  `isolate`: yield
+    (pose list, per-pose status words) and never raise for a flagged pose (Kabsch failure): one bad ligand must not end a library run."""
     if seed is None:
         raise ValueError("the streaming sampler draws its noise on the device: seed is required")
     common = (inference_steps, tr_schedule, rot_schedule, tor_schedule)
     yield from _run_parts(((p, None, None, u) for p, u in parts), model, device, common, t_to_sigma, model_args, no_random, ode,
-                          no_final_step_noise, 20, None, randomize, int(seed), write_back)
+                          no_final_step_noise, 20, None, randomize, int(seed), write_back, isolate=isolate)
 
 
 def _host_stage_noise_only(pb, N, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise,

@@ -118,14 +118,25 @@ class TensorProductScoreModel:
 
     @classmethod
     def _cheap_key(cls, data):
-        """Identity + in-place version of every static field: O(1) per field, no device sync, no hashing.  Two calls with equal cheap
-        keys on the SAME live batch object saw the same static tensors (a replaced attribute changes `id`, an in-place write bumps
-        torch's version counter)."""
+        """Identity + in-place version of every static field: O(1) per tensor field, no device sync.  Two calls with equal cheap keys on
+        the SAME live batch object saw the same static tensors (a replaced attribute changes `id`, an in-place torch write bumps the
+        version counter).  Fields that are NOT torch tensors (numpy `mask_rotate` / lists of them) have no version counter: their
+        content is hashed (they are small: T x N booleans per complex).  What this cannot see: a write through `tensor.data` or through a
+        `.numpy()` view of a static TENSOR - replace static tensors instead of mutating them that way."""
+        import hashlib
         out = []
         for store, name in cls._STATIC_FIELDS:
             st = data[store]
             v = st[name] if name in st else None
-            out.append((id(v), getattr(v, "_version", None), tuple(v.shape) if hasattr(v, "shape") else None))
+            if v is None or torch.is_tensor(v):
+                out.append((id(v), getattr(v, "_version", None), tuple(v.shape) if v is not None else None))
+            else:
+                h = hashlib.blake2b(digest_size=8)
+                for m in (v if isinstance(v, (list, tuple)) else [v]):
+                    a = np.ascontiguousarray(np.asarray(m))
+                    h.update(str(a.shape).encode())
+                    h.update(a.tobytes())
+                out.append((id(v), h.hexdigest(), None))
         return tuple(out)
 
     def _fingerprint_cached(self, data):

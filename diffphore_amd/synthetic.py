@@ -60,14 +60,17 @@ def transformation_mask(n_atoms: int, edge_index: np.ndarray) -> Tuple[np.ndarra
 
 
 def make_ligand(rng: np.random.Generator, n_atoms: int, n_tor: int) -> dict:
-    """Random tree + a few ring closures; exactly `n_tor` rotatable bonds when the tree allows it."""
+    """Random tree + a few ring closures; exactly `n_tor` rotatable bonds when the tree allows it.  A torsion-dense request (more than one
+    rotatable bond per three atoms: the 256-atom / 128-torsion kernel-limit pose of the tests) grows long chains and closes no rings -
+    every other (n_atoms, n_tor) keeps the generator it always had."""
+    dense = 3 * n_tor > n_atoms
     for _attempt in range(200):
         parent, pos, deg = [-1], [np.zeros(3)], [0]
         ok = True
         for k in range(1, n_atoms):
             for _try in range(2000):
                 # bias toward recent atoms so chains (and therefore rotatable bridges) are common
-                p = int(rng.integers(max(0, k - 6), k)) if rng.random() < 0.7 else int(rng.integers(0, k))
+                p = int(rng.integers(max(0, k - (2 if dense else 6)), k)) if rng.random() < (0.9 if dense else 0.7) else int(rng.integers(0, k))
                 if deg[p] >= 4:
                     continue
                 v = rng.normal(size=3)
@@ -87,7 +90,7 @@ def make_ligand(rng: np.random.Generator, n_atoms: int, n_tor: int) -> dict:
         pos_a = np.asarray(pos)
         und = [(parent[k], k) for k in range(1, n_atoms)]
         have = set(und)
-        n_ring = n_atoms // 10
+        n_ring = 0 if dense else n_atoms // 10
         D = np.linalg.norm(pos_a[:, None] - pos_a[None], axis=-1)
         cand = [(a, b) for a in range(n_atoms) for b in range(a + 1, n_atoms)
                 if 2.0 <= D[a, b] <= 3.0 and (a, b) not in have and (b, a) not in have and deg[a] < 4 and deg[b] < 4]

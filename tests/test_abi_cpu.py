@@ -175,7 +175,7 @@ def test_philox_known_answers():
 def test_rng_stream_fixture_words_and_box_muller():
     """tests/golden/rng_stream.npz (made on an MI355X by make_rng_golden.py) pins the seeded noise stream: the Philox words of every
     counter are exact integers - recomputed here through the host entry point - and the device's normals / uniform angles / rotation
-    matrices follow from them by the documented construction (Box-Muller on (x >> 8 + 0.5) * 2^-24; csrc/dp_rng.hip), recomputed in
+    matrices follow from them by the documented construction (Box-Muller on ((x >> 9) + 0.5) * 2^-23, strictly inside (0, 1); csrc/dp_rng.hip), recomputed in
     numpy float64 and compared at 2e-6 (device logf / sincosf are not bit-specified)."""
     import numpy as np
     G = np.load(os.path.join(ROOT, "tests", "golden", "rng_stream.npz"))
@@ -190,7 +190,7 @@ def test_rng_stream_fixture_words_and_box_muller():
         return np.asarray(list(out), dtype=np.uint32)
 
     def unit(w):
-        return ((w >> 8).astype(np.float64) + 0.5) / 16777216.0
+        return ((w >> 9).astype(np.float64) + 0.5) / 8388608.0
 
     def normals(w):
         u = unit(w)

@@ -151,3 +151,20 @@ def test_two_ranks_plan_disjoint_shards_without_exchanging_anything():
         assert p.exitcode == 0
     a, b = ([i for bt in pl for i in bt] for pl in plans)
     assert not set(a) & set(b) and sorted(a + b) == list(range(37)) and all(len(bt) <= 10 for pl in plans for bt in pl)
+
+
+def test_unit_problem_names_what_would_sink_a_device_batch():
+    """distributed._unit_problem: the per-unit checks that keep one bad complex from failing the whole device batch of a screen"""
+    from diffphore_amd import distributed as D
+    g = synthetic.synthetic_pairs(5, 1, 12, 2, 9)[0]
+    assert D._unit_problem(g) is None
+    assert "malformed" in D._unit_problem({"ligand": None})
+    lim = dict(D.LIMITS)
+    try:
+        D.LIMITS["atoms"] = 11
+        assert "kernel limits" in D._unit_problem(g)
+        D.LIMITS.update(lim)
+        D.LIMITS["torsions"] = 1
+        assert "kernel limits" in D._unit_problem(g)
+    finally:
+        D.LIMITS.update(lim)

@@ -88,13 +88,13 @@ def test_step_normals_are_standard_normal_and_keyed_by_uid_and_step():
     # uid_base shifts the default uids
     f = _draw(PackedBatch(gs[100:110], "cuda"), 1234, 0, uid_base=100)
     assert np.array_equal(f[0], a[0][100:110])
-    # the first normal of pose 0 from the host-side Philox words (Box-Muller on (x >> 8 + 0.5) * 2^-24)
+    # the first normal of pose 0 from the host-side Philox words (Box-Muller on ((x >> 9) + 0.5) * 2^-23)
     U4, U2 = C.c_uint32 * 4, C.c_uint32 * 2
     L = _lib.lib()
     L.dp_philox4x32.argtypes = [U4, U2, U4]
     out = U4()
     L.dp_philox4x32(U4(0, 0, 0, 0), U2(1234, 0), out)
-    u = [((x >> 8) + 0.5) / 16777216.0 for x in out]
+    u = [((x >> 9) + 0.5) / 8388608.0 for x in out]
     want = [np.sqrt(-2 * np.log(u[0])) * np.cos(2 * np.pi * u[1]), np.sqrt(-2 * np.log(u[0])) * np.sin(2 * np.pi * u[1]),
             np.sqrt(-2 * np.log(u[2])) * np.cos(2 * np.pi * u[3]), np.sqrt(-2 * np.log(u[2])) * np.sin(2 * np.pi * u[3])]
     got = [a[0][0, 0], a[0][0, 1], a[0][0, 2], a[1][0, 0]]
@@ -237,6 +237,51 @@ def test_screen_stream_equals_one_call_and_keeps_two_batches_alive():
     worst = max(_rmsd(res[i][s], out[i * NS + s]["ligand"].pos.numpy()) for i in range(9) for s in range(NS))
     print("worst RMSD streamed vs one call (A):", worst)
     assert worst < 2e-5 and all(r.shape == (NS, lib.sizes(i)[0], 3) for i, r in res.items())
+
+
+def test_screen_isolates_failing_units(monkeypatch):
+    """one bad ligand must not end a library run (the reference wraps every complex in try / except and retries SVD failures,
+    src/inference.py:200-219).  A unit whose loader raises, a unit over the kernel limits and a unit whose Kabsch alignment can never
+    succeed (non-finite coordinates: flagged on every retry) are reported as failures - exactly once each, with their reasons - while
+    every other unit is delivered and equals the run of a clean library (the noise is keyed by seed and pose uid)."""
+    from diffphore_amd import distributed as D
+    lib = synthetic.ScreenLibrary(4, 8)
+    args, NS = _args(), 3
+    m = _model()
+    big = max(range(8), key=lambda i: lib.sizes(i)[0])                # the unit with the most atoms plays "over the limits"
+    monkeypatch.setitem(D.LIMITS, "atoms", lib.sizes(big)[0] - 1)
+    if any(lib.sizes(i)[0] > D.LIMITS["atoms"] for i in range(8) if i != big):
+        pytest.skip("library has several units at the largest size")
+    others = [i for i in range(8) if i != big]
+    raises, nan_unit = others[0], others[1]
+
+    def load(i):
+        if i == raises:
+            raise OSError("ligand file is corrupt")
+        g = lib.unit(i)
+        if i == nan_unit:
+            g["ligand"].pos = g["ligand"].pos * float("nan")
+        return g
+
+    got, failed, calls = {}, [], []
+    mine, coll = D.screen(8, load, m, args, costs=[lib.cost(i) for i in range(8)], samples_per_complex=NS, max_poses=2 * NS, seed=77,
+                          on_result=lambda i, arr: (calls.append(i), got.__setitem__(i, arr)), failed=failed, retries=2)
+    assert coll is None and sorted(calls) == list(range(8)), calls                      # every unit reported exactly once
+    why = dict(failed)
+    assert sorted(why) == sorted([raises, nan_unit, big]) and all(got[i] is None for i in why)
+    assert "load_unit raised OSError" in why[raises] and "kernel limits" in why[big] and "Kabsch" in why[nan_unit]
+    good = [i for i in range(8) if i not in why]
+    clean = {}
+    monkeypatch.setitem(D.LIMITS, "atoms", 256)
+    D.screen(8, lib.unit, m, args, costs=[lib.cost(i) for i in range(8)], samples_per_complex=NS, max_poses=2 * NS, seed=77,
+             on_result=lambda i, arr: clean.__setitem__(i, arr))
+    worst = max(_rmsd(got[i][s], clean[i][s]) for i in good for s in range(NS))
+    print("worst RMSD of the surviving units vs the clean library (A):", worst)
+    assert worst < 2e-5
+    # collected mode: None entries in processing order
+    monkeypatch.setitem(D.LIMITS, "atoms", lib.sizes(big)[0] - 1)
+    mine2, coll2 = D.screen(8, load, m, args, costs=[lib.cost(i) for i in range(8)], samples_per_complex=NS, max_poses=2 * NS, seed=77, retries=0)
+    assert [c is None for c in coll2] == [i in why for i in mine2]
 
 
 def _free_port():
