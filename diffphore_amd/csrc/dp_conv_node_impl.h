@@ -605,6 +605,12 @@ template <int KIND, bool HAS_LL, int XMODE> int launch_seq(const FusedArgs& fa, 
   const DpConvArgs& a = fa.conv[0];
   if (a.path_split) {
     const int n_conv = fa.conv_split ? fa.n_ll + fa.n_x : 1;
+#ifdef DP_SPLIT_LEAN      // experiment (profiles/r4_experiments.md): the path-split kernel without the half-pass variant, for batches with no short pass
+    if (fa.lean && DP_NODE_HALF_PASS) {
+      hipLaunchKernelGGL((tp_conv_node_split_kernel<KIND, HAS_LL, XMODE, false>), dim3((unsigned)(a.B * a.slices * 2 * n_conv)), dim3(256), 0, st, fa);
+      return (int)hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((tp_conv_node_split_kernel<KIND, HAS_LL, XMODE, true>), dim3((unsigned)(a.B * a.slices * 2 * n_conv)), dim3(256), 0, st, fa);
   } else if (fa.lean && DP_NODE_HALF_PASS) {
     hipLaunchKernelGGL((tp_conv_node_kernel<KIND, HAS_LL, XMODE, false>), dim3((unsigned)(a.B * a.slices)), dim3(256), 0, st, fa);

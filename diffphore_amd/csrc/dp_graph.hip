@@ -593,7 +593,7 @@ __global__ void tor_head_kernel(DpBatch b, DpWeights w, DpWork k, float* __restr
 extern "C" {
 
 // node-side convs: two workgroups per node group (DpConvArgs.path_split) while one per group leaves half of the 256 CUs x 2 slots idle
-static int node_path_split(int B, int slices) { return (long long)B * slices <= 256 ? 1 : 0; }
+static int node_path_split_auto(int B, int slices) { return (long long)B * slices <= 256 ? 1 : 0; }
 
 static int dp_check_batch(const DpBatch* b) {
   if (!b || b->B <= 0) return DP_E_BADARG;
@@ -693,6 +693,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while (B * slices < 512 && slices < 8) ++slices;
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
+  auto node_path_split = [&](int B_, int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B_, slices_)); };
   // the convs that stay edge-side in an fp32 model (phore-phore, torsion bonds) take the bf16x6 form of their radial contraction when the
   // blob carries it (DpConvW.w2x): same tolerances, 16x the matrix rate per product
   const bool edge_x6 = w->precision == DP_PREC_F32 && k->edge_bf16x6 != 0;

@@ -65,7 +65,7 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("prof_events", VOIDP), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("conv_fuse", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("path_split", c_i32), ("conv_fuse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -552,6 +552,10 @@ class Engine:
         self.ws.struct.edge_bf16x6 = int(x6)         # 1 (default): edge-side convs of an fp32 model as a bf16x6 split; 0: exact fp32 MFMA everywhere
         self.edge_side_convs = ("bf16x6" if x6 == "1" else "f32") if model.precision == "f32" else model.precision
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
+        ps = os.environ.get("DIFFPHORE_PATH_SPLIT", "auto")
+        if ps not in ("auto", "1", "0"):
+            raise ValueError(f"DIFFPHORE_PATH_SPLIT must be auto, 1 or 0 (got {ps!r})")
+        self.ws.struct.path_split = {"auto": 0, "1": 1, "0": 2}[ps]
         self._handles = None
         self._graph = None
         # second stream (DpWork.aux_stream): 'auto' runs the phore-side convs and the torsion head beside the ligand-side convs when one

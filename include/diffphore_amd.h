@@ -318,6 +318,8 @@ typedef struct DpWork {
                                        0 = exact fp32 MFMA everywhere */
   float* conv_part;                 /* [DP_CONV_PART_FLOATS] scratch of the conv-split launches of small batches (dp_tp_conv_node_fused_split) */
   float* z_noise;                   /* [6 B + n_tor] scratch of DP_NOISE_SEED: one step's z_tr | z_rot | z_tor */
+  int32_t path_split;               /* node-side fp32 convs: 0 = library's choice (two workgroups per node group while B x groups <= 256: small batches), 1 = always,
+                                       2 = never (A/B runs: profiles/r4_experiments.md) */
   int32_t conv_fuse;                /* node-side convs of a layer that scatter onto the same nodes: 0 = one fused launch per side (default),
                                        1 = one launch per conv, 2 = the two cross convs fused but the ligand-ligand conv on its own launch,
                                        3 = fused launches but never the conv split of small batches (1-3: A/B runs and tests) */
