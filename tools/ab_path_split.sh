@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the node-side fp32 kernels at configs[1] (512 poses): unsplit lean kernels (default) vs two workgroups per node group (path split:
+# A/B of the node-side fp32 kernels at configs[1] (512 poses): unsplit lean kernels (default) vs the LEAN path-split build (build first:
+# tools/build_variant.sh splitlean "-DDP_SPLIT_LEAN" dp_conv_node_k0.hip dp_conv_node_k1.hip dp_conv_node_k2.hip dp_conv_node_k3.hip) - two workgroups per node group
 # each owns half of the out slots -> half the accumulators, no spills) - step rate, per-kernel time, HBM bytes per launch (PMC).
 # -> gpurun_out/r4_ab_split_{0,1}_{bench.json,trace.txt,fetch.txt,write.txt}
 cd "$(dirname "$0")/.." || exit 1
@@ -7,7 +8,7 @@ export PYTHONPATH=. TMPDIR=/tmp
 ROOT=$PWD
 mkdir -p gpurun_out
 ROOT=$PWD
-for v in 1; do
+for v in 0 1; do
   if [ $v == 1 ]; then export DIFFPHORE_PATH_SPLIT=1 DIFFPHORE_LIB=$ROOT/build_abl/libsplitlean.so; else export DIFFPHORE_PATH_SPLIT=auto; fi
   python bench.py --steps 60 --warmup 10 --no-alt --no-e2e --no-cpu-baseline --no-other > gpurun_out/r4_ab_split_${v}_bench.json 2>/dev/null
   for c in trace FETCH_SIZE WRITE_SIZE; do
@@ -34,7 +35,7 @@ PY
 done
 python - <<'PY'
 import json
-for v in (1,):
+for v in (0, 1):
     d = json.load(open(f"gpurun_out/r4_ab_split_{v}_bench.json"))
     print("path_split", v, "pose-steps/s", round(d["value"]), "ms/step", round(d["ms_per_step"], 3), "layer-3 launch ms", round(d["roofline"]["kernel_ms"], 4))
     for f in ("trace", "FETCH_SIZE", "WRITE_SIZE"):
