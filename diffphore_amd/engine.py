@@ -35,6 +35,25 @@ class DpBatch(C.Structure):
                                         "t")])
 
 
+class DpGraphView(C.Structure):
+    _fields_ = ([(n, c_i32) for n in ("n_atoms", "n_phore", "n_bond_edges", "n_tor", "n_pp")]
+                + [(n, VOIDP) for n in ("lig_x", "bond_index", "bond_attr", "edge_mask", "mask_rotate", "phorefp", "norm_angle1", "norm_angle2",
+                                        "ph_x", "ph_pos", "ph_norm", "ph_type", "pp_index")])
+
+
+class DpPoseRef(C.Structure):
+    _fields_ = [("view", VOIDP), ("pos", VOIDP), ("norm", VOIDP)]
+
+
+_PACK_ARRAYS = ("lig_ptr", "ph_ptr", "bond_ptr", "tor_ptr", "pp_ptr", "x_ptr", "ll_ptr", "mask_ptr", "pose_ptr", "llp_ptr",
+                "lig_x", "bond_src", "bond_dst", "bond_type", "tor_u", "tor_v", "mask_rotate", "phorefp", "norm_angle1", "norm_angle2",
+                "ph_pos", "ph_norm", "ph_x", "ph_scalar", "ph_type", "pp_src", "pp_dst", "pp_rowptr", "pp_rowend", "pos", "norm")
+
+
+class DpPackLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in _PACK_ARRAYS] + [("bytes", C.c_int64)]
+
+
 class DpMlp(C.Structure):
     _fields_ = [(n, VOIDP) for n in ("w0", "b0", "w3", "b3")]
 
@@ -131,6 +150,12 @@ def _declare():
     L.dp_aux_create.restype = C.c_int
     L.dp_aux_destroy.argtypes = [VOIDP] * 3
     L.dp_aux_destroy.restype = C.c_int
+    L.dp_pack_query.argtypes = [c_i32, VOIDP, C.POINTER(DpBatch), C.POINTER(DpPackLayout)]
+    L.dp_pack_query.restype = C.c_int
+    L.dp_pack_fill.argtypes = [c_i32, VOIDP, C.POINTER(DpPackLayout), VOIDP, C.POINTER(c_i32)]
+    L.dp_pack_fill.restype = C.c_int
+    L.dp_pack_bind.argtypes = [C.POINTER(DpPackLayout), VOIDP, c_i32, C.POINTER(DpBatch)]
+    L.dp_pack_bind.restype = C.c_int
     L._dp_engine_declared = True
     return L
 
@@ -303,15 +328,164 @@ def d2h(t: torch.Tensor) -> torch.Tensor:
         return t.cpu()
 
 
+class _GraphView:
+    """HOST view of one complex's static arrays for the native collate (DpGraphView, csrc/dp_pack.hip): typed, contiguous CPU arrays (the
+    complex's own tensors wherever they already are) + the C struct pointing at them.  Cached on the graph object and shared by its samples
+    (`HeteroData.sample_copy` copies the attribute); `key` = identity + in-place version of every source object, re-checked once per device
+    batch, so a replaced or in-place edited static tensor rebuilds the view."""
+    __slots__ = ("struct", "addr", "keep", "key", "n")
+
+    @staticmethod
+    def sources(g):
+        st = getattr(g, "_stores", None)
+        if st is not None:                            # diffphore_amd.hetero.HeteroData: plain dict access (this runs once per complex and batch)
+            L, P, LL, PP = st["ligand"], st["phore"], st[("ligand", "ligand")], st[("phore", "phore")]
+            return (L["x"], LL["edge_index"], LL["edge_attr"], L["edge_mask"], L["mask_rotate"], L["phorefp"], L["norm_angle1"], L["norm_angle2"],
+                    P["x"], P["pos"], P["norm"], P["phoretype"], PP["edge_index"])
+        L, P = g["ligand"], g["phore"]
+        LL, PP = g["ligand", "ligand"], g["phore", "phore"]
+        return (L.x, LL.edge_index, LL.edge_attr, L.edge_mask, L.mask_rotate, L.phorefp, L.norm_angle1, L.norm_angle2, P.x, P.pos, P.norm,
+                P.phoretype, PP.edge_index)
+
+    @staticmethod
+    def key_of(src):
+        # identity of every source object + the in-place version counter of the tensors among them
+        return tuple([id(v) for v in src]) + tuple([v._version if hasattr(v, "_version") else 0 for v in src])
+
+    def __init__(self, g):
+        src = self.sources(g)
+        self.key = self.key_of(src)
+        x, ei, ea, em, mr, fp, na1, na2, px, ppos, pnorm, ptype, pei = src
+
+        def T(v, dt, shape=None):
+            if torch.is_tensor(v) and v.dtype == dt and v.device.type == "cpu" and v.is_contiguous() and not v.requires_grad:
+                t = v                                   # the complex's own tensor, no copy (the usual case)
+            else:
+                t = (v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))).detach().to("cpu", dt).contiguous()
+            return t.reshape(shape) if shape is not None else t
+        n = int(x.shape[0])
+        em_t = T(em, torch.bool)
+        nt = int(em_t.sum())
+        if nt > 0:
+            m = mr if isinstance(mr, np.ndarray) else (mr[0] if isinstance(mr, (list, tuple)) else mr)
+            mr_t = T(m, torch.bool)
+            if tuple(mr_t.shape) != (nt, n):
+                raise ValueError(f"mask_rotate has shape {tuple(mr_t.shape)}, expected ({nt}, {n})")
+        else:
+            mr_t = None
+        self.keep = [T(x, torch.int64), T(ei, torch.int64), T(ea, torch.float32, (-1, 4)), em_t, mr_t, T(fp, torch.float32), T(na1, torch.float32),
+                     T(na2, torch.float32), T(px, torch.float32), T(ppos, torch.float32), T(pnorm, torch.float32), T(ptype, torch.float32),
+                     T(pei, torch.int64)]
+        k = self.keep
+        if k[0].shape[1] != 16 or k[8].shape[1] != 5 or k[11].shape[1] != 11 or k[1].shape[0] != 2 or k[12].shape[0] != 2:
+            raise ValueError("complex has unexpected field shapes (ligand x [N,16], phore x [N,5], phoretype [N,11], edge_index [2,E])")
+        v = DpGraphView()
+        v.n_atoms, v.n_phore, v.n_bond_edges, v.n_tor, v.n_pp = n, int(k[8].shape[0]), int(k[1].shape[1]), nt, int(k[12].shape[1])
+        if k[2].shape[0] != v.n_bond_edges or k[3].numel() != v.n_bond_edges:
+            raise ValueError("ligand bond edge_attr / edge_mask do not match edge_index")
+        for name, t in zip(("lig_x", "bond_index", "bond_attr", "edge_mask", "mask_rotate", "phorefp", "norm_angle1", "norm_angle2", "ph_x", "ph_pos",
+                            "ph_norm", "ph_type", "pp_index"), k):
+            setattr(v, name, t.data_ptr() if t is not None else None)
+        self.struct = v
+        self.addr = C.addressof(v)
+        self.n = n
+
+    @classmethod
+    def of(cls, g, checked, by_key):
+        """the (cached) view of `g`'s complex; `checked`: views already validated for this device batch, `by_key`: the batch's views by
+        source key (samples of one complex that were copied before any of them was packed find each other here)"""
+        gv = getattr(g, "_dp_view", None)
+        if gv is not None and id(gv) in checked:
+            return gv
+        key = cls.key_of(cls.sources(g))
+        if gv is None or gv.key != key:
+            gv = by_key.get(key)
+            if gv is None:
+                gv = cls(g)
+            try:
+                object.__setattr__(g, "_dp_view", gv)
+            except (AttributeError, TypeError):
+                pass
+        by_key[key] = gv
+        checked.add(id(gv))
+        return gv
+
+
 class PackedBatch:
     """Struct-of-arrays image of a list of complexes on the device (static topology + diffusion state)."""
 
-    def __init__(self, graphs: Sequence, device, upload: bool = True):
+    def __init__(self, graphs: Sequence, device, upload: bool = True, host_pack: Optional[str] = None):
         """`upload=False` stops after the host-side packing (no device interaction at all) so that a caller can pack the next batch
-        while the GPU works on the current one; `upload()` then moves everything across in one go."""
+        while the GPU works on the current one; `upload()` then moves everything across in one go.  `host_pack`: "native" (default;
+        $DIFFPHORE_HOST_PACK) = the C collate dp_pack_query / dp_pack_fill over per-complex views, one host block, one upload; "numpy" =
+        the same packing written out in numpy (the readable form; tests hold the two equal byte for byte)."""
         self.device = torch.device(device)
+        assert len(graphs) > 0
+        host_pack = host_pack or os.environ.get("DIFFPHORE_HOST_PACK", "native")
+        if host_pack not in ("native", "numpy"):
+            raise ValueError("host_pack must be 'native' or 'numpy'")
+        self.static = None
+        self._block = None
+        if host_pack == "native":
+            self._pack_native(graphs)
+        else:
+            self._pack_numpy(graphs)
+        if upload:
+            self.upload()
+
+    def _pack_native(self, graphs):
+        L = _declare()
         B = len(graphs)
-        assert B > 0
+        refs = (DpPoseRef * B)()
+        checked, by_key, keep = set(), {}, []
+        f32 = torch.float32
+        view_of = _GraphView.of
+        flat = []                                      # (view address, pos address, norm address) per pose
+        for g in graphs:
+            gv = view_of(g, checked, by_key)
+            st = getattr(g, "_stores", None)
+            lig = st["ligand"] if st is not None else g["ligand"]
+            pos, norm = lig["pos"], lig["norm"]
+            if pos.dtype is not f32 or not pos.is_contiguous() or pos.device.type != "cpu":
+                pos = pos.detach().to("cpu", f32).contiguous()
+            if norm.dtype is not f32 or not norm.is_contiguous() or norm.device.type != "cpu":
+                norm = norm.detach().to("cpu", f32).contiguous()
+            if pos.numel() != 3 * gv.n or norm.numel() != 33 * gv.n:
+                raise ValueError("ligand pos / norm do not match the ligand's atom count")
+            keep.append((gv, pos, norm))
+            flat.append(gv.addr); flat.append(pos.data_ptr()); flat.append(norm.data_ptr())
+        # DpPoseRef is three pointers: fill the array in one go
+        flat_np = np.asarray(flat, dtype=np.uint64)
+        C.memmove(refs, flat_np.ctypes.data, 24 * B)
+        tot, lay = DpBatch(), DpPackLayout()
+        rc = L.dp_pack_query(B, C.addressof(refs), C.byref(tot), C.byref(lay))
+        if rc == -3:
+            raise ValueError("diffphore_amd kernel limits: <=256 ligand atoms, <=256 pharmacophore nodes, <=128 torsions per pose "
+                             "(or the batch is too large for int32 indexing; split it)")
+        _lib.check(rc, "dp_pack_query")
+        block = torch.empty(int(lay.bytes), dtype=torch.uint8)
+        flags = c_i32()
+        rc = L.dp_pack_fill(B, C.addressof(refs), C.byref(lay), block.data_ptr(), C.byref(flags))
+        if rc == -1:
+            raise ValueError("malformed complex in the batch: ligand bond edge_attr must be one-hot over 4 bond types, data['phore'].phoretype "
+                             "one-hot over 11 types (pdbbind_phore.py:1173), edge indices inside the complex, edge_mask / mask_rotate consistent")
+        _lib.check(rc, "dp_pack_fill")
+        del keep
+        self._block, self._layout, self._flags, self._totals = block, lay, int(flags.value), tot
+        bn = block.numpy()
+
+        def host(name, count, dt=np.int32):
+            off = int(getattr(lay, name))
+            return bn[off:off + count * np.dtype(dt).itemsize].view(dt)
+        self.B = B
+        for name in ("lig_ptr", "ph_ptr", "bond_ptr", "tor_ptr", "pp_ptr", "x_ptr", "ll_ptr", "mask_ptr", "llp_ptr"):
+            setattr(self, name, host(name, B + 1).astype(np.int64))
+        self.nl, self.np_, self.nt = np.diff(self.lig_ptr), np.diff(self.ph_ptr), np.diff(self.tor_ptr)
+        self.ll_pairs_ok = not (self._flags & 1)
+        self._n_ph = int(tot.n_ph)
+
+    def _pack_numpy(self, graphs):
+        B = len(graphs)
         nl = np.asarray([g["ligand"].pos.shape[0] for g in graphs], dtype=np.int64)
         npn = np.asarray([g["phore"].pos.shape[0] for g in graphs], dtype=np.int64)
         nb = np.asarray([g["ligand", "ligand"].edge_index.shape[1] for g in graphs], dtype=np.int64)
@@ -411,13 +585,46 @@ class PackedBatch:
         self._host_pos = torch.from_numpy(cat([l.pos for l in L], np.float32))
         self._host_norm = torch.from_numpy(np.concatenate([A(l.norm).astype(np.float32, copy=False).reshape(A(l.pos).shape[0], 33) for l in L]))
         self._n_ph = n_ph
-        self.static = None
-        if upload:
-            self.upload()
+
+    def _upload_native(self):
+        L = _declare()
+        lay, tot = self._layout, self._totals
+        dev = h2d(self._block, self.device)                    # ONE copy for the whole batch
+        self._dev_block = dev
+        base = dev.data_ptr()
+        assert base % 256 == 0
+
+        def view(name, count, dt, shape=None):
+            off = int(getattr(lay, name))
+            v = dev[off:off + count * dt.itemsize].view(dt)
+            return v.view(shape) if shape is not None else v
+        n_lig, n_ph, B = int(tot.n_lig), int(tot.n_ph), self.B
+        i32, f32, u8 = torch.int32, torch.float32, torch.uint8
+        sizes = dict(lig_ptr=B + 1, ph_ptr=B + 1, bond_ptr=B + 1, tor_ptr=B + 1, pp_ptr=B + 1, x_ptr=B + 1, ll_ptr=B + 1, mask_ptr=B + 1, pose_ptr=B + 1,
+                     llp_ptr=B + 1, lig_x=n_lig * 16, bond_src=int(tot.n_bond), bond_dst=int(tot.n_bond), bond_type=int(tot.n_bond), tor_u=int(tot.n_tor),
+                     tor_v=int(tot.n_tor), mask_rotate=max(int(self.mask_ptr[-1]), 1), phorefp=n_lig * 11, norm_angle1=n_lig * 11, norm_angle2=n_lig * 11,
+                     ph_pos=n_ph * 3, ph_norm=n_ph * 3, ph_x=n_ph * 3, ph_scalar=n_ph * 2, ph_type=n_ph, pp_src=int(tot.n_pp), pp_dst=int(tot.n_pp),
+                     pp_rowptr=n_ph, pp_rowend=n_ph)
+        fl = {"phorefp", "norm_angle1", "norm_angle2", "ph_pos", "ph_norm", "ph_scalar"}
+        self.static = {k: view(k, n, u8 if k == "mask_rotate" else (f32 if k in fl else i32)) for k, n in sizes.items()}
+        for k, cols in (("lig_x", 16), ("phorefp", 11), ("norm_angle1", 11), ("norm_angle2", 11), ("ph_pos", 3), ("ph_norm", 3), ("ph_x", 3), ("ph_scalar", 2)):
+            self.static[k] = self.static[k].view(-1, cols)
+        self.pos = view("pos", n_lig * 3, f32, (n_lig, 3))
+        self.norm = view("norm", n_lig * 33, f32, (n_lig, 33))
+        self.t = torch.zeros(B, 3, dtype=f32, device=self.device)
+        s = DpBatch()
+        C.memmove(C.byref(s), C.byref(tot), C.sizeof(DpBatch))
+        _lib.check(L.dp_pack_bind(C.byref(lay), base, self._flags, C.byref(s)), "dp_pack_bind")
+        s.t = self.t.data_ptr()
+        self.struct = s
+        self._block = None
+        return self
 
     def upload(self):
         if self.static is not None:
             return self
+        if self._block is not None:
+            return self._upload_native()
         B, nl, npn, nt, n_ph = self.B, self.nl, self.np_, self.nt, self._n_ph
         self.static = {k: h2d(v, self.device) for k, v in self._host.items()}
         self.pos = h2d(self._host_pos, self.device)

@@ -192,8 +192,8 @@ def _finish_run(eng, part, done=None, raise_on_status=True):
     pos, norm = d2h(pb.pos), d2h(pb.norm)
     for i, g in enumerate(part):
         lo, hi = int(pb.lig_ptr[i]), int(pb.lig_ptr[i + 1])
-        g["ligand"].pos = pos[lo:hi].clone()
-        g["ligand"].norm = norm[lo:hi].clone()
+        g["ligand"].pos = pos[lo:hi]                   # (disjoint row ranges of the batch's host copy: no per-pose clone)
+        g["ligand"].norm = norm[lo:hi]
     return status
 
 

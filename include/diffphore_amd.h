@@ -229,6 +229,46 @@ typedef struct DpBatch {
   const float* t;             /* [B,3] diffusion times (tr, rot, tor) per pose            diffusion_utils.py:181-207 */
 } DpBatch;
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Native collate (csrc/dp_pack.hip, HOST code - callable without a GPU).  Stands where the reference builds a PyG batch of the pose list
+ * (DataLoader / Batch.from_data_list, src/utils/sampling.py:210-215): one call turns N poses into the DpBatch image.  All pointers below
+ * are HOST pointers into the caller's own tensors (reference field names in the comments); the samples of one complex share ONE view.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct DpGraphView {
+  int32_t n_atoms, n_phore, n_bond_edges, n_tor, n_pp;
+  const int64_t* lig_x;         /* data['ligand'].x            [n_atoms,16] int64 */
+  const int64_t* bond_index;    /* data['ligand','ligand'].edge_index [2,n_bond_edges] int64, local atom ids */
+  const float* bond_attr;       /* .edge_attr                  [n_bond_edges,4] one-hot */
+  const uint8_t* edge_mask;     /* data['ligand'].edge_mask    [n_bond_edges] bool: rotatable bonds, n_tor of them set */
+  const uint8_t* mask_rotate;   /* .mask_rotate                [n_tor,n_atoms] bool (NULL when n_tor == 0) */
+  const float *phorefp, *norm_angle1, *norm_angle2;   /* [n_atoms,11] */
+  const float* ph_x;            /* data['phore'].x             [n_phore,5] float: type, is-EX idx, has-norm idx, alpha, weight */
+  const float *ph_pos, *ph_norm;                      /* [n_phore,3] */
+  const float* ph_type;         /* .phoretype                  [n_phore,11] one-hot */
+  const int64_t* pp_index;      /* data['phore','phore'].edge_index [2,n_pp] int64, local node ids */
+} DpGraphView;
+typedef struct DpPoseRef {
+  const DpGraphView* view;      /* the pose's complex */
+  const float* pos;             /* data['ligand'].pos  [n_atoms,3]  (this sample's diffusion state) */
+  const float* norm;            /* data['ligand'].norm [n_atoms,33] */
+} DpPoseRef;
+/* byte offsets of every DpBatch array inside the ONE block dp_pack_fill writes (256-byte aligned segments); `bytes` = size of the block */
+typedef struct DpPackLayout {
+  int64_t lig_ptr, ph_ptr, bond_ptr, tor_ptr, pp_ptr, x_ptr, ll_ptr, mask_ptr, pose_ptr, llp_ptr;
+  int64_t lig_x, bond_src, bond_dst, bond_type, tor_u, tor_v, mask_rotate, phorefp, norm_angle1, norm_angle2;
+  int64_t ph_pos, ph_norm, ph_x, ph_scalar, ph_type, pp_src, pp_dst, pp_rowptr, pp_rowend, pos, norm;
+  int64_t bytes;
+} DpPackLayout;
+/* totals (B, n_*, max_*) of the batch into *totals and the block layout into *layout; DP_E_TOOLARGE for a pose over the kernel limits
+ * (256 atoms / 256 pharmacophore nodes / 128 torsions) or a batch beyond int32 edge indexing */
+int dp_pack_query(int32_t n, const DpPoseRef* poses, DpBatch* totals, DpPackLayout* layout);
+/* fill a HOST block of layout->bytes: CSR offsets, concatenated static arrays with global ids, one-hots as indices, pharmacophore edges
+ * sorted by source (stable), pos / norm.  *flags: bit 0 = a ligand lists the same ordered bond twice (no pair tables), bit 1 / 2 = some
+ * pose ends on a short ligand / pharmacophore pass (the no_tail hints).  DP_E_BADARG for a malformed view (not one-hot, ids out of range). */
+int dp_pack_fill(int32_t n, const DpPoseRef* poses, const DpPackLayout* layout, void* host_block, int32_t* flags);
+/* set the pointer fields of *b (and llp / no_tail from `flags`) to a block at `base` - typically the DEVICE copy of the filled block */
+int dp_pack_bind(const DpPackLayout* layout, void* base, int32_t flags, DpBatch* b);
+
 typedef struct DpMlp { const float *w0, *b0, *w3, *b3; } DpMlp;   /* nn.Sequential(Linear, act, Dropout, Linear) */
 typedef struct DpConvW {
   const float *w1p, *w2p, *bn_scale, *bn_shift;

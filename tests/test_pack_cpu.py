@@ -1,0 +1,116 @@
+"""The native collate (csrc/dp_pack.hip: dp_pack_query / dp_pack_fill / dp_pack_bind, host code) against the numpy packer it replaces
+(engine.PackedBatch._pack_numpy, the readable statement of the layout): every array of the DpBatch image byte for byte, the totals, the
+hints and the error behaviour.  The reference's counterpart is PyG's Batch.from_data_list over the pose list (src/utils/sampling.py:210-215).
+No GPU: both packers are host code."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from diffphore_amd import engine, synthetic
+from diffphore_amd.engine import PackedBatch
+
+
+def _native_arrays(pb):
+    lay, tot, bn = pb._layout, pb._totals, pb._block.numpy()
+    B, n_lig, n_ph = pb.B, int(tot.n_lig), int(tot.n_ph)
+    cnt = dict(lig_ptr=B + 1, ph_ptr=B + 1, bond_ptr=B + 1, tor_ptr=B + 1, pp_ptr=B + 1, x_ptr=B + 1, ll_ptr=B + 1, mask_ptr=B + 1, pose_ptr=B + 1,
+               llp_ptr=B + 1, lig_x=n_lig * 16, bond_src=tot.n_bond, bond_dst=tot.n_bond, bond_type=tot.n_bond, tor_u=tot.n_tor, tor_v=tot.n_tor,
+               mask_rotate=int(pb.mask_ptr[-1]), phorefp=n_lig * 11, norm_angle1=n_lig * 11, norm_angle2=n_lig * 11, ph_pos=n_ph * 3, ph_norm=n_ph * 3,
+               ph_x=n_ph * 3, ph_scalar=n_ph * 2, ph_type=n_ph, pp_src=tot.n_pp, pp_dst=tot.n_pp, pp_rowptr=n_ph, pp_rowend=n_ph, pos=n_lig * 3,
+               norm=n_lig * 33)
+    fl = {"phorefp", "norm_angle1", "norm_angle2", "ph_pos", "ph_norm", "ph_scalar", "pos", "norm"}
+    out = {}
+    for k, n in cnt.items():
+        dt = np.uint8 if k == "mask_rotate" else (np.float32 if k in fl else np.int32)
+        off = int(getattr(lay, k))
+        assert off % 256 == 0
+        out[k] = bn[off:off + int(n) * np.dtype(dt).itemsize].view(dt).copy()
+    return out
+
+
+def _batch():
+    gs = synthetic.synthetic_pairs(31, 5, (9, 40), (0, 9), (6, 70))                 # ragged ligands / pharmacophores, some without torsions
+    gs += synthetic.synthetic_pairs(32, 1, 16, 7, 33)                               # N_l = 16, N_p = 33: both "short last pass" hints
+    poses = [g.sample_copy() for g in gs for _ in range(3)]                        # samples share their complex's static tensors
+    for k, p in enumerate(poses):
+        p["ligand"].pos = p["ligand"].pos + 0.01 * k                              # ... and own their diffusion state
+    return poses
+
+
+def test_native_pack_equals_numpy_pack():
+    poses = _batch()
+    a = PackedBatch(poses, "cpu", upload=False, host_pack="native")
+    b = PackedBatch(poses, "cpu", upload=False, host_pack="numpy")
+    na = _native_arrays(a)
+    for k, v in b._host.items():
+        w = v.numpy().reshape(-1)
+        if k == "mask_rotate" and int(b.mask_ptr[-1]) == 0:
+            continue
+        assert np.array_equal(na[k], w.view(na[k].dtype) if w.dtype != na[k].dtype and w.dtype.itemsize == na[k].dtype.itemsize else w.astype(na[k].dtype)), k
+    assert np.array_equal(na["pos"], b._host_pos.numpy().reshape(-1)) and np.array_equal(na["norm"], b._host_norm.numpy().reshape(-1))
+    for k in ("lig_ptr", "ph_ptr", "bond_ptr", "tor_ptr", "pp_ptr", "x_ptr", "ll_ptr", "mask_ptr", "llp_ptr"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert np.array_equal(a.nl, b.nl) and np.array_equal(a.np_, b.np_) and np.array_equal(a.nt, b.nt) and a.ll_pairs_ok == b.ll_pairs_ok
+    # totals and hints of the DpBatch the numpy path would fill
+    t = a._totals
+    assert (t.B, t.n_lig, t.n_ph, t.n_bond, t.n_tor, t.n_pp, t.n_x, t.ll_cap, t.n_llp) == (
+        len(poses), int(b.lig_ptr[-1]), int(b.ph_ptr[-1]), int(b.bond_ptr[-1]), int(b.tor_ptr[-1]), int(b.pp_ptr[-1]), int(b.x_ptr[-1]), int(b.ll_ptr[-1]),
+        int(b.llp_ptr[-1]))
+    assert (t.max_nl, t.max_np, t.max_t) == (int(b.nl.max()), int(b.np_.max()), int(b.nt.max()))
+    assert a._flags & 2 and a._flags & 4                                            # the 16-atom / 33-node complex ends on short passes
+    # dp_pack_bind: pointers = base + offsets, hints from the flags
+    s = engine.DpBatch()
+    L = engine._declare()
+    assert L.dp_pack_bind(C.byref(a._layout), 1 << 30, a._flags, C.byref(s)) == 0
+    assert s.lig_x == (1 << 30) + a._layout.lig_x and s.norm == (1 << 30) + a._layout.norm and s.no_tail_nl == 0 and s.no_tail_np == 0
+
+
+def test_views_are_cached_per_complex_and_rebuilt_when_a_static_changes():
+    gs = synthetic.synthetic_pairs(33, 2, 12, 3, 10)
+    poses = [g.sample_copy() for g in gs for _ in range(4)]
+    PackedBatch(poses, "cpu", upload=False, host_pack="native")
+    views = {id(p._dp_view) for p in poses}
+    assert len(views) == 2                                                          # one view per complex, shared by its samples
+    v0 = poses[0]._dp_view
+    PackedBatch(poses, "cpu", upload=False, host_pack="native")
+    assert poses[0]._dp_view is v0                                                  # reused
+    poses[0]["ligand"].phorefp = poses[0]["ligand"].phorefp.clone()                 # a replaced static tensor on ONE sample
+    a = PackedBatch(poses, "cpu", upload=False, host_pack="native")
+    assert poses[0]._dp_view is not v0 and poses[1]._dp_view is v0
+    poses[1]["ligand"].x[0, 1] = (poses[1]["ligand"].x[0, 1] + 1) % 4               # an in-place edit (shared by samples 1-3 of complex 0)
+    a = PackedBatch(poses, "cpu", upload=False, host_pack="native")
+    b = PackedBatch(poses, "cpu", upload=False, host_pack="numpy")
+    assert np.array_equal(_native_arrays(a)["lig_x"], b._host["lig_x"].numpy().reshape(-1))
+
+
+def test_native_pack_rejects_what_the_numpy_packer_rejects():
+    gs = synthetic.synthetic_pairs(34, 2, 12, 3, 10)
+    bad = gs[1]
+    pt = bad["phore"].phoretype.clone()
+    pt[0] = 0.0
+    bad["phore"].phoretype = pt
+    for hp in ("native", "numpy"):
+        with pytest.raises(ValueError, match="one-hot"):
+            PackedBatch(gs, "cpu", upload=False, host_pack=hp)
+    gs = synthetic.synthetic_pairs(34, 2, 12, 3, 10)
+    ea = gs[0]["ligand", "ligand"].edge_attr.clone()
+    ea[0] = torch.tensor([0.5, 0.5, 0.0, 0.0])
+    gs[0]["ligand", "ligand"].edge_attr = ea
+    for hp in ("native", "numpy"):
+        with pytest.raises(ValueError, match="one-hot"):
+            PackedBatch(gs, "cpu", upload=False, host_pack=hp)
+    L = engine._declare()
+    assert L.dp_pack_query(0, None, None, None) == -1
+
+
+def test_repeated_ordered_bond_is_flagged_by_both_packers():
+    gs = synthetic.synthetic_pairs(5, 2, 10, 2, 8)
+    g = gs[1]
+    ei, ea = g["ligand", "ligand"].edge_index, g["ligand", "ligand"].edge_attr
+    g["ligand", "ligand"].edge_index = torch.cat([ei, ei[:, :1]], 1)
+    g["ligand", "ligand"].edge_attr = torch.cat([ea, ea[:1]], 0)
+    g["ligand"].edge_mask = torch.cat([torch.as_tensor(g["ligand"].edge_mask), torch.zeros(1, dtype=torch.bool)])
+    for hp in ("native", "numpy"):
+        assert not PackedBatch(gs, "cpu", upload=False, host_pack=hp).ll_pairs_ok
