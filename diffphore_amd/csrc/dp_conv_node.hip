@@ -7,14 +7,6 @@
 
 #include "dp_conv_node_bf16_impl.h"
 
-#ifdef DP_PROF
-__device__ unsigned long long dpn_prof[16];
-extern "C" int dp_debug_prof_node(unsigned long long* host16, int reset) {
-  if (host16 && hipMemcpyFromSymbol(host16, HIP_SYMBOL(dpn_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(dpn_prof), z, sizeof(z)) != hipSuccess) return -1; }
-  return 0;
-}
-#endif
 
 namespace dpn {
 

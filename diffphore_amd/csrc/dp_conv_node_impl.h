@@ -41,20 +41,25 @@
 #include "../../include/diffphore_amd.h"
 #include "dp_spec.h"
 
-#ifdef DP_PROF   // cycle-stamp breakdown (ablation builds only; tools/bench_conv.py --prof): wave 0 of every workgroup adds its segment times
-extern __device__ unsigned long long dpn_prof[16];
-struct NProf { unsigned long long prev, acc[5]; };
+#ifdef DP_PROF   // cycle-stamp breakdown (timing builds only: tools/build_variant.sh prof "-DDP_PROF" dp_conv_node_k3.hip): wave 0 of every workgroup
+                 // adds its segment times; one counter array per translation unit (no relocatable device code), read through dp_debug_prof_node.
+                 // Bins: 4 * conv + {0 staging, 1 GEMM1, 2 GEMM-A, 3 GEMM-B} for the convs of a fused launch (conv 0 = ligand-ligand), 12 = k-partial
+                 // reduction + epilogue, 13 = workgroup prologue (the bf16 kernel uses bins 0..4 only)
+static __device__ unsigned long long dpn_prof[16];
+struct NProf { unsigned long long prev, acc[16]; int base; };
 __device__ __forceinline__ void nprof_mark(int seg, NProf& p) {
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long now = __builtin_readcyclecounter();
-  if (seg >= 0) p.acc[seg] += now - p.prev;
+  if (seg >= 0) p.acc[seg < 4 ? p.base + seg : seg] += now - p.prev;
   p.prev = now;
   __builtin_amdgcn_sched_barrier(0);
 }
 #define NPROF(seg) nprof_mark(seg, prof_prev)
+#define NPROF_CONV(c) prof_prev.base = 4 * (c)
 typedef NProf NProfT;
 #else
 #define NPROF(seg)
+#define NPROF_CONV(c)
 typedef int NProfT;
 #endif
 

@@ -26,6 +26,7 @@
     if (cx_only <= 0) {
       constexpr int MODE = LL;
       const DpConvArgs& a = fa.conv[0];
+      NPROF_CONV(0);
 #include "dp_conv_node_conv.h"
     }
   }
@@ -34,6 +35,7 @@
     if (cx_only >= 0 && cx_only != (HAS_LL ? 1 : 0) + cx) continue;
     constexpr int MODE = XMODE;
     const DpConvArgs& a = fa.conv[(HAS_LL ? 1 : 0) + cx];
+    NPROF_CONV((HAS_LL ? 1 : 0) + cx);
 #include "dp_conv_node_conv.h"
   }
 
@@ -74,8 +76,8 @@
       else fa.part[(size_t)cx_only * fa.part_stride + (size_t)(grp.n_lo - fa.node0 + n) * a.out_stride + ch] = part;   // summed by dp_conv_node_combine
     }
   }
-  NPROF(4);
+  NPROF(12);
 #ifdef DP_PROF
   if ((threadIdx.x & 63) == 0)
-    for (int i = 0; i < 5; ++i) atomicAdd(&dpn_prof[i], prof_prev.acc[i]);
+    for (int i = 0; i < 16; ++i) atomicAdd(&dpn_prof[i], prof_prev.acc[i]);
 #endif
