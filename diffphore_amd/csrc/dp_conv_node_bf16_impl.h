@@ -77,6 +77,8 @@ __device__ __forceinline__ unsigned pk2(float lo, float hi) {       // v_cvt_pk_
   const bf16x2 v = __builtin_convertvector((f32x2){lo, hi}, bf16x2);
   return __builtin_bit_cast(unsigned, v);
 }
+// ReLU as ONE instruction (v_med3_f32 x, 0, +inf): fmaxf(x, 0) compiles to two (a canonicalising v_max x, x first)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 __device__ __forceinline__ bf16x8 as_bf(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
@@ -473,12 +475,12 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_r
     const int nn = HALF ? step : step >> 1, t2 = HALF ? 0 : step & 1;
     const f32x4 D = Dg[step & 1];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) hf[4 * t2 + rr] = fmaxf(D[rr], 0.f);
+    for (int rr = 0; rr < 4; ++rr) hf[4 * t2 + rr] = relu1(D[rr]);
     if constexpr (MODE == LL) {
       if (has2[step & 1]) {
         const f32x4 D2 = Dg2[step & 1];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) hf[4 * t2 + rr] += fmaxf(D2[rr], 0.f);
+        for (int rr = 0; rr < 4; ++rr) hf[4 * t2 + rr] += relu1(D2[rr]);
       }
     }
     if (HALF || t2 == 1) {
