@@ -1,6 +1,6 @@
 """Oracle restatement of the e3nn==0.5.1 operators the score model calls (TEST INFRASTRUCTURE ONLY).
 
-e3nn is NOT under /root/reference (pinned in `src/environment_diffphore.yml:283`); its algorithm is restated from the
+e3nn is NOT under /root/reference (pinned in `src/environment_diffphore.yml:117`); its algorithm is restated from the
 published definitions.  Call sites in the reference that these functions stand in for:
 
   o3.spherical_harmonics(irreps, v, normalize=True, normalization='component')

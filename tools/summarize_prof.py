@@ -127,7 +127,7 @@ def main():
                 if f and w:
                     fa, wa = sum(f) / len(f), sum(w) / len(w)
                     res.append(f"{k},{sname},{len(f)},{fa:.1f},{wa:.1f},{2 * fa / 1024:.2f},{wa / 1024:.2f}")
-                    if (k.startswith("tp_conv_node_kernel<2, true, 1, ")) or (k == "tp_conv_kernel<2>" and sname == "phore->lig"):
+                    if (k.startswith("tp_conv_node_kernel<3, true, 1, ")) or (k == "tp_conv_kernel<3>" and sname == "phore->lig"):      # bench.py PROF_LAYER = 3
                         rec = int((2 * fa + wa) * 1024)
         open(f"{a.prefix}_conv_hbm_traffic.csv", "w").write("\n".join(res) + "\n")
         if rec is not None and bench is not None:
