@@ -54,7 +54,7 @@ def main():
         ztr, zrot = torch.randn(S, B, 3, device="cuda", generator=g), torch.randn(S, B, 3, device="cuda", generator=g)
         ztor = torch.randn(S, int(pb.tor_ptr[-1]), device="cuda", generator=g)
         row = dict(poses=B)
-        for algo in (["edge", "node"] if a.precision == "f32" else ["edge"]):
+        for algo in (["edge", "node"] if a.precision in ("f32", "bf16") else ["edge"]):
             for drv in ("steps", "loop", "graph", "graph+2s"):
                 eng = Engine(model, pb, conv_algo=algo)
                 if drv == "graph+2s":
