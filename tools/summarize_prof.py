@@ -24,6 +24,10 @@ for k in range(4):
             SLOTS[f"{kn}<{k}, true, 1, {h}>"] = [LIG3]
             SLOTS[f"{kn}<{k}, false, 1, {h}>"] = [LIG2]
             SLOTS[f"{kn}<{k}, false, 2, {h}>"] = [PH2]
+    for kn in ("tp_conv_node_bf16_kernel",):                  # precision="bf16": <KIND, HAS_LL, XMODE>
+        SLOTS[f"{kn}<{k}, true, 1>"] = [LIG3]
+        SLOTS[f"{kn}<{k}, false, 1>"] = [LIG2]
+        SLOTS[f"{kn}<{k}, false, 2>"] = [PH2]
 SLOTS["tp_conv_kernel<4>"] = ["centre (final_conv)"]
 SLOTS["tp_conv_kernel<5>"] = ["torsion bonds (tor_bond_conv)"]
 # SURVEY.md 8d per edge-conv (edge-side count): 2*(n_attr*hid + hid*numel) + 2*sum_paths mul_in*mul_out*(2 l_out + 1); kinds 4 / 5 = the
@@ -34,7 +38,7 @@ EDGE_SET = {LIG3: ("ll", "x", "x"), LIG2: ("x", "x"), PH2: ("x", "x"), "lig-lig"
 
 
 def short(name):
-    name = name.replace("void ", "").replace("dp::", "").replace("dpn::", "")
+    name = name.replace("void ", "").replace("dp::", "").replace("dpn::", "").replace("dpb::", "")
     return name.split("(")[0][:60]
 
 
@@ -45,8 +49,9 @@ def slot_names(kernels_seen):
     node = any("tp_conv_node" in k for k in kernels_seen)
     node_ll = any("tp_conv_node" in k and ", true, " in k.split("<")[1][:12] for k in kernels_seen)
     x6 = any(k.startswith("tp_conv_bf16_kernel<") and k.endswith(", 3, false>") for k in kernels_seen)
+    x1 = any(k.startswith("tp_conv_bf16_kernel<") and k.endswith(", 1, false>") for k in kernels_seen)      # precision="bf16": one-product edge-side kernel
     for k in range(4):
-        names = [f"tp_conv_kernel<{k}>"] + ([f"tp_conv_bf16_kernel<{k}, 3, false>"] if node and x6 else [])
+        names = [f"tp_conv_kernel<{k}>"] + ([f"tp_conv_bf16_kernel<{k}, 3, false>"] if node and x6 else []) + ([f"tp_conv_bf16_kernel<{k}, 1, false>"] if node and x1 else [])
         for n in names:
             if not node:
                 s[n] = EDGE_ALL if k < 3 else EDGE_ALL[:3]
@@ -56,6 +61,9 @@ def slot_names(kernels_seen):
                 s[n] = ["lig-lig", "phore-phore"] if k < 3 else ["lig-lig"]
     if node and x6:
         s["tp_conv_bf16_kernel<5, 3, false>"] = ["torsion bonds (tor_bond_conv)"]
+    if node and x1:
+        s["tp_conv_bf16_kernel<5, 1, false>"] = ["torsion bonds (tor_bond_conv)"]
+        s["tp_conv_bf16_kernel<4, 1, false>"] = ["centre (final_conv)"]
     return s
 
 
