@@ -13,6 +13,18 @@ constexpr int EX = 10;
 constexpr int TP_STRIDE = 32;    // floats per pose in DpWork::tparams
 constexpr int MAXN_L = 256, MAXN_P = 256, MAXT = 128, TOR_SLOTS = 32;
 
+// Parameters are read through the CONSTANT address space: a wave-uniform address then becomes a scalar load (s_load_dwordxN into SGPRs, one
+// per wave) whatever stores surround it.  As plain global pointers the compiler must assume that the kernel's own stores may alias them and
+// falls back to one vector load per weight and lane group - the graph kernels then wait on ~400 dependent global loads per edge.
+// The pointer is made opaque at every use: otherwise the loads of a whole 20 x 73 matrix are hoisted out of the per-edge loops, which takes
+// ~1 500 SGPRs - parked in VGPR lanes and fetched back with one v_readlane per weight and iteration.
+typedef const float __attribute__((address_space(4)))* kptr;
+__device__ __forceinline__ kptr K(const float* p) {
+  unsigned long long v = (unsigned long long)p;
+  asm volatile("" : "+s"(v));
+  return (kptr)v;
+}
+
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }     // F.softplus, beta=1, threshold=20
 __device__ __forceinline__ float leaky_f(float x) { return x >= 0.f ? x : 0.01f * x; }
 
@@ -32,7 +44,8 @@ __device__ __forceinline__ void sh9(float x, float y, float z, float* o) {
 }
 
 // GaussianSmearing.forward: exp(coeff * (d - offset[k])^2), offset = the module's registered buffer (linspace(0, stop, 20))
-__device__ __forceinline__ void gauss20(float d, const float* __restrict__ mu, float coeff, float* g) {
+__device__ __forceinline__ void gauss20(float d, const float* __restrict__ mu_, float coeff, float* g) {
+  const kptr mu = K(mu_);
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     const float t = d - mu[k];
@@ -42,7 +55,8 @@ __device__ __forceinline__ void gauss20(float d, const float* __restrict__ mu, f
 
 // out[o] = b[o] + sum_i W[o*ld + off + i] * x[i]   (uniform weight addresses -> scalar loads)
 template <int NOUT, int NIN>
-__device__ __forceinline__ void matvec_acc(const float* __restrict__ W, int ld, int off, const float* x, float* out) {
+__device__ __forceinline__ void matvec_acc(const float* __restrict__ W_, int ld, int off, const float* x, float* out) {
+  const kptr W = K(W_);
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     float a = out[o];
@@ -60,11 +74,12 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float* 
 
 // second Linear of a 20->20 MLP with ReLU in between:  out = b3 + W3 relu(h)
 __device__ __forceinline__ void mlp_tail20(const DpMlp& m, const float* h, float* out) {
+  const kptr b3 = K(m.b3), w3 = K(m.w3);
 #pragma unroll
   for (int o = 0; o < NS; ++o) {
-    float a = m.b3[o];
+    float a = b3[o];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) a = fmaf(m.w3[o * NS + i], fmaxf(h[i], 0.f), a);
+    for (int i = 0; i < NS; ++i) a = fmaf(w3[o * NS + i], fmaxf(h[i], 0.f), a);
     out[o] = a;
   }
 }

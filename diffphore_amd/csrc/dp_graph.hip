@@ -155,11 +155,12 @@ __device__ __forceinline__ void store_flag_row_bf16(uint16_t* __restrict__ tab, 
 // ligand graph per pose: radius graph (torch_cluster CUDA semantics) + bond edges, CSR by scatter node, edge embedding, SH
 //   build_lig_conv_graph :715-739 ; lig_edge_embedding :657
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, DpWork k) {
+__global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWork k) {
+  constexpr int BCAP = 2048;                             // directed bonds of the pose staged in LDS (a 256-atom ligand has ~550); beyond: read in place
   __shared__ float s_pos[MAXN_L * 3];
   __shared__ uint32_t s_adj[MAXN_L * (MAXN_L / 32)];     // s_adj[centre][nbr/32]: bit set <=> edge (nbr -> centre) exists
   __shared__ int s_deg[MAXN_L], s_row[MAXN_L + 1];
-  __shared__ float s_c0[NS];
+  __shared__ int s_bond[BCAP];                           // src (local) | dst (local) << 8 | type << 16
   const int p = blockIdx.x, tid = threadIdx.x;
   const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
   const int bo0 = b.bond_ptr[p], nbond = b.bond_ptr[p + 1] - bo0;
@@ -167,18 +168,27 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
   const int words = (N + 31) / 32;
   for (int i = tid; i < N * 3; i += 256) s_pos[i] = b.pos[(size_t)l0 * 3 + i];
   for (int i = tid; i < N * words; i += 256) s_adj[i] = 0u;
+  for (int e = tid; e < nbond && e < BCAP; e += 256)
+    s_bond[e] = (b.bond_src[bo0 + e] - l0) | ((b.bond_dst[bo0 + e] - l0) << 8) | (b.bond_type[bo0 + e] << 16);
+  auto bond = [&](int e) {
+    return e < BCAP ? s_bond[e] : ((b.bond_src[bo0 + e] - l0) | ((b.bond_dst[bo0 + e] - l0) << 8) | (b.bond_type[bo0 + e] << 16));
+  };
   const int pr0 = b.llp_ptr ? b.llp_ptr[p] : 0;
   const bool pairs = b.llp_ptr != nullptr && k.ll_pair_rad != nullptr && k.ll_pair_bond != nullptr;
   if (k.ll_emb_bf && p == 0) store_flag_row_bf16(k.ll_emb_bf, b.ll_cap, tid);
   if (pairs)
     for (int i = tid; i < N * N; i += 256) { k.ll_pair_rad[pr0 + i] = -1; k.ll_pair_bond[pr0 + i] = -1; }
-  if (tid < NS) {   // layer-0 bias + sigma-embedding part of the edge MLP (same for every edge of the pose)
-    const float* se = k.tparams + (size_t)p * TP_STRIDE;
-    float a = w.lig_edge.b0[tid];
-    for (int i = 0; i < NS; ++i) a = fmaf(w.lig_edge.w0[tid * 44 + 4 + i], se[i], a);
-    s_c0[tid] = a;
-  }
   __syncthreads();
+  if (pairs) {
+    // every edge must own its entry of the pair tables (lig_edges_kernel fills them): radius edges are unique per ordered pair by
+    // construction, so the only way to lose one is a ligand graph that lists the same ordered bond twice -> flag the pose
+    for (int e = tid; e < nbond; e += 256) {
+      const int me = bond(e) & 0xFFFF;
+      bool dup = false;
+      for (int f = 0; f < e; ++f) dup = dup || (bond(f) & 0xFFFF) == me;
+      if (dup) atomicOr(&k.status[p], 2);
+    }
+  }
   // radius search: for centre y scan x ascending, keep d^2 < 25, stop after 33 hits (incl. self), drop self.
   for (int y = tid; y < N; y += 256) {
     const float yx = s_pos[y * 3], yy = s_pos[y * 3 + 1], yz = s_pos[y * 3 + 2];
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
   // degree of scatter node a = #bond edges with src a + #centres y whose list contains a
   for (int a = tid; a < N; a += 256) {
     int deg = 0;
-    for (int e = 0; e < nbond; ++e) deg += (b.bond_src[bo0 + e] - l0 == a) ? 1 : 0;
+    for (int e = 0; e < nbond; ++e) deg += ((bond(e) & 0xFF) == a) ? 1 : 0;
     for (int y = 0; y < N; ++y) deg += (s_adj[y * words + (a >> 5)] >> (a & 31)) & 1u;
     s_deg[a] = deg;
   }
@@ -211,12 +221,14 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
     k.ll_rowptr[l0 + a] = base + s_row[a];
     k.ll_rowend[l0 + a] = base + s_row[a + 1];
     int o = base + s_row[a];
-    for (int e = 0; e < nbond; ++e)
-      if (b.bond_src[bo0 + e] - l0 == a) {
-        k.ll_nbr[o] = b.bond_dst[bo0 + e];
-        k.ll_src[o] = (l0 + a) | (b.bond_type[bo0 + e] << 28);      // stash the bond type in the top bits until the feature pass
+    for (int e = 0; e < nbond; ++e) {
+      const int be = bond(e);
+      if ((be & 0xFF) == a) {
+        k.ll_nbr[o] = l0 + ((be >> 8) & 0xFF);
+        k.ll_src[o] = (l0 + a) | ((be >> 16) << 28);      // the bond type rides in the top bits until lig_edges_kernel has read it
         ++o;
       }
+    }
     for (int y = 0; y < N; ++y)
       if ((s_adj[y * words + (a >> 5)] >> (a & 31)) & 1u) {
         k.ll_nbr[o] = l0 + y;
@@ -224,17 +236,38 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
         ++o;
       }
   }
+}
+
+// features of the ligand-ligand edges lig_graph_kernel listed: spherical harmonics, edge embedding (lig_edge_embedding :657), the pair tables
+// of the node-side conv.  One edge per thread: `slices` workgroup slots per pose (enough for the batch's largest ligand at its full radius
+// degree; a pose with more edges loops), a pose's unused slots leave at once.  (Inside lig_graph_kernel this pass was three dependent rounds
+// on the pose's one workgroup.)
+__global__ __launch_bounds__(256) void lig_edges_kernel(DpBatch b, DpWeights w, DpWork k, int slices) {
+  __shared__ float s_c0[NS];
+  const int p = blockIdx.x / slices, slice = blockIdx.x % slices, tid = threadIdx.x;
+  const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
+  if (N <= 0) return;
+  const int base = b.ll_ptr[p];
+  const int E = k.ll_rowend[l0 + N - 1] - base;
+  if (slice * 256 >= E) return;
+  const int pr0 = b.llp_ptr ? b.llp_ptr[p] : 0;
+  const bool pairs = b.llp_ptr != nullptr && k.ll_pair_rad != nullptr && k.ll_pair_bond != nullptr;
+  if (tid < NS) {   // layer-0 bias + sigma-embedding part of the edge MLP (same for every edge of the pose)
+    const float* se = k.tparams + (size_t)p * TP_STRIDE;
+    float a = w.lig_edge.b0[tid];
+    for (int i = 0; i < NS; ++i) a = fmaf(w.lig_edge.w0[tid * 44 + 4 + i], se[i], a);
+    s_c0[tid] = a;
+  }
   __syncthreads();
-  const int E = s_row[N];
-  for (int e = tid; e < E; e += 256) {
+  for (int e = slice * 256 + tid; e < E; e += slices * 256) {
     const int o = base + e;
     const int packed = k.ll_src[o];
     const int bt = (packed >> 28) & 7, src = packed & 0x0fffffff, dst = k.ll_nbr[o];
     k.ll_src[o] = src;
     if (pairs) (bt < 4 ? k.ll_pair_bond : k.ll_pair_rad)[pr0 + (src - l0) * N + (dst - l0)] = o;    // pair tables of the node-side lig-lig conv
-    const float vx = s_pos[(dst - l0) * 3] - s_pos[(src - l0) * 3];
-    const float vy = s_pos[(dst - l0) * 3 + 1] - s_pos[(src - l0) * 3 + 1];
-    const float vz = s_pos[(dst - l0) * 3 + 2] - s_pos[(src - l0) * 3 + 2];
+    const float vx = b.pos[(size_t)dst * 3] - b.pos[(size_t)src * 3];
+    const float vy = b.pos[(size_t)dst * 3 + 1] - b.pos[(size_t)src * 3 + 1];
+    const float vz = b.pos[(size_t)dst * 3 + 2] - b.pos[(size_t)src * 3 + 2];
     float sh[9];
     sh9(vx, vy, vz, sh);
     store_row<9>(k.ll_sh + (size_t)o * 9, sh);
@@ -246,15 +279,6 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWeights w, 
     mlp_tail20(w.lig_edge, h, out);
     store_row<NS>(k.ll_emb + (size_t)o * NS, out);
     if (k.ll_emb_bf) store_row_bf16(k.ll_emb_bf + (size_t)o * 32, out);
-  }
-  if (pairs) {
-    // every edge must own its table entry: a ligand graph that lists the same ordered bond twice would lose one here -> flag the pose
-    __syncthreads();
-    for (int a = tid; a < N; a += 256) {
-      int cnt = 0;
-      for (int y = 0; y < N; ++y) cnt += (k.ll_pair_rad[pr0 + a * N + y] >= 0 ? 1 : 0) + (k.ll_pair_bond[pr0 + a * N + y] >= 0 ? 1 : 0);
-      if (cnt != s_deg[a]) atomicOr(&k.status[p], 2);
-    }
   }
 }
 
@@ -288,10 +312,11 @@ __global__ __launch_bounds__(256) void node_embed_kernel(DpBatch b, DpWeights w,
     const float dmin = dmin2 < 0.f ? 1e9f : sqrtf(dmin2);
     float* o = k.h_l[0] + (size_t)(l0 + i) * 100;
     const float* xe = k.lig_x_emb + (size_t)(l0 + i) * NS;
+    const kptr bl_b = K(w.boarder_lin_b), bl_w = K(w.boarder_lin_w);
 #pragma unroll
     for (int c = 0; c < NS; ++c) {
       float v = xe[c] + s_ls[c];
-      float bd = w.boarder_lin_b[c] + w.boarder_lin_w[c] * dmin;
+      float bd = bl_b[c] + bl_w[c] * dmin;
 #pragma unroll
       for (int q = 0; q < 5; ++q) bd += w.boarder_emb[(q * 2 + (dmin <= (float)(q + 1) ? 1 : 0)) * NS + c];
       o[c] = v + bd;
@@ -317,110 +342,111 @@ __global__ __launch_bounds__(256) void node_embed_kernel(DpBatch b, DpWeights w,
 // ---------------------------------------------------------------------------------------------------------------------
 // dense ligand x pharmacophore cross edges per pose (_build_phoretype_cross_conv_graph :759-895, cross_edge_embedding :673)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w, DpWork k) {
+__global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w, DpWork k, int slices) {
   __shared__ float s_cs[NS];
-  __shared__ float s_den[MAXN_L];
-  const int p = blockIdx.x, tid = threadIdx.x;
-  const int l0 = b.lig_ptr[p], NL = b.lig_ptr[p + 1] - l0, p0 = b.ph_ptr[p], NP = b.ph_ptr[p + 1] - p0;
-  const int x0 = b.x_ptr[p], E = NL * NP;
-  if (k.x_emb_bf && p == 0) store_flag_row_bf16(k.x_emb_bf, b.n_x, tid);
+  __shared__ float s_ew[256];                   // exp(total_weight) of the workgroup's edges, in edge order
+  __shared__ float s_den[256];
+  const int p = blockIdx.x / slices, slice = blockIdx.x % slices, tid = threadIdx.x;
+  const int l0g = b.lig_ptr[p], NLp = b.lig_ptr[p + 1] - l0g, p0 = b.ph_ptr[p], NP = b.ph_ptr[p + 1] - p0;
+  if (k.x_emb_bf && blockIdx.x == 0) store_flag_row_bf16(k.x_emb_bf, b.n_x, tid);
+  // ONE EDGE PER THREAD.  `slices` workgroup slots per pose are launched (enough for the batch's largest pose); a pose deals its atoms -
+  // whole atoms: the softmax denominator is per atom - to ceil(N_l / floor(256 / N_p)) of them, at most 256 edges each, and its other slots
+  // leave at once.  (One workgroup per pose ran 4 dependent rounds of ~3 000 instructions on two waves per SIMD, and evaluated the distance
+  // embedding and the total-weight MLP twice: once for the softmax numerator, once for the rest.)
+  const int apw = NP > 0 ? (256 / NP > 0 ? 256 / NP : 1) : 256;
+  const int ng = NLp > 0 ? (NLp + apw - 1) / apw : 0;
+  if (slice >= ng || NP <= 0) return;
+  const int a_lo = (NLp * slice) / ng, a_hi = (NLp * (slice + 1)) / ng;
+  const int l0 = l0g + a_lo, NL = a_hi - a_lo;               // this workgroup's atoms
+  const int x0 = b.x_ptr[p] + a_lo * NP, E = NL * NP;        // E <= 256 (DpBatch limits: N_p <= 256)
   if (tid < NS) {
     const float* se = k.tparams + (size_t)p * TP_STRIDE;
     float a = 0.f;
     for (int i = 0; i < NS; ++i) a = fmaf(w.x_edge.w0[tid * 73 + i], se[i], a);
     s_cs[tid] = a;
   }
-  __syncthreads();
-  // pass 1: total_weight and its exponential (:801-811, :839)
-  for (int e = tid; e < E; e += 256) {
-    const int i = e / NP, j = e - i * NP;
-    const float vx = b.ph_pos[(p0 + j) * 3] - b.pos[(l0 + i) * 3];
-    const float vy = b.ph_pos[(p0 + j) * 3 + 1] - b.pos[(l0 + i) * 3 + 1];
-    const float vz = b.ph_pos[(p0 + j) * 3 + 2] - b.pos[(l0 + i) * 3 + 2];
-    float g[NS];
-    gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.x_gauss_mu, w.x_gauss_coeff, g);
-    float z = w.cdt.b3[0];
+  const int e = tid;
+  const bool live = e < E;
+  const int i = live ? e / NP : 0, j = live ? e - i * NP : 0;
+  const int li = l0 + i, pj = p0 + j, ty = b.ph_type[pj];
+  float vx = b.ph_pos[pj * 3] - b.pos[li * 3];
+  float vy = b.ph_pos[pj * 3 + 1] - b.pos[li * 3 + 1];
+  float vz = b.ph_pos[pj * 3 + 2] - b.pos[li * 3 + 2];
+  float g[NS];
+  gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.x_gauss_mu, w.x_gauss_coeff, g);
+  // total_weight and its exponential (:801-811, :839)
+  float tw, ew;
+  {
+    const kptr c_b0 = K(w.cdt.b0), c_w0 = K(w.cdt.w0), c_w3 = K(w.cdt.w3);
+    float z = K(w.cdt.b3)[0];
 #pragma unroll
     for (int o = 0; o < 10; ++o) {
-      float s = w.cdt.b0[o];
+      float s = c_b0[o];
 #pragma unroll
-      for (int q = 0; q < NS; ++q) s = fmaf(w.cdt.w0[o * NS + q], g[q], s);
-      z = fmaf(w.cdt.w3[o], fmaxf(s, 0.f), z);
+      for (int q = 0; q < NS; ++q) s = fmaf(c_w0[o * NS + q], g[q], s);
+      z = fmaf(c_w3[o], fmaxf(s, 0.f), z);
     }
     const float dist = softplus_f(z);
-    const float fm = k.pair_fm[(size_t)(l0 + i) * NPT + b.ph_type[p0 + j]];
-    const float tw = fm * (dist * 1.0f) * w.scaler;
-    k.x_ew[x0 + e] = expf(tw);
+    const float fm = k.pair_fm[(size_t)li * NPT + ty];
+    tw = fm * (dist * 1.0f) * w.scaler;
+    ew = expf(tw);
+  }
+  if (live) {
+    s_ew[e] = ew;
+    k.x_ew[x0 + e] = ew;
   }
   __syncthreads();
-  for (int i = tid; i < NL; i += 256) {     // scatter(..., reduce='sum') over the atom's edges, in edge order
+  if (tid < NL) {     // scatter(..., reduce='sum') over the atom's edges, in edge order
     float s = 0.f;
-    for (int j = 0; j < NP; ++j) s += k.x_ew[x0 + i * NP + j];
-    s_den[i] = s;
+    for (int jj = 0; jj < NP; ++jj) s += s_ew[tid * NP + jj];
+    s_den[tid] = s;
   }
   __syncthreads();
-  // pass 2: everything else
-  for (int e = tid; e < E; e += 256) {
-    const int i = e / NP, j = e - i * NP;
-    const int li = l0 + i, pj = p0 + j, ty = b.ph_type[pj];
-    float vx = b.ph_pos[pj * 3] - b.pos[li * 3];
-    float vy = b.ph_pos[pj * 3 + 1] - b.pos[li * 3 + 1];
-    float vz = b.ph_pos[pj * 3 + 2] - b.pos[li * 3 + 2];
-    float g[NS];
-    gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.x_gauss_mu, w.x_gauss_coeff, g);
-    // edge embedding: Linear(73,20) on [sigma emb | gauss | P], ReLU, Linear(20,20)
-    {
-      float h[NS], out[NS];
-      const float* pre = k.pair_pre + ((size_t)li * NPT + ty) * NS;
+  if (!live) return;
+  // edge embedding: Linear(73,20) on [sigma emb | gauss | P], ReLU, Linear(20,20)
+  {
+    float h[NS], out[NS];
+    const float* pre = k.pair_pre + ((size_t)li * NPT + ty) * NS;
 #pragma unroll
-      for (int c = 0; c < NS; ++c) h[c] = pre[c] + s_cs[c];
-      matvec_acc<NS, NS>(w.x_edge.w0, 73, 20, g, h);
-      mlp_tail20(w.x_edge, h, out);
-      store_row<NS>(k.x_emb + (size_t)(x0 + e) * NS, out);
-      if (k.x_emb_bf) store_row_bf16(k.x_emb_bf + (size_t)(x0 + e) * 32, out);
-    }
-    // sign rule (:813-816) and softmax weight (:839,:845-848)
-    {
-      float z = w.cdt.b3[0];
+    for (int c = 0; c < NS; ++c) h[c] = pre[c] + s_cs[c];
+    matvec_acc<NS, NS>(w.x_edge.w0, 73, 20, g, h);
+    mlp_tail20(w.x_edge, h, out);
+    store_row<NS>(k.x_emb + (size_t)(x0 + e) * NS, out);
+    if (k.x_emb_bf) store_row_bf16(k.x_emb_bf + (size_t)(x0 + e) * 32, out);
+  }
+  // sign rule (:813-816) and softmax weight (:839,:845-848)
+  {
+    const kptr p_b0 = K(w.pdt.b0), p_w0 = K(w.pdt.w0), p_w3 = K(w.pdt.w3);
+    float dz = K(w.pdt.b3)[0];
 #pragma unroll
-      for (int o = 0; o < 10; ++o) {
-        float s = w.cdt.b0[o];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) s = fmaf(w.cdt.w0[o * NS + q], g[q], s);
-        z = fmaf(w.cdt.w3[o], fmaxf(s, 0.f), z);
-      }
-      const float tw = k.pair_fm[(size_t)li * NPT + ty] * (softplus_f(z) * 1.0f) * w.scaler;
-      float dz = w.pdt.b3[0];
-#pragma unroll
-      for (int o = 0; o < NPT; ++o) dz = fmaf(w.pdt.w3[o], leaky_f(fmaf(w.pdt.w0[o], tw, w.pdt.b0[o])), dz);
-      const float dir = leaky_f(dz) < 0.f ? -1.f : 1.f;
-      const float aw = k.x_ew[x0 + e] / s_den[i];
-      vx = vx * dir * aw; vy = vy * dir * aw; vz = vz * dir * aw;
-      float sh[9];
-      sh9(vx, vy, vz, sh);
-      store_row<9>(k.x_sh + (size_t)(x0 + e) * 9, sh);
-    }
-    // normal-vector rule (:874-889); only the phore's own type can agree (phoretype is one-hot)
-    {
-      const float a = ty == EX ? 0.f : b.phorefp[li * NPT + ty];
-      const float* ln = b.norm + (size_t)li * 33 + ty * 3;
-      const float lx = a * ln[0], ly = a * ln[1], lz = a * ln[2];
-      const float px = b.ph_norm[pj * 3], py = b.ph_norm[pj * 3 + 1], pz = b.ph_norm[pj * 3 + 2];
-      float rx = fmaxf(ly * pz - lz * py, 1e-12f) * a;       // torch.clip(cross, 1e-12) * sum(agreement)  (quirk N4)
-      float ry = fmaxf(lz * px - lx * pz, 1e-12f) * a;
-      float rz = fmaxf(lx * py - ly * px, 1e-12f) * a;
-      const float rn = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
-      rx /= rn; ry /= rn; rz /= rn;
-      const float lnm = sqrtf(lx * lx + ly * ly + lz * lz), pnm = sqrtf(px * px + py * py + pz * pz);
-      const float mx = lx * pnm - lnm * px, my = ly * pnm - lnm * py, mz = lz * pnm - lnm * pz;
-      const float qx = lx * pnm + lnm * px, qy = ly * pnm + lnm * py, qz = lz * pnm + lnm * pz;
-      const float ang = 2.f * atan2f(sqrtf(mx * mx + my * my + mz * mz), sqrtf(qx * qx + qy * qy + qz * qz));
-      const float d1 = ang - a * b.norm_angle1[li * NPT + ty], d2 = ang - a * b.norm_angle2[li * NPT + ty];
-      const float dl = fabsf(d2) < fabsf(d1) ? d2 : d1;
-      float sh[9];
-      sh9(rx * dl, ry * dl, rz * dl, sh);
-      store_row<9>(k.x_nsh + (size_t)(x0 + e) * 9, sh);
-    }
+    for (int o = 0; o < NPT; ++o) dz = fmaf(p_w3[o], leaky_f(fmaf(p_w0[o], tw, p_b0[o])), dz);
+    const float dir = leaky_f(dz) < 0.f ? -1.f : 1.f;
+    const float aw = ew / s_den[i];
+    vx = vx * dir * aw; vy = vy * dir * aw; vz = vz * dir * aw;
+    float sh[9];
+    sh9(vx, vy, vz, sh);
+    store_row<9>(k.x_sh + (size_t)(x0 + e) * 9, sh);
+  }
+  // normal-vector rule (:874-889); only the phore's own type can agree (phoretype is one-hot)
+  {
+    const float a = ty == EX ? 0.f : b.phorefp[li * NPT + ty];
+    const float* ln = b.norm + (size_t)li * 33 + ty * 3;
+    const float lx = a * ln[0], ly = a * ln[1], lz = a * ln[2];
+    const float px = b.ph_norm[pj * 3], py = b.ph_norm[pj * 3 + 1], pz = b.ph_norm[pj * 3 + 2];
+    float rx = fmaxf(ly * pz - lz * py, 1e-12f) * a;       // torch.clip(cross, 1e-12) * sum(agreement)  (quirk N4)
+    float ry = fmaxf(lz * px - lx * pz, 1e-12f) * a;
+    float rz = fmaxf(lx * py - ly * px, 1e-12f) * a;
+    const float rn = fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), 1e-12f);
+    rx /= rn; ry /= rn; rz /= rn;
+    const float lnm = sqrtf(lx * lx + ly * ly + lz * lz), pnm = sqrtf(px * px + py * py + pz * pz);
+    const float mx = lx * pnm - lnm * px, my = ly * pnm - lnm * py, mz = lz * pnm - lnm * pz;
+    const float qx = lx * pnm + lnm * px, qy = ly * pnm + lnm * py, qz = lz * pnm + lnm * pz;
+    const float ang = 2.f * atan2f(sqrtf(mx * mx + my * my + mz * mz), sqrtf(qx * qx + qy * qy + qz * qz));
+    const float d1 = ang - a * b.norm_angle1[li * NPT + ty], d2 = ang - a * b.norm_angle2[li * NPT + ty];
+    const float dl = fabsf(d2) < fabsf(d1) ? d2 : d1;
+    float sh[9];
+    sh9(rx * dl, ry * dl, rz * dl, sh);
+    store_row<9>(k.x_nsh + (size_t)(x0 + e) * 9, sh);
   }
 }
 
@@ -430,11 +456,14 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
 __global__ __launch_bounds__(256) void center_edges_kernel(DpBatch b, DpWeights w, DpWork k) {
   __shared__ float s_c[3];
   __shared__ float s_cs[NS];
+  __shared__ float s_pos[MAXN_L * 3];
   const int p = blockIdx.x, tid = threadIdx.x;
   const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
+  for (int i = tid; i < N * 3; i += 256) s_pos[i] = b.pos[(size_t)l0 * 3 + i];
+  __syncthreads();
   if (tid == 0) {     // index_add_ over the atoms in order, then / count
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int i = 0; i < N; ++i) { sx += b.pos[(l0 + i) * 3]; sy += b.pos[(l0 + i) * 3 + 1]; sz += b.pos[(l0 + i) * 3 + 2]; }
+    for (int i = 0; i < N; ++i) { sx += s_pos[i * 3]; sy += s_pos[i * 3 + 1]; sz += s_pos[i * 3 + 2]; }
     s_c[0] = sx / (float)N; s_c[1] = sy / (float)N; s_c[2] = sz / (float)N;
   }
   if (tid >= 64 && tid < 64 + NS) {
@@ -446,7 +475,7 @@ __global__ __launch_bounds__(256) void center_edges_kernel(DpBatch b, DpWeights 
   }
   __syncthreads();
   for (int i = tid; i < N; i += 256) {
-    const float vx = b.pos[(l0 + i) * 3] - s_c[0], vy = b.pos[(l0 + i) * 3 + 1] - s_c[1], vz = b.pos[(l0 + i) * 3 + 2] - s_c[2];
+    const float vx = s_pos[i * 3] - s_c[0], vy = s_pos[i * 3 + 1] - s_c[1], vz = s_pos[i * 3 + 2] - s_c[2];
     float sh[9], g[NS], h[NS], out[NS];
     sh9(vx, vy, vz, sh);
     store_row<9>(k.c_sh + (size_t)(l0 + i) * 9, sh);
@@ -578,9 +607,10 @@ __global__ void tor_head_kernel(DpBatch b, DpWeights w, DpWork k, float* __restr
   const float* x = k.t_q + (size_t)q * 40;
   float out = 0.f;
   for (int o = 0; o < NS; ++o) {
+    const kptr w0 = K(w.tor_w0), w3 = K(w.tor_w3);
     float s = 0.f;
-    for (int i = 0; i < 40; ++i) s = fmaf(w.tor_w0[o * 40 + i], x[i], s);
-    out = fmaf(w.tor_w3[o], tanhf(s), out);
+    for (int i = 0; i < 40; ++i) s = fmaf(w0[o * 40 + i], x[i], s);
+    out = fmaf(w3[o], tanhf(s), out);
   }
   tor[q] = out * k.tparams[(size_t)lo * TP_STRIDE + 24];
 }
@@ -679,10 +709,19 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     // the N x N pair tables are filled (and verified: status bit 1) only when the node-side ligand-ligand conv will read them
     DpWork kg = kx;
     if (!node_ll) kg.ll_pair_rad = kg.ll_pair_bond = nullptr;
-    hipLaunchKernelGGL(dp::lig_graph_kernel, dim3(B), dim3(256), 0, aux ? aux : st, *b, *w, kg);
+    hipLaunchKernelGGL(dp::lig_graph_kernel, dim3(B), dim3(256), 0, aux ? aux : st, *b, kg);
+    // edge features: one edge per thread, workgroup slots for the largest ligand at its full radius degree (+ ~3 directed bonds per atom)
+    const int deg = b->max_nl - 1 < 33 ? (b->max_nl > 1 ? b->max_nl - 1 : 1) : 33;
+    const int e_slices = (b->max_nl * (deg + 3) + 255) / 256;
+    hipLaunchKernelGGL(dp::lig_edges_kernel, dim3(B * e_slices), dim3(256), 0, aux ? aux : st, *b, *w, kg, e_slices);
   }
   hipLaunchKernelGGL(dp::node_embed_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
-  hipLaunchKernelGGL(dp::cross_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, kx);
+  {
+    // workgroup slots per pose of the cross-edge kernel: whole atoms, at most 256 edges each (see the kernel)
+    const int apw = b->max_np > 0 && 256 / b->max_np > 0 ? 256 / b->max_np : 1;
+    const int x_slices = b->max_nl > 0 ? (b->max_nl + apw - 1) / apw : 1;
+    hipLaunchKernelGGL(dp::cross_edges_kernel, dim3(B * x_slices), dim3(256), 0, st, *b, *w, kx, x_slices);
+  }
   if (aux) join();
   // workgroups per pose: keep <= 48 scatter nodes per workgroup and >= ~2 workgroups per CU in flight
   const int prec_edge = w->precision;        // (DP_PREC_BF16: the convs that stay edge-side run the one-product form of the split-bf16 kernel)
