@@ -64,8 +64,11 @@ __device__ inline bool kabsch_rotation(const double H[3][3], double R[3][3]) {
       V[i][j] = i == j ? 1.0 : 0.0;
     }
   for (int sweep = 0; sweep < 24; ++sweep) {
+    // converged: rotations by angles < 1e-22 leave every entry that matters unchanged in double precision.  (Without the relative test the
+    // loop never stops early - rounding keeps the off-diagonal at ~1e-30 of the diagonal - and thread 0 spends 24 sweeps = ~64 rotations of
+    // dependent fp64 divides and square roots where 3-4 sweeps converge: half of this kernel's time.)
     const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-    if (off < 1e-300) break;
+    if (off < 1e-300 || off <= 1e-22 * (fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]))) break;
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         if (fabs(A[p][q]) < 1e-300) continue;
@@ -137,22 +140,70 @@ __device__ inline bool kabsch_rotation(const double H[3][3], double R[3][3]) {
   return true;
 }
 
+// sum of v[c] over the 256 threads, every thread gets the result.  The pairing is the classic LDS tree (i += i + s for s = 128, 64, ..., 1), so
+// the rounding of every sum is the same as that tree's; the last six levels run inside wave 0 on cross-lane moves instead of LDS + barrier
+// (3 workgroup barriers per call instead of 9).  Whole workgroup must call it.
+template <int NV>
+__device__ inline void tree_sum(double (&v)[NV], double* s_red, int tid) {
+#pragma unroll
+  for (int c = 0; c < NV; ++c) s_red[tid * NV + c] = v[c];
+  __syncthreads();
+  if (tid < 128) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) s_red[tid * NV + c] += s_red[(tid + 128) * NV + c];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double x[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) x[c] = s_red[tid * NV + c] + s_red[(tid + 64) * NV + c];
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c) x[c] += __shfl_down(x[c], s, 64);      // lane i < s: x[i] + x[i + s], both from the level above
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c) s_red[256 * NV - NV + c] = x[c];       // (slot 255: nobody reads it below level 128)
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NV; ++c) v[c] = s_red[256 * NV - NV + c];
+  __syncthreads();                                   // s_red may be rewritten right away
+}
+
 // modify_conformer_torsion_angles (torsion.py:64-109) on LDS-resident coordinates; whole workgroup must call it.
-__device__ inline void apply_torsions(const DpBatch& b, int p, int l0, int N, int t0, int T, int NS3, float* s_pos, float* s_pts,
-                                      const float* s_theta) {
+// The bonds' atoms and the mask rows are staged in LDS first (`s_uv`: u | v << 16 per bond; `s_mask`: T x N bytes when they fit TMASK_CAP,
+// else read in place): the loop over the bonds is sequential - every bond sees the positions the previous ones left - so a global load per
+// bond and per mask row was a full memory latency, twice, on every bond's critical path.
+constexpr int TMASK_CAP = 8192;
+__device__ inline void stage_torsions(const DpBatch& b, int p, int l0, int N, int t0, int T, int* s_uv, uint8_t* s_mask) {
   const int tid = threadIdx.x;
-  const uint8_t* mask = b.mask_rotate + b.mask_ptr[p];
+  for (int i = tid; i < T; i += 256) s_uv[i] = (b.tor_u[t0 + i] - l0) | ((b.tor_v[t0 + i] - l0) << 16);
+  if (T * N <= TMASK_CAP) {
+    const uint8_t* mask = b.mask_rotate + b.mask_ptr[p];
+    for (int i = tid; i < T * N; i += 256) s_mask[i] = mask[i];
+  }
+}
+__device__ inline void apply_torsions(const DpBatch& b, int p, int l0, int N, int t0, int T, int NS3, float* s_pos, float* s_pts,
+                                      const float* s_theta, const int* s_uv, const uint8_t* s_mask) {
+  const int tid = threadIdx.x;
+  (void)l0; (void)t0;
+  const bool lds_mask = T * N <= TMASK_CAP;
+  const uint8_t* gmask = b.mask_rotate + b.mask_ptr[p];
   for (int kb = 0; kb < T; ++kb) {
     const float theta = s_theta[kb];
     if (theta == 0.f) continue;                      // uniform across the workgroup
-    const int u = b.tor_u[t0 + kb] - l0, v = b.tor_v[t0 + kb] - l0;
+    const int uv = s_uv[kb];
+    const int u = uv & 0xFFFF, v = uv >> 16;
     const float pv[3] = {s_pos[v * 3], s_pos[v * 3 + 1], s_pos[v * 3 + 2]};
     float rv[3] = {s_pos[u * 3] - pv[0], s_pos[u * 3 + 1] - pv[1], s_pos[u * 3 + 2] - pv[2]};
     const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rv[0], rv[0]), __fmul_rn(rv[1], rv[1])), __fmul_rn(rv[2], rv[2])));
     for (int c = 0; c < 3; ++c) rv[c] = __fdiv_rn(__fmul_rn(rv[c], theta), nrm);
     const Mat3d Rk = rotvec_to_matrix((double)rv[0], (double)rv[1], (double)rv[2]);
     __syncthreads();                                 // everyone has read pos[u], pos[v] before anyone writes
-    const uint8_t* mk = mask + (size_t)kb * N;
+    const uint8_t* mk = (lds_mask ? s_mask : gmask) + (size_t)kb * N;
     for (int a = tid; a < N; a += 256)
       if (mk[a]) {
         const float d[3] = {s_pos[a * 3] - pv[0], s_pos[a * 3 + 1] - pv[1], s_pos[a * 3 + 2] - pv[2]};
@@ -178,17 +229,20 @@ __global__ __launch_bounds__(256) void randomize_kernel(DpBatch b, const float* 
   __shared__ float s_pts[MAXN_L * 33];
   __shared__ float s_theta[MAXT];
   __shared__ float s_c[3];
+  __shared__ int s_uv[MAXT];
+  __shared__ uint8_t s_mask[TMASK_CAP];
   const int p = blockIdx.x, tid = threadIdx.x;
   const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
   const int t0 = b.tor_ptr[p], T = no_torsion ? 0 : b.tor_ptr[p + 1] - t0;
   const int NS3 = 11 * N;
   for (int i = tid; i < N * 3; i += 256) s_pos[i] = b.pos[(size_t)l0 * 3 + i];
   for (int i = tid; i < T; i += 256) s_theta[i] = theta[t0 + i];
+  stage_torsions(b, p, l0, N, t0, T, s_uv, s_mask);
   __syncthreads();
   for (int s = tid; s < NS3; s += 256)
     for (int c = 0; c < 3; ++c) s_pts[s * 3 + c] = b.norm[(size_t)l0 * 33 + s * 3 + c] + s_pos[(s % N) * 3 + c];
   __syncthreads();
-  if (T > 0) apply_torsions(b, p, l0, N, t0, T, NS3, s_pos, s_pts, s_theta);
+  if (T > 0) apply_torsions(b, p, l0, N, t0, T, NS3, s_pos, s_pts, s_theta, s_uv, s_mask);
   __syncthreads();
   if (tid == 0) {
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -224,14 +278,17 @@ __global__ __launch_bounds__(256) void conformer_update_kernel(DpBatch b, DpStep
   __shared__ float s_theta[MAXT];
   __shared__ double s_R[3][3], s_t[3];
   __shared__ float s_Rf[3][3], s_c[3], s_trp[3];
-  __shared__ double s_red[256 * 3];
+  __shared__ double s_red[256 * 9];
   __shared__ int s_flag;
+  __shared__ int s_uv[MAXT];
+  __shared__ uint8_t s_mask[TMASK_CAP];
   const int p = blockIdx.x, tid = threadIdx.x;
   const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
   const int t0 = b.tor_ptr[p], T = sp.no_torsion ? 0 : b.tor_ptr[p + 1] - t0;
   const int NS3 = 11 * N;
   for (int i = tid; i < N * 3; i += 256) s_pos[i] = b.pos[(size_t)l0 * 3 + i];
   for (int i = tid; i < T; i += 256) s_theta[i] = sp.tor_c1 * tor[t0 + i] + (z_tor ? sp.tor_c2 * z_tor[t0 + i] : 0.f);
+  stage_torsions(b, p, l0, N, t0, T, s_uv, s_mask);
   if (tid == 0) s_flag = 0;
   __syncthreads();
   if (tid == 0) {
@@ -269,33 +326,25 @@ __global__ __launch_bounds__(256) void conformer_update_kernel(DpBatch b, DpStep
   for (int i = tid; i < N * 3; i += 256) s_pos[i] = s_rig[i];
   __syncthreads();
   if (T > 0) {
-    apply_torsions(b, p, l0, N, t0, T, NS3, s_pos, s_pts, s_theta);
+    apply_torsions(b, p, l0, N, t0, T, NS3, s_pos, s_pts, s_theta, s_uv, s_mask);
     // Kabsch: align flexible (s_pos) onto rigid (s_rig)
     {
       double acc[6] = {0, 0, 0, 0, 0, 0};
       for (int a = tid; a < N; a += 256)
         for (int c = 0; c < 3; ++c) { acc[c] += s_pos[a * 3 + c]; acc[3 + c] += s_rig[a * 3 + c]; }
-      // centroid reduction (fixed tree order -> deterministic)
-      for (int c = 0; c < 3; ++c) s_red[tid * 3 + c] = acc[c];
-      __syncthreads();
-      for (int s = 128; s > 0; s >>= 1) { if (tid < s) for (int c = 0; c < 3; ++c) s_red[tid * 3 + c] += s_red[(tid + s) * 3 + c]; __syncthreads(); }
-      const double cA[3] = {s_red[0] / N, s_red[1] / N, s_red[2] / N};
-      __syncthreads();
-      for (int c = 0; c < 3; ++c) s_red[tid * 3 + c] = acc[3 + c];
-      __syncthreads();
-      for (int s = 128; s > 0; s >>= 1) { if (tid < s) for (int c = 0; c < 3; ++c) s_red[tid * 3 + c] += s_red[(tid + s) * 3 + c]; __syncthreads(); }
-      const double cB[3] = {s_red[0] / N, s_red[1] / N, s_red[2] / N};
-      __syncthreads();
+      // centroid reduction (fixed tree order -> deterministic): both centroids in one tree
+      tree_sum<6>(acc, s_red, tid);
+      const double cA[3] = {acc[0] / N, acc[1] / N, acc[2] / N};
+      const double cB[3] = {acc[3] / N, acc[4] / N, acc[5] / N};
       double H[3][3];
-      for (int i = 0; i < 3; ++i) {
-        double h[3] = {0, 0, 0};
+      {
+        double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int a = tid; a < N; a += 256)
-          for (int j = 0; j < 3; ++j) h[j] += ((double)s_pos[a * 3 + i] - cA[i]) * ((double)s_rig[a * 3 + j] - cB[j]);
-        for (int j = 0; j < 3; ++j) s_red[tid * 3 + j] = h[j];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) { if (tid < s) for (int j = 0; j < 3; ++j) s_red[tid * 3 + j] += s_red[(tid + s) * 3 + j]; __syncthreads(); }
-        for (int j = 0; j < 3; ++j) H[i][j] = s_red[j];
-        __syncthreads();
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) h[i * 3 + j] += ((double)s_pos[a * 3 + i] - cA[i]) * ((double)s_rig[a * 3 + j] - cB[j]);
+        tree_sum<9>(h, s_red, tid);
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) H[i][j] = h[i * 3 + j];
       }
       if (tid == 0) {
         double R[3][3];
