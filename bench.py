@@ -425,7 +425,8 @@ def main():
         sampling_phore(gl, m, S_total, sched, sched, sched, dev, t2s, margs, batch_size=20, timing=tm)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        e2e = {"what": "drop-in sampling_phore(data_list) incl. host packing, noise draw/upload and write-back", "poses": len(gl),
+        e2e = {"what": "drop-in sampling_phore(data_list) incl. host packing, noise draw/upload and write-back (reference-order normals from the global "
+                       "CPU generator: the first 2 steps' before the first launch, the others while the GPU runs those)", "poses": len(gl),
                "steps": S_total, "seconds": dt, "value": len(gl) * S_total / dt, "unit": "pose-steps/s",
                "breakdown_s": {k: round(v, 4) for k, v in tm.items()}}
         # the same call with the noise drawn on the device (seed=): no S x N x (6 + T) normals drawn by one host thread and uploaded

@@ -53,6 +53,22 @@ def _step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule
     return sp
 
 
+LAZY_HEAD = 2      # noisy steps whose normals are drawn before the first launch (see _host_stage_noise_only)
+
+
+def _draw_rest(Z):
+    """Draw the steps `_host_stage_noise_only` left for later into the host tables; returns the first of them (None: nothing was left)."""
+    rest = Z.pop("_rest", None) if Z is not None else None
+    if rest is None:
+        return None
+    steps, N, nt, batch_size = rest
+    for t in steps:
+        dd = _draw_reference_order(N, nt, batch_size)
+        for i, k in enumerate(("tr", "rot", "tor")):
+            Z[k][t] = dd[i]
+    return steps[0]
+
+
 def _draw_reference_order(N, T_per_pose: np.ndarray, batch_size: int):
     """One step's normals from the global CPU generator in the reference's order (per chunk: tr, rot, tor)."""
     ztr, zrot, ztor = [], [], []
@@ -117,7 +133,15 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
     no_torsion = bool(getattr(model_args, "no_torsion", False))
     keep_update = bool(getattr(model_args, "keep_update", False))
     eng.ws.t["status"].zero_()     # dp_conformer_update ORs its flag in: a run on a reused engine must not inherit an old failure
-    if Z is not None:
+    whole = not keep_update and visualization_list is None and os.environ.get("DIFFPHORE_WHOLE_LOOP", "1") != "0"
+    g = os.environ.get("DIFFPHORE_GRAPH", "auto")
+    use_graph = g == "1" or (g == "auto" and pb.B <= GRAPH_MAX_POSES)
+    lazy = Z is not None and "_rest" in Z
+    if lazy and not (whole and not use_graph):
+        _draw_rest(Z)
+        lazy = False
+    Zh = Z
+    if Z is not None and not lazy:
         Z = {k: h2d(v.to(torch.float32).contiguous(), dev) for k, v in Z.items()}
     T_all = h2d(T_all.contiguous(), dev)
     sps = []
@@ -125,15 +149,25 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
         last = t_idx == inference_steps - 1
         zero = no_random or (no_final_step_noise and last)
         sps.append(_step_params(t_idx, inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, zero))
-    if not keep_update and visualization_list is None and os.environ.get("DIFFPHORE_WHOLE_LOOP", "1") != "0":
+    if whole:
         # the whole loop in one library call (dp_sample): times and noise are device tables indexed by the step.  Enqueued eagerly; the
         # hipGraph form (capture once, replay) is for callers that rerun the same engine many times (dp_sample_graph_*)
-        g = os.environ.get("DIFFPHORE_GRAPH", "auto")
-        use_graph = g == "1" or (g == "auto" and pb.B <= GRAPH_MAX_POSES)
-        z_tor = Z["tor"] if (Z is not None and not no_torsion and Z["tor"].numel()) else None
         seed, uid = dev_noise if dev_noise is not None else (None, None)
-        eng.sample(sps, T_all, Z["tr"] if Z is not None else None, Z["rot"] if Z is not None else None, z_tor, graph=use_graph, seed=seed,
-                   pose_uid=uid)
+
+        def tables(Zd, lo, hi):
+            z_tor = Zd["tor"][lo:hi] if (Zd is not None and not no_torsion and Zd["tor"].numel()) else None
+            return (Zd["tr"][lo:hi] if Zd is not None else None, Zd["rot"][lo:hi] if Zd is not None else None, z_tor)
+        if lazy:
+            # two calls: the steps whose normals exist, then - drawn while the GPU runs those - the others (same schedule, same tables)
+            split = Zh["_rest"][0][0]
+            head = {k: h2d(Zh[k][:split].contiguous(), dev) for k in ("tr", "rot", "tor")}
+            eng.sample(sps[:split], T_all[:split], *tables(head, 0, split), graph=False)
+            _draw_rest(Zh)
+            tail = {k: h2d(Zh[k][split:].contiguous(), dev) for k in ("tr", "rot", "tor")}
+            eng.sample(sps[split:], T_all[split:], *tables(tail, 0, inference_steps - split), graph=False)
+            eng._keep = (eng._keep, head, tail)            # both calls' tables stay alive until the run is collected
+            return
+        eng.sample(sps, T_all, *tables(Z, 0, inference_steps), graph=use_graph, seed=seed, pose_uid=uid)
         return
     for t_idx in range(inference_steps):
         last = t_idx == inference_steps - 1
@@ -353,12 +387,18 @@ def _host_stage_noise_only(pb, N, inference_steps, tr_schedule, rot_schedule, to
         if noise is not None:
             Z = {k: noise[k].to(torch.float32) for k in ("tr", "rot", "tor")}
         else:
-            # step-major, then per `batch_size` chunk: tr, rot, tor - nothing else consumes the generator inside the reference's loop
-            d = [_draw_reference_order(N, pb.nt, batch_size) for _ in steps]
+            # step-major, then per `batch_size` chunk: tr, rot, tor - nothing else consumes the generator inside the reference's loop.
+            # Only the first LAZY_HEAD steps are drawn here; `_enqueue_run` draws the others - same generator, same order, nothing in
+            # between - AFTER it has queued those first steps, so the ~1000 small torch.normal calls of a 20-step run (3-4 ms for 512
+            # poses) run while the GPU is already sampling instead of in front of it.
+            head = steps[:LAZY_HEAD] if len(steps) > LAZY_HEAD + 1 else steps
+            d = [_draw_reference_order(N, pb.nt, batch_size) for _ in head]
             Z = {k: torch.zeros((inference_steps,) + tuple(d[0][i].shape)) for i, k in enumerate(("tr", "rot", "tor"))}
-            for t, dd in zip(steps, d):
+            for t, dd in zip(head, d):
                 for i, k in enumerate(("tr", "rot", "tor")):
                     Z[k][t] = dd[i]
+            if len(head) < len(steps):
+                Z["_rest"] = (steps[len(head):], N, pb.nt, batch_size)
     T_all = torch.stack([torch.tensor([float(tr_schedule[t]), float(rot_schedule[t]), float(tor_schedule[t])], dtype=torch.float32)
                          for t in range(inference_steps)])
     return pb, Z, T_all
