@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256) void lig_edges_kernel(DpBatch b, DpWeights w, 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void node_embed_kernel(DpBatch b, DpWeights w, DpWork k) {
   __shared__ float s_ls[NS], s_ps[NS], s_pc[NS];
+  __shared__ float s_pp[MAXN_P * 3];            // the pose's pharmacophore positions and types (boarder_analyze: distance to the nearest
+  __shared__ int s_ty[MAXN_P];                  // exclusion sphere): read by every atom, so staged once instead of N_p global loads per atom
   const int p = blockIdx.x, tid = threadIdx.x;
   const int l0 = b.lig_ptr[p], NL = b.lig_ptr[p + 1] - l0, p0 = b.ph_ptr[p], NP = b.ph_ptr[p + 1] - p0;
   const float* se = k.tparams + (size_t)p * TP_STRIDE;
@@ -299,13 +301,15 @@ __global__ __launch_bounds__(256) void node_embed_kernel(DpBatch b, DpWeights w,
     }
     s_ls[tid] = a; s_ps[tid] = c; s_pc[tid] = d;
   }
+  for (int j = tid; j < NP; j += 256) s_ty[j] = b.ph_type[p0 + j];
+  for (int j = tid; j < NP * 3; j += 256) s_pp[j] = b.ph_pos[(size_t)p0 * 3 + j];
   __syncthreads();
   for (int i = tid; i < NL; i += 256) {
     const float x = b.pos[(l0 + i) * 3], y = b.pos[(l0 + i) * 3 + 1], z = b.pos[(l0 + i) * 3 + 2];
     float dmin2 = -1.f;
     for (int j = 0; j < NP; ++j)
-      if (b.ph_type[p0 + j] == EX) {
-        const float dx = x - b.ph_pos[(p0 + j) * 3], dy = y - b.ph_pos[(p0 + j) * 3 + 1], dz = z - b.ph_pos[(p0 + j) * 3 + 2];
+      if (s_ty[j] == EX) {
+        const float dx = x - s_pp[j * 3], dy = y - s_pp[j * 3 + 1], dz = z - s_pp[j * 3 + 2];
         const float d2 = dx * dx + dy * dy + dz * dz;
         dmin2 = (dmin2 < 0.f || d2 < dmin2) ? d2 : dmin2;
       }
