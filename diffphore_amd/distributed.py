@@ -164,6 +164,11 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     batches = screen_plan(n_units, costs, rank, world, samples_per_complex, max_poses)
     mine = [i for bt in batches for i in bt]
+    if len(batches) >= 3 and len(batches[0]) >= 4:
+        # ramp: nothing runs until the first device batch is built and packed, so that one is a quarter batch (the rest of it follows as the
+        # second); poses do not depend on the batching (seeded noise per pose uid)
+        q = len(batches[0]) // 4
+        batches = [batches[0][:q], batches[0][q:]] + batches[1:]
     steps = int(getattr(args, "inference_steps", 20))
     sched = get_t_schedule(steps)
 
