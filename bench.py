@@ -571,7 +571,10 @@ def main():
                     f5, n5, ns5 = w2.prof_launch
                     wk = launch_work(w2.pb, w2.edge_counts, PROF_LAYER, list(range(f5, f5 + n5)), prec_c)
                     km = r2["kernel_ms"]
-                    rec["roofline"] = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel_ms": km,
+                    tr5, tr5_src = measured_traffic(5, w2.B, prec_c, r2["algo"]) if world == 1 else (None, None)
+                    rec["roofline"] = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel_ms": km, "traffic": tr5,
+                                       "traffic_note": (f"HBM bytes per launch from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE), {tr5_src}: mostly scratch - the "
+                                                        "kernel parks 89-163 registers (128 fp32 accumulators + 64 hidden-vector registers of 256)") if tr5 is not None else None,
                                        "kernel": f"layer-{PROF_LAYER} ligand-side launch ({n5} conv(s)), bf16 operands / fp32 accumulate, node-side={bool(ns5)}",
                                        "achieved": wk["node_flops"] / (km * 1e-3) / 1e12, "frac": wk["node_flops"] / (km * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                        "issued_frac": wk["issued_flops"] / (km * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,

@@ -5,6 +5,7 @@ set -u
 tag=${1:-r2}
 shift || true
 EXTRA="$*"
+CID=2; prev=""; for w in $EXTRA; do [ "$prev" == "--config" ] && CID=$w; prev=$w; done
 cd "$(dirname "$0")/.." || exit 1
 export PYTHONPATH=. TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -16,7 +17,7 @@ rm -rf /tmp/prof_$tag; mkdir -p /tmp/prof_$tag
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_$tag/write -o w -- python $OLDPWD/bench.py --steps 8 --warmup 2 --no-alt --no-e2e --no-cpu-baseline --no-other $EXTRA > /tmp/prof_$tag/write.out 2>&1)
 T=$(find /tmp/prof_$tag/trace -name '*.db' | head -1); F=$(find /tmp/prof_$tag/fetch -name '*.db' | head -1); W=$(find /tmp/prof_$tag/write -name '*.db' | head -1)
 echo "dbs: $T $F $W"
-python tools/summarize_prof.py gpurun_out/$tag "$T" --fetch "$F" --write "$W" --bench gpurun_out/${tag}_bench.json --command "rocprofv3 --kernel-trace --stats -- $CMD (PMC passes: --steps 8 --warmup 2)"
+python tools/summarize_prof.py gpurun_out/$tag "$T" --fetch "$F" --write "$W" --bench gpurun_out/${tag}_bench.json --config-id $CID --command "rocprofv3 --kernel-trace --stats -- $CMD (PMC passes: --steps 8 --warmup 2)"
 tail -1 /tmp/prof_$tag/trace.out | cut -c1-300
-[ -f gpurun_out/${tag}_traffic_record.json ] && python -c "import json,sys; r=json.load(open(sys.argv[1])); json.dump(r if isinstance(r,list) else [r], open(sys.argv[2],'w'), indent=1)" gpurun_out/${tag}_traffic_record.json gpurun_out/conv_hbm_traffic.json
-head -30 gpurun_out/${tag}_conv_slots.csv; cat gpurun_out/conv_hbm_traffic.json; head -14 gpurun_out/${tag}_kernel_stats.csv
+# (append gpurun_out/${tag}_traffic_record.json to profiles/conv_hbm_traffic.json when the profile is committed)
+head -30 gpurun_out/${tag}_conv_slots.csv; cat gpurun_out/${tag}_traffic_record.json; head -14 gpurun_out/${tag}_kernel_stats.csv

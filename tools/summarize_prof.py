@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--bench")
     ap.add_argument("--command", default="")
+    ap.add_argument("--config-id", type=int, default=2, help="bench.py --config value of the profiled run (keys the traffic record)")
     a = ap.parse_args()
     cur = sqlite3.connect(a.trace).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
@@ -135,7 +136,8 @@ def main():
                 if f and w:
                     fa, wa = sum(f) / len(f), sum(w) / len(w)
                     res.append(f"{k},{sname},{len(f)},{fa:.1f},{wa:.1f},{2 * fa / 1024:.2f},{wa / 1024:.2f}")
-                    if (k.startswith("tp_conv_node_kernel<3, true, 1, ")) or (k == "tp_conv_kernel<3>" and sname == "phore->lig"):      # bench.py PROF_LAYER = 3
+                    if (k.startswith("tp_conv_node_kernel<3, true, 1, ")) or (k == "tp_conv_kernel<3>" and sname == "phore->lig") or \
+                            k == "tp_conv_node_bf16_kernel<3, true, 1>":      # bench.py PROF_LAYER = 3
                         rec = int((2 * fa + wa) * 1024)
         open(f"{a.prefix}_conv_hbm_traffic.csv", "w").write("\n".join(res) + "\n")
         if rec is not None and bench is not None:
@@ -143,7 +145,7 @@ def main():
             import sys
             sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
             import bench as benchmod
-            json.dump({"source_hash": benchmod.kernel_source_hash(), "config": 2, "poses": bench["config"]["poses_per_gpu"],
+            json.dump({"source_hash": benchmod.kernel_source_hash(), "config": a.config_id, "poses": bench["config"]["poses_per_gpu"],
                        "precision": bench["config"]["precision"], "conv_algo": bench["config"]["conv_algo"], "traffic_bytes": rec,
                        "profile": os.path.basename(a.prefix) + "_conv_hbm_traffic.csv"}, open(f"{a.prefix}_traffic_record.json", "w"))
 
