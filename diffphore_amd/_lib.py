@@ -13,12 +13,14 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 9
+DP_ABI_VERSION = 10
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
 PREC_BF16X9 = 4
 PREC_BF16 = 5          # plain bf16 operands, fp32 accumulate: node-side dp_conv_node_bf16_impl.h, edge-side the one-product split-bf16 kernel
+PREC_F16X3 = 6         # node-side kernel only, fp32-grade: two fp16 limbs per operand on v_mfma_f32_16x16x32_f16 (dp_conv_node_f16_impl.h); not a
+                       # model precision - what the node-side convs of an "f32" model run on unless DIFFPHORE_NODE_F16=0
 PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16x9": PREC_BF16X9, "bf16": PREC_BF16}
 EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER, EDGES_LLPAIR = range(5)
 ALGO_AUTO, ALGO_EDGE, ALGO_NODE = range(3)
@@ -115,6 +117,14 @@ def _declare(L):
     L.dp_pack_conv_weights_node_bf16.restype = C.c_int
     L.dp_edge_emb_bf16.argtypes = [VOIDP, c_i32, VOIDP, VOIDP]
     L.dp_edge_emb_bf16.restype = C.c_int
+    L.dp_conv_w1h_floats.argtypes = [c_i32]
+    L.dp_conv_w1h_floats.restype = C.c_int
+    L.dp_conv_w2h_floats.argtypes = [c_i32]
+    L.dp_conv_w2h_floats.restype = C.c_int
+    L.dp_pack_conv_weights_node_f16.argtypes = [c_i32] + [VOIDP] * 7
+    L.dp_pack_conv_weights_node_f16.restype = C.c_int
+    L.dp_edge_emb_f16.argtypes = [VOIDP, c_i32, VOIDP, VOIDP]
+    L.dp_edge_emb_f16.restype = C.c_int
     L.dp_build_info.argtypes = [C.POINTER(DpBuildInfo)]
     L.dp_build_info.restype = C.c_int
 

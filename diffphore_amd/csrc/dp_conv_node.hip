@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#include "dp_conv_node_bf16_impl.h"
+#include "dp_conv_node_f16_impl.h"
 
 
 namespace dpn {
@@ -136,6 +136,134 @@ __global__ void edge_emb_bf16_kernel(const float* __restrict__ emb, int n_rows, 
   *reinterpret_cast<dpb::u32x4*>(out + (size_t)row * dpb::EMB_ROW + 8 * g) = v;
 }
 
+// ---- DP_PREC_F16X3 (dp_conv_node_f16_impl.h): two-limb fp16 MFMA fragments, exact power-of-two scales ------------------------------------
+static inline unsigned short f16_rne(float x) {                     // fp32 -> fp16 bits, round to nearest even (overflow -> inf, subnormals kept)
+  unsigned int u;
+  memcpy(&u, &x, 4);
+  const unsigned int sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u >= 0x7f800000u) return (unsigned short)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (u >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);    // >= 65520 rounds to inf
+  if (u < 0x38800000u) {                                            // below 2^-14: fp16 subnormal (or zero)
+    if (u < 0x33000000u) return (unsigned short)sign;               // < 2^-25 rounds to zero
+    const int e = (int)(u >> 23);                                   // biased exponent, 102..112
+    unsigned int m = (u & 0x7fffffu) | 0x800000u;                   // 24-bit significand
+    const int shift = 126 - e;                                      // bits to drop so that the result counts units of 2^-24
+    const unsigned int halfway = 1u << (shift - 1), rest = m & ((1u << shift) - 1u);
+    m >>= shift;
+    if (rest > halfway || (rest == halfway && (m & 1u))) ++m;
+    return (unsigned short)(sign | m);
+  }
+  unsigned int r = u - 0x38000000u;                                 // re-bias the exponent (127 -> 15)
+  const unsigned int rest = r & 0x1fffu;
+  r >>= 13;
+  if (rest > 0x1000u || (rest == 0x1000u && (r & 1u))) ++r;
+  return (unsigned short)(sign | r);
+}
+static inline float f16_to_f32(unsigned short h) {
+  const unsigned int sign = ((unsigned int)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float f;
+  if (e == 0) {
+    f = (float)m * 5.9604644775390625e-8f;                          // m * 2^-24
+    unsigned int u;
+    memcpy(&u, &f, 4);
+    u |= sign;
+    memcpy(&f, &u, 4);
+    return f;
+  }
+  const unsigned int u = sign | (e == 31 ? 0x7f800000u : ((e + 112u) << 23)) | (m << 13);
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline void f16_split(float v, unsigned short& hi, unsigned short& lo) {
+  hi = f16_rne(v);
+  lo = f16_rne(v - f16_to_f32(hi));
+}
+// first layer: three B-operand images x two limbs per wave q, as pack_w1b, stored as 16 W1 (dpf::W1_SCALE; relu commutes with the scale, the kernel
+// divides the hidden vectors by it); the flag row is dpf::FLAG_W: [img][limb][q][lane][8]
+template <int KIND> void pack_w1h(const float* fc0_w, const float* fc0_b, unsigned short* w1h) {
+  using S = Spec<KIND>;
+  static_assert(S::HID == HIDN && S::N_ATTR == 60, "node-side kernel: layer convs only");
+  for (int img = 0; img < 3; ++img)
+    for (int q = 0; q < 4; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int g = lane >> 4, k = 16 * q + (lane & 15), f = 8 * g + j;
+          float v = 0.f;
+          if (f < 20) v = k < HIDN ? dpf::W1_SCALE * fc0_w[k * 60 + 20 * img + f] : 0.f;
+          else if (f == dpb::EMB_FLAG) v = img == 0 ? dpf::FLAG_W : dpf::W1_SCALE * (k < HIDN ? fc0_b[k] : (k == HIDN ? 1.f : 0.f));
+          unsigned short hi, lo;
+          f16_split(v, hi, lo);
+          w1h[((((size_t)img * 2 + 0) * 4 + q) * 64 + lane) * 8 + j] = hi;
+          w1h[((((size_t)img * 2 + 1) * 4 + q) * 64 + lane) * 8 + j] = lo;
+        }
+}
+// second layer as GEMM-B A fragments [header][path][supertile][limb][K chunk][M tile][wave q][lane][8] (fragment order of pack_w2b), stored as
+// W2 * 2^w with w = the largest exponent that keeps max |W2 * 2^w| <= 2048; header float[0] = w
+template <int KIND> void pack_w2h(const float* fc3_w, const float* fc3_b, const float* bn_scale, unsigned short* w2h) {
+  using S = Spec<KIND>;
+  auto value = [&](int p, int u, int w, int k) -> double {
+    const PathC& pc = S::P[p];
+    const int dout = d_out_of(pc.ztype);
+    if (w >= pc.mul_out || k > HIDN) return 0.0;
+    const double scale = __builtin_sqrt((double)(2 * (dout == 3 ? 1 : 0) + 1) / (double)pc.fan_in) * cg_const(pc.ztype);
+    const int widx = pc.w_off + u * pc.mul_out + w;
+    const double bn = bn_scale ? (double)bn_scale[pc.out_off + w * dout] : 1.0;
+    return scale * bn * (double)(k < HIDN ? fc3_w[widx * HIDN + k] : fc3_b[widx]);
+  };
+  double mx = 0.0;
+  for (int p = 0; p < S::NPATH; ++p)
+    for (int u = 0; u < S::P[p].mul_in; ++u)
+      for (int w = 0; w < S::P[p].mul_out; ++w)
+        for (int k = 0; k <= HIDN; ++k) { const double v = __builtin_fabs(value(p, u, w, k)); if (v > mx) mx = v; }
+  int wexp = 0;
+  if (mx > 0.0 && mx < 1e30) {
+    wexp = 11 - (int)__builtin_ceil(__builtin_log2(mx));            // mx * 2^wexp in (1024, 2048]
+    if (wexp > 40) wexp = 40;
+    if (wexp < -40) wexp = -40;
+  }
+  const double sc = __builtin_ldexp(1.0, wexp);
+  float* hdr = reinterpret_cast<float*>(w2h);
+  for (int i = 0; i < dpf::HDR_QUADS * 4; ++i) hdr[i] = 0.f;
+  hdr[0] = (float)wexp;
+  for (int p = 0; p < S::NPATH; ++p) {
+    const int MT = path_mt<KIND>(p);
+    for (int st = 0; st < dpb::st_count<KIND>(p); ++st)
+      for (int ch = 0; ch < dpb::SUPER_CH; ++ch)
+        for (int mt = 0; mt < MT; ++mt)
+          for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int g = lane >> 4, w = 16 * mt + (lane & 15);
+                const int u = dpb::SUPER_NU * st + 2 * ch + (j >> 2), k = 16 * q + 4 * g + (j & 3);
+                unsigned short hi, lo;
+                f16_split((float)(sc * value(p, u, w, k)), hi, lo);
+                const size_t stq = (size_t)dpf::w2h_path_off<KIND>(p) + (size_t)(st * 2 * dpb::SUPER_CH * MT) * 256;
+                w2h[(stq + (size_t)((0 * dpb::SUPER_CH + ch) * MT + mt) * 256 + q * 64 + lane) * 8 + j] = hi;
+                w2h[(stq + (size_t)((1 * dpb::SUPER_CH + ch) * MT + mt) * 256 + q * 64 + lane) * 8 + j] = lo;
+              }
+  }
+}
+// emb [n, 20] fp32 -> [n + 1, 64] fp16 rows (hi limb: 20 features | zeros to 32; lo limb: the same) + the flag row (hi feature 20 = 1.0);
+// one thread per 8 features of a row
+__global__ void edge_emb_f16_kernel(const float* __restrict__ emb, int n_rows, uint16_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (n_rows + 1) * 4) return;
+  const int row = i >> 2, g = i & 3;
+  dpb::u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+  if (row < n_rows) {
+    if (g < 3) {
+      const float* p = emb + (size_t)row * 20 + 8 * g;
+      const int npair = g < 2 ? 4 : 2;
+      for (int k = 0; k < npair; ++k) { const dpf::HL s = dpf::split2(p[2 * k], p[2 * k + 1]); vh[k] = s.h; vl[k] = s.l; }
+    }
+  } else if (g == 2) {
+    vh[2] = 0x3C00u;                                // feature 20 = 1.0
+  }
+  *reinterpret_cast<dpb::u32x4*>(out + (size_t)row * dpf::EMBH_ROW + 8 * g) = vh;
+  *reinterpret_cast<dpb::u32x4*>(out + (size_t)row * dpf::EMBH_ROW + 32 + 8 * g) = vl;
+}
+
 // conv split: out = (previous out | residual stream | 0) + ((part[0] + part[1]) + part[2]) + the convs' BatchNorm shifts, in this fixed order
 struct CombineArgs {
   const float* part;
@@ -169,8 +297,18 @@ static int launch_kind_bf16(int kind, const FusedArgs& fa, int xmode, hipStream_
   }
 }
 
+static int launch_kind_f16(int kind, const FusedArgs& fa, int xmode, hipStream_t st) {
+  switch (kind) {
+    case 0: return dpf_launch_k0(fa, xmode, st);
+    case 1: return dpf_launch_k1(fa, xmode, st);
+    case 2: return dpf_launch_k2(fa, xmode, st);
+    default: return dpf_launch_k3(fa, xmode, st);
+  }
+}
+
 static int launch_kind(int kind, const FusedArgs& fa, int xmode, hipStream_t st) {
   if (fa.conv[0].precision == DP_PREC_BF16) return launch_kind_bf16(kind, fa, xmode, st);
+  if (fa.conv[0].precision == DP_PREC_F16X3) return launch_kind_f16(kind, fa, xmode, st);
   switch (kind) {
     case 0: return dpn_launch_k0(fa, xmode, st);
     case 1: return dpn_launch_k1(fa, xmode, st);
@@ -186,8 +324,8 @@ static int check_conv(const DpConvArgs* a) {
   if (a->mode != DP_EDGES_P2L && a->mode != DP_EDGES_L2P && a->mode != DP_EDGES_LLPAIR) return DP_E_UNSUPPORTED;
   if (a->mode == DP_EDGES_LLPAIR ? (!a->pair_a || !a->pair_b || !a->pair_ptr || !a->rowptr || !a->rowend) : (!a->ph_ptr || !a->x_ptr)) return DP_E_BADARG;
   if (a->kind < 0 || a->kind > 3 || a->sh_stride < 9) return DP_E_UNSUPPORTED;
-  if (a->precision != DP_PREC_F32 && a->precision != DP_PREC_BF16) return DP_E_UNSUPPORTED;
-  if (a->precision == DP_PREC_BF16 && (!a->edge_emb_bf || a->emb_flag_row < 0)) return DP_E_BADARG;
+  if (a->precision != DP_PREC_F32 && a->precision != DP_PREC_BF16 && a->precision != DP_PREC_F16X3) return DP_E_UNSUPPORTED;
+  if (a->precision != DP_PREC_F32 && (!a->edge_emb_bf || a->emb_flag_row < 0)) return DP_E_BADARG;
   if (a->max_scatter <= 0) return DP_E_BADARG;
   if ((a->max_scatter + a->slices - 1) / a->slices > NB) return DP_E_TOOLARGE;
   return DP_OK;
@@ -224,6 +362,30 @@ int dp_pack_conv_weights_node_bf16(int32_t kind, const float* fc0_w, const float
 #undef DP_CASE
     default: return DP_E_UNSUPPORTED;
   }
+}
+int dp_conv_w1h_floats(int32_t kind) { return kind >= 0 && kind <= 3 ? dpf::W1H_QUADS * 4 : DP_E_BADARG; }
+int dp_conv_w2h_floats(int32_t kind) {
+  switch (kind) {
+    case 0: return dpf::w2h_quads<0>() * 4; case 1: return dpf::w2h_quads<1>() * 4;
+    case 2: return dpf::w2h_quads<2>() * 4; case 3: return dpf::w2h_quads<3>() * 4;
+    default: return DP_E_BADARG;
+  }
+}
+int dp_pack_conv_weights_node_f16(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
+                                  const float* bn_scale, float* w1h, float* w2h) {
+  if (!fc0_w || !fc0_b || !fc3_w || !fc3_b || !w1h || !w2h) return DP_E_BADARG;
+  switch (kind) {
+#define DP_CASE(K) case K: dpn::pack_w1h<K>(fc0_w, fc0_b, (unsigned short*)w1h); dpn::pack_w2h<K>(fc3_w, fc3_b, bn_scale, (unsigned short*)w2h); return DP_OK;
+    DP_CASE(0) DP_CASE(1) DP_CASE(2) DP_CASE(3)
+#undef DP_CASE
+    default: return DP_E_UNSUPPORTED;
+  }
+}
+int dp_edge_emb_f16(const float* emb, int32_t n_rows, uint16_t* out, void* stream) {
+  if (!emb || !out || n_rows < 0) return DP_E_BADARG;
+  const int total = (n_rows + 1) * 4;
+  hipLaunchKernelGGL(dpn::edge_emb_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, emb, n_rows, out);
+  return (int)hipGetLastError();
 }
 int dp_edge_emb_bf16(const float* emb, int32_t n_rows, uint16_t* out, void* stream) {
   if (!emb || !out || n_rows < 0) return DP_E_BADARG;
@@ -286,7 +448,7 @@ static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, flo
   for (int i = 0; i < n; ++i)
     if (!convs[i].no_tail) fa.lean = 0;
   if (!convs[0].out) return DP_E_BADARG;
-  if (convs[0].precision == DP_PREC_BF16) {        // one instantiation: unsplit, with the half-pass variant
+  if (convs[0].precision == DP_PREC_BF16 || convs[0].precision == DP_PREC_F16X3) {        // one instantiation: unsplit, with the half-pass variant
     for (int i = 0; i < n; ++i) fa.conv[i].path_split = 0;
     return dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
   }

@@ -21,8 +21,9 @@
 //   * column tiles are processed in PAIRS (a "supertile" = 10 in-channels: 2 x (5 in-channels x 3 m), or the 10 in-channels of a
 //     scalar-output tile): both tiles of a pair take the same SH factors per lane, so those are read from LDS once per (node, pair),
 //     and GEMM-B's K = 32 is exactly two in-channels (5 K-chunks per supertile).
-//   * T crosses from "columns on lanes" to "nodes on lanes" as bf16 through a wave-private LDS image [column][k quad][node ^ column][4]:
-//     one ds_write_b64 per (node, tile) - the XOR spreads the 16 lanes of a store over all banks - and two ds_read_b64 per MFMA.
+//   * T crosses from "columns on lanes" to "nodes on lanes" as bf16 through a wave-private LDS image [column][k quad][node][4] with 520-byte
+//     columns (512 + 8: the 16 lanes of a ds_write_b64 - one column each - fall into 16 different 8-byte bank units without any swizzle
+//     arithmetic, the node is an immediate offset): one ds_write_b64 per (node, tile), two ds_read_b64 per MFMA.
 //   * W2 is packed offline as bf16 A fragments (16 bytes per lane and MFMA), BatchNorm scale folded in.
 #pragma once
 #include "dp_conv_node_impl.h"
@@ -104,8 +105,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 
 // gathered operands of supertile (path P, st) for this lane's 8 (HALF: 4) edges, both tiles, as pairs of consecutive edge slots (the operand
-// layout of v_pk_*_f32); requested during the previous supertile's GEMM-B.  No masking: an edge slot that does not exist has a zero hidden
-// vector and a lane without a column stores to the dummy column, so whatever (finite) value arrives there is never seen.
+// layout of v_pk_*_f32); requested during the previous supertile's GEMM-B.  No masking: an edge slot that does not exist lies past the end of
+// the pose-limited buffer resource and reads 0 (and has a zero hidden vector), a lane without a column stores to the dummy column.
 template <int KIND, int MODE, bool HALF, int P>
 __device__ __forceinline__ void load_x2(const XSrc& xs, int lane_l, int st, f32x2 (&xr)[2][3][4]) {
   using S = Spec<KIND>;
@@ -462,7 +463,7 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_r
   XSrc xs;
   xs.rs = xrs;
   const unsigned gstride4 = uni((unsigned)a.gather_stride * 4u);
-  xs.voff_row = (unsigned)gather_row<MODE>(r, 32 * et + 4 * g) * gstride4;
+  xs.voff_row = (unsigned)(32 * et + 4 * g) * gstride4;                         // relative to the pose's first gather row (the resource's base)
 #pragma unroll
   for (int j = 0; j < 8; ++j) xs.soff[j] = (unsigned)(16 * (j >> 2) + (j & 3)) * gstride4;
   float hf[8];
@@ -531,10 +532,11 @@ __device__ __forceinline__ void conv_bf16(const DpConvArgs& a, const Grp& grp, i
     s_inv[tid] = 1.f / (float)max(deg, 1);         // scatter MEAN (torch_scatter: / max(count, 1)), applied to the hidden vectors
   }
   const int n_et = (r.En + 31) >> 5;
-  // buffer resources of the gathered-feature table (rows: pharmacophore nodes for phore->ligand, ligand atoms otherwise) and of the bf16
-  // edge-embedding image (+ its flag row)
-  const int g_rows = MODE == DP_EDGES_P2L ? a.ph_ptr[a.B] : a.lig_ptr[a.B];
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.gather_tab, (unsigned)g_rows * (unsigned)a.gather_stride * 4u);
+  // buffer resources: the POSE's rows of the gathered-feature table (pharmacophore nodes for phore->ligand, ligand atoms otherwise: an edge
+  // slot past the pose's last node reads 0 - never the next pose's rows, whose NaN would survive the multiplication by a zero hidden vector
+  // and leak a diverged neighbour into this pose) and the bf16 edge-embedding image (+ its flag row)
+  const int g_row0 = MODE == DP_EDGES_P2L ? r.p0 : r.l0;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.gather_tab + (size_t)g_row0 * a.gather_stride, (unsigned)r.En * (unsigned)a.gather_stride * 4u);
   const __amdgpu_buffer_rsrc_t ers = make_rsrc(a.edge_emb_bf, (unsigned)(a.emb_flag_row + 1) * (unsigned)(EMB_ROW * 2));
 #pragma unroll 1
   for (int et = 0; et < n_et; ++et) {

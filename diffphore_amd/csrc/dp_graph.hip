@@ -150,6 +150,34 @@ __device__ __forceinline__ void store_row_bf16(uint16_t* __restrict__ dst, const
 __device__ __forceinline__ void store_flag_row_bf16(uint16_t* __restrict__ tab, int n_rows, int tid) {
   if (tid < 32) tab[(size_t)n_rows * 32 + tid] = tid == 20 ? (uint16_t)0x3F80 : (uint16_t)0;
 }
+// two-limb fp16 image of an embedded edge row for the DP_PREC_F16X3 node-side conv: 64 fp16 = hi limbs (features 0..19 | zeros to 32) | lo limbs
+// (hi = rne16(v), lo = rne16(v - hi); the same split as dp_conv_node_f16_impl.h: split2)
+__device__ __forceinline__ void store_row_f16x2(uint16_t* __restrict__ dst, const float* v) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const h2 hi = __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, h2);
+    const h2 lo = __builtin_convertvector((f2){v[2 * i] - (float)hi[0], v[2 * i + 1] - (float)hi[1]}, h2);
+    d[i] = __builtin_bit_cast(uint32_t, hi);
+    d[16 + i] = __builtin_bit_cast(uint32_t, lo);
+  }
+#pragma unroll
+  for (int i = 10; i < 16; ++i) { d[i] = 0u; d[16 + i] = 0u; }
+}
+__device__ __forceinline__ void store_flag_row_f16x2(uint16_t* __restrict__ tab, int n_rows, int tid) {
+  if (tid < 64) tab[(size_t)n_rows * 64 + tid] = tid == 20 ? (uint16_t)0x3C00 : (uint16_t)0;
+}
+// DpWork.node_f16 (as dp_forward sets it in the kernels' copy of the workspace): which 16-bit image the node-side convs of this forward read
+__device__ __forceinline__ void store_row_16(uint16_t* __restrict__ tab, size_t row, const float* v, int f16) {
+  if (f16) store_row_f16x2(tab + row * 64, v);
+  else store_row_bf16(tab + row * 32, v);
+}
+__device__ __forceinline__ void store_flag_row_16(uint16_t* __restrict__ tab, int n_rows, int tid, int f16) {
+  if (f16) store_flag_row_f16x2(tab, n_rows, tid);
+  else store_flag_row_bf16(tab, n_rows, tid);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ligand graph per pose: radius graph (torch_cluster CUDA semantics) + bond edges, CSR by scatter node, edge embedding, SH
@@ -175,7 +203,7 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWork k) {
   };
   const int pr0 = b.llp_ptr ? b.llp_ptr[p] : 0;
   const bool pairs = b.llp_ptr != nullptr && k.ll_pair_rad != nullptr && k.ll_pair_bond != nullptr;
-  if (k.ll_emb_bf && p == 0) store_flag_row_bf16(k.ll_emb_bf, b.ll_cap, tid);
+  if (k.ll_emb_bf && p == 0) store_flag_row_16(k.ll_emb_bf, b.ll_cap, tid, k.node_f16);
   if (pairs)
     for (int i = tid; i < N * N; i += 256) { k.ll_pair_rad[pr0 + i] = -1; k.ll_pair_bond[pr0 + i] = -1; }
   __syncthreads();
@@ -278,7 +306,7 @@ __global__ __launch_bounds__(256) void lig_edges_kernel(DpBatch b, DpWeights w, 
     matvec_acc<NS, NS>(w.lig_edge.w0, 44, 24, g, h);
     mlp_tail20(w.lig_edge, h, out);
     store_row<NS>(k.ll_emb + (size_t)o * NS, out);
-    if (k.ll_emb_bf) store_row_bf16(k.ll_emb_bf + (size_t)o * 32, out);
+    if (k.ll_emb_bf) store_row_16(k.ll_emb_bf, (size_t)o, out, k.node_f16);
   }
 }
 
@@ -352,7 +380,7 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
   __shared__ float s_den[256];
   const int p = blockIdx.x / slices, slice = blockIdx.x % slices, tid = threadIdx.x;
   const int l0g = b.lig_ptr[p], NLp = b.lig_ptr[p + 1] - l0g, p0 = b.ph_ptr[p], NP = b.ph_ptr[p + 1] - p0;
-  if (k.x_emb_bf && blockIdx.x == 0) store_flag_row_bf16(k.x_emb_bf, b.n_x, tid);
+  if (k.x_emb_bf && blockIdx.x == 0) store_flag_row_16(k.x_emb_bf, b.n_x, tid, k.node_f16);
   // ONE EDGE PER THREAD.  `slices` workgroup slots per pose are launched (enough for the batch's largest pose); a pose deals its atoms -
   // whole atoms: the softmax denominator is per atom - to ceil(N_l / floor(256 / N_p)) of them, at most 256 edges each, and its other slots
   // leave at once.  (One workgroup per pose ran 4 dependent rounds of ~3 000 instructions on two waves per SIMD, and evaluated the distance
@@ -416,7 +444,7 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
     matvec_acc<NS, NS>(w.x_edge.w0, 73, 20, g, h);
     mlp_tail20(w.x_edge, h, out);
     store_row<NS>(k.x_emb + (size_t)(x0 + e) * NS, out);
-    if (k.x_emb_bf) store_row_bf16(k.x_emb_bf + (size_t)(x0 + e) * 32, out);
+    if (k.x_emb_bf) store_row_16(k.x_emb_bf, (size_t)(x0 + e), out, k.node_f16);
   }
   // sign rule (:813-816) and softmax weight (:839,:845-848)
   {
@@ -703,12 +731,20 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   // the three graph / embedding kernels only share their inputs (positions, time parameters): the ligand radius graph runs on the second
   // stream beside the node embeddings and the cross edges (each is one workgroup per pose and latency-bound on its own)
   if (aux) fork();
-  // the bf16 images of the edge embeddings are written only for the convs that read them (DP_PREC_BF16, node-side)
+  // node-side convs of an fp32 model at fp32 grade on the 16-bit matrix pipe (DP_PREC_F16X3, two fp16 limbs per operand) when the blob carries
+  // those images; the kernel has no path-split / conv-split form, so launches that take the path split (small batches) stay on the fp32 kernel
+  const int nb_ = dp_conv_node_max_nodes();
+  auto split_of = [&](int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B, slices_)); };
+  const bool f16_ok = node_side && w->precision == DP_PREC_F32 && k->node_f16 != 0 && w->p2l_conv[0].w2h != nullptr && k->x_emb_bf != nullptr;
+  const bool f16_lig = f16_ok && !split_of((b->max_nl + nb_ - 1) / nb_) && (!node_ll || (w->lig_conv[0].w2h != nullptr && k->ll_emb_bf != nullptr));
+  const bool f16_ph = f16_ok && !split_of((b->max_np + nb_ - 1) / nb_);
+  // the 16-bit images of the edge embeddings are written only for the convs that read them (DP_PREC_BF16 or DP_PREC_F16X3, node-side)
   const bool bf_node = node_side && w->precision == DP_PREC_BF16;
   if (bf_node && (!k->x_emb_bf || (node_ll && !k->ll_emb_bf))) return DP_E_BADARG;
   DpWork kx = *k;
-  if (!bf_node) kx.x_emb_bf = kx.ll_emb_bf = nullptr;
-  if (!node_ll) kx.ll_emb_bf = nullptr;
+  kx.node_f16 = (f16_lig || f16_ph) ? 1 : 0;
+  if (!bf_node && !kx.node_f16) kx.x_emb_bf = kx.ll_emb_bf = nullptr;
+  if (!node_ll || !(bf_node || f16_lig)) kx.ll_emb_bf = nullptr;
   {
     // the N x N pair tables are filled (and verified: status bit 1) only when the node-side ligand-ligand conv will read them
     DpWork kg = kx;
@@ -810,6 +846,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.no_tail = b->no_tail_nl;
         c.path_split = node_path_split(B, slices_pl);
         c.pair_a = k->ll_pair_rad; c.pair_b = k->ll_pair_bond; c.pair_ptr = b->llp_ptr;
+        if (f16_lig) { c.precision = DP_PREC_F16X3; c.w1n = w->lig_conv[l].w1h; c.w2n = w->lig_conv[l].w2h; }
       }
     }
     for (int nv = 0; nv < 2; ++nv) {
@@ -821,7 +858,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
       c.out = hl2; c.accumulate = 1;
       if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); c.no_tail = b->no_tail_np;
-                       c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x; }
+                       c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x;
+                       if (f16_lig) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; } }
     }
     if (node_side && fuse && node_ll && k->conv_fuse != 2) {
       // one launch: the three convs scatter onto the same atoms and their outputs add up (:703-706)
@@ -856,7 +894,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.w1p = cw.w1p; c.w2p = cw.w2p; c.bn_scale = cw.bn_scale; c.bn_shift = cw.bn_shift;
         c.out = hp2; c.accumulate = 1;
         if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); c.no_tail = b->no_tail_nl;
-                         c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x; }
+                         c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x;
+                         if (f16_ph) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; } }
       }
       if (node_side && fuse) {
         if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);

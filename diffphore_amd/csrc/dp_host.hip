@@ -54,8 +54,8 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   w.x_sh = c.take<float>(nx * 9);
   w.x_nsh = c.take<float>(nx * 9);
   w.x_ew = c.take<float>(nx);
-  w.x_emb_bf = c.take<uint16_t>((nx + 1) * 32);
-  w.ll_emb_bf = c.take<uint16_t>((cap + 1) * 32);
+  w.x_emb_bf = c.take<uint16_t>((nx + 1) * 64);
+  w.ll_emb_bf = c.take<uint16_t>((cap + 1) * 64);
   w.h_l[0] = c.take<float>(nl * 100);
   w.h_l[1] = c.take<float>(nl * 100);
   w.h_p[0] = c.take<float>(np * 100);
@@ -78,6 +78,7 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   float* rot_ = c.take<float>(B * 3);
   float* tor_ = c.take<float>(nt);
   w.edge_bf16x6 = 1;                                  // default: the edge-side convs of an fp32 model on the bf16 pipe (fp32-grade split)
+  w.node_f16 = 1;                                     // default: the node-side convs of an fp32 model as two fp16 limbs on the 16-bit pipe (fp32-grade)
   if (k) *k = w;
   if (tr) *tr = tr_;
   if (rot) *rot = rot_;
@@ -134,6 +135,9 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
       if (f != 1 && precision == DP_PREC_F32) {       // every family but phore-phore (low degree: edge-side stays better): node-side layout as well
         snprintf(nm, sizeof(nm), "%s.%d.w1n", FAMS[f], l); s.add(nm, dp_conv_w1n_floats(l));
         snprintf(nm, sizeof(nm), "%s.%d.w2n", FAMS[f], l); s.add(nm, dp_conv_w2n_floats(l));
+        // ... and once more as two-limb fp16 fragments (dp_pack_conv_weights_node_f16): DP_PREC_F16X3, what these convs run on by default
+        snprintf(nm, sizeof(nm), "%s.%d.w1h", FAMS[f], l); s.add(nm, dp_conv_w1h_floats(l));
+        snprintf(nm, sizeof(nm), "%s.%d.w2h", FAMS[f], l); s.add(nm, dp_conv_w2h_floats(l));
       }
       if (f != 1 && precision == DP_PREC_BF16) {      // the same families as bf16 MFMA fragments (dp_pack_conv_weights_node_bf16)
         snprintf(nm, sizeof(nm), "%s.%d.w1n", FAMS[f], l); s.add(nm, dp_conv_w1b_floats(l));
@@ -253,6 +257,8 @@ int dp_weights_bind(const float* blob, int32_t precision, const DpModelScalars* 
     snprintf(nm, sizeof(nm), "%s.w1n", name); c.w1n = find(nm);
     snprintf(nm, sizeof(nm), "%s.w2n", name); c.w2n = find(nm);
     snprintf(nm, sizeof(nm), "%s.w2x", name); c.w2x = find(nm);
+    snprintf(nm, sizeof(nm), "%s.w1h", name); c.w1h = find(nm);
+    snprintf(nm, sizeof(nm), "%s.w2h", name); c.w2h = find(nm);
   };
   w->lig_emb = find("lig_emb"); w->lig_lin_w = find("lig_lin_w"); w->lig_lin_b = find("lig_lin_b");
   w->boarder_emb = find("boarder_emb"); w->boarder_lin_w = find("boarder_lin_w"); w->boarder_lin_b = find("boarder_lin_b");

@@ -59,7 +59,7 @@ class DpMlp(C.Structure):
 
 
 class DpConvW(C.Structure):
-    _fields_ = [(n, VOIDP) for n in ("w1p", "w2p", "bn_scale", "bn_shift", "w1n", "w2n", "w2x")]
+    _fields_ = [(n, VOIDP) for n in ("w1p", "w2p", "bn_scale", "bn_shift", "w1n", "w2n", "w2x", "w1h", "w2h")]
 
 
 class DpWeights(C.Structure):
@@ -84,7 +84,7 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("prof_events", VOIDP), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("path_split", c_i32), ("conv_fuse", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("path_split", c_i32), ("conv_fuse", c_i32), ("node_f16", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -214,7 +214,8 @@ class DeviceModel:
                 node_bf = name != "ph_conv" and prec == _lib.PREC_BF16
                 # edge-side in an fp32 model (phore-phore always, ligand-ligand for large ligands): bf16x6 second layer as well
                 x6 = ((name == "ph_conv" and l < 3) or name == "lig_conv") and prec == _lib.PREC_F32
-                for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6, node_bf16=node_bf).items():
+                # node-side in an fp32 model: the fp32-grade two-limb fp16 fragments as well (DP_PREC_F16X3: what those convs run on by default)
+                for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6, node_bf16=node_bf, node_f16=node).items():
                     H[f"{name}.{l}.{part}"] = t
         for part, t in packing.pack_conv(sd, "final_conv", _lib.CONV_FINAL, prec).items():
             H[f"final_conv.{part}"] = t
@@ -363,7 +364,15 @@ class _GraphView:
     complex's own tensors wherever they already are) + the C struct pointing at them.  Cached on the graph object and shared by its samples
     (`HeteroData.sample_copy` copies the attribute); `key` = identity + in-place version of every source object, re-checked once per device
     batch, so a replaced or in-place edited static tensor rebuilds the view."""
-    __slots__ = ("struct", "addr", "keep", "key", "n")
+    __slots__ = ("struct", "addr", "keep", "key", "n", "src")
+
+    # The view holds a ctypes struct of raw pointers: it is a cache, never state.  A pickled / deep-copied graph simply carries no view (None)
+    # and rebuilds it at its next packing - torch.save, multiprocessing hand-off and copy.deepcopy of a packed graph keep working.
+    def __reduce__(self):
+        return (type(None), ())
+
+    def __deepcopy__(self, memo):
+        return None
 
     @staticmethod
     def sources(g):
@@ -379,12 +388,22 @@ class _GraphView:
 
     @staticmethod
     def key_of(src):
-        # identity of every source object + the in-place version counter of the tensors among them
-        return tuple([id(v) for v in src]) + tuple([v._version if hasattr(v, "_version") else 0 for v in src])
+        # identity of every source object + the in-place version counter of the tensors among them; sources without a version counter (the
+        # reference keeps mask_rotate as an ndarray or a list of them) are hashed by content, as score_model._cheap_key does
+        def ver(v):
+            if hasattr(v, "_version"):
+                return v._version
+            if isinstance(v, np.ndarray):
+                return hash(v.tobytes())
+            if isinstance(v, (list, tuple)):
+                return hash(tuple(ver(x) for x in v))
+            return 0
+        return tuple([id(v) for v in src]) + tuple([ver(v) for v in src])
 
     def __init__(self, g):
         src = self.sources(g)
         self.key = self.key_of(src)
+        self.src = src                                  # keeps the source objects alive: their ids (part of the key) cannot be recycled
         x, ei, ea, em, mr, fp, na1, na2, px, ppos, pnorm, ptype, pei = src
 
         def T(v, dt, shape=None):
@@ -806,6 +825,11 @@ class Engine:
         if x6 not in ("0", "1"):
             raise ValueError(f"DIFFPHORE_EDGE_X6 must be 0 or 1 (got {x6!r})")
         self.ws.struct.edge_bf16x6 = int(x6)         # 1 (default): edge-side convs of an fp32 model as a bf16x6 split; 0: exact fp32 MFMA everywhere
+        f16 = os.environ.get("DIFFPHORE_NODE_F16", "1")
+        if f16 not in ("0", "1"):
+            raise ValueError(f"DIFFPHORE_NODE_F16 must be 0 or 1 (got {f16!r})")
+        self.ws.struct.node_f16 = int(f16)           # 1 (default): node-side convs of an fp32 model as two fp16 limbs per operand (DP_PREC_F16X3); 0: fp32 MFMA
+        self.node_side_convs = ("f16x3" if f16 == "1" else "f32") if model.precision == "f32" else model.precision
         self.edge_side_convs = ("bf16x6" if x6 == "1" else "f32") if model.precision == "f32" else model.precision
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         ps = os.environ.get("DIFFPHORE_PATH_SPLIT", "auto")

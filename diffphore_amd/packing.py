@@ -32,11 +32,12 @@ def bn_affine(sd: Dict[str, torch.Tensor], prefix: str, irreps, eps: float = 1e-
 
 
 def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: int = 0, node_side: bool = False, x6: bool = False,
-              node_bf16: bool = False) -> Dict[str, torch.Tensor]:
+              node_bf16: bool = False, node_f16: bool = False) -> Dict[str, torch.Tensor]:
     """fc.0 / fc.3 / batch_norm of one TensorProductConvLayer -> MFMA operand order (host tensors).  `node_side` adds the layout of
     the node-side kernel (dp_conv_node_impl.h: layer convs over the dense cross edge sets, fp32); `x6` adds the second layer packed for
     DP_PREC_BF16X6 (`w2x`: what the edge-side convs of an fp32 model run on, DpConvW.w2x); `node_bf16` adds the bf16 MFMA fragments of the
-    DP_PREC_BF16 node-side kernel (dp_conv_node_bf16_impl.h) under the same names `w1n` / `w2n`."""
+    DP_PREC_BF16 node-side kernel (dp_conv_node_bf16_impl.h) under the same names `w1n` / `w2n`; `node_f16` adds the two-limb fp16 fragments of
+    the fp32-grade DP_PREC_F16X3 node-side kernel (dp_conv_node_f16_impl.h) as `w1h` / `w2h` (DpConvW.w1h / w2h)."""
     L = _lib.lib()
     dims = _lib.conv_dims(kind)
     fc0_w = sd[prefix + ".fc.0.weight"].float().contiguous()
@@ -65,6 +66,12 @@ def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: in
         _lib.check(L.dp_pack_conv_weights_node_bf16(kind, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
                                                     scale.data_ptr(), w1b.data_ptr(), w2b.data_ptr()), "dp_pack_conv_weights_node_bf16")
         out.update(w1n=w1b, w2n=w2b)
+    if node_f16:
+        w1h = torch.empty(L.dp_conv_w1h_floats(kind), dtype=torch.float32)
+        w2h = torch.empty(L.dp_conv_w2h_floats(kind), dtype=torch.float32)
+        _lib.check(L.dp_pack_conv_weights_node_f16(kind, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
+                                                   scale.data_ptr(), w1h.data_ptr(), w2h.data_ptr()), "dp_pack_conv_weights_node_f16")
+        out.update(w1h=w1h, w2h=w2h)
     if x6:
         w1_ = torch.empty(L.dp_conv_w1p_floats(kind), dtype=torch.float32)
         w2x = torch.empty(L.dp_conv_w2p_floats(kind, _lib.PREC_BF16X6), dtype=torch.float32)

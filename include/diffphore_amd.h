@@ -31,7 +31,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 9
+#define DP_ABI_VERSION 10
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -59,11 +59,16 @@ enum DpPrecision {
   DP_PREC_BF16X6 = 3,   /* 3-way bf16 operand split, 6 cross products, fp32 accumulate: ~2^-24 relative, fp32-grade */
   DP_PREC_BF16X3 = 2,   /* 2-way bf16 split, 3 cross products: ~2^-17 relative */
   DP_PREC_BF16X9 = 4,   /* 3-way split, all 9 cross products: every fp32 x fp32 product exact (3 x 8 significand bits), fp32 accumulate */
-  DP_PREC_BF16 = 5      /* plain bf16 OPERANDS, fp32 accumulate ("bf16 mixed precision", BASELINE.json configs[4]): radial MLP weights and
+  DP_PREC_BF16 = 5,     /* plain bf16 OPERANDS, fp32 accumulate ("bf16 mixed precision", BASELINE.json configs[4]): radial MLP weights and
                            activations, the tensor-product operand and the node-side intermediate T are rounded to bf16 once (2^-9
                            relative each); geometry, spherical harmonics, edge-embedding MLPs, accumulation, BatchNorm shift and the
                            residual stream stay fp32.  Node-side kernel: dp_conv_node_bf16_impl.h (one v_mfma_f32_16x16x32_bf16 per node,
                            column tile and pass).  Edge-side kernel: the bf16x3 arithmetic (its weights are packed as for DP_PREC_BF16X3). */
+  DP_PREC_F16X3 = 6     /* node-side kernel only (dp_conv_node_f16_impl.h), fp32-GRADE: every operand of the three GEMMs as TWO fp16 limbs
+                           (hi = rne16(v), lo = rne16(v - hi): 22 significand bits; exact power-of-two scales map the operands into fp16's
+                           range), cross products hi*hi + hi*lo + lo*hi (+ lo*lo in the second contraction) on v_mfma_f32_16x16x32_f16, fp32
+                           accumulate.  Held to the same tolerances as DP_PREC_F32.  Precondition: |features|, |edge embedding| < 65504.
+                           Not a model precision: dp_forward uses it for the node-side convs of a DP_PREC_F32 model (DpWork.node_f16). */
 };
 
 /* formulation of the fused conv: per-edge radial GEMM, or node-side contraction (dense cross edge sets; DP_PREC_F32 or DP_PREC_BF16) */
@@ -137,7 +142,8 @@ typedef struct DpConvArgs {
   const int32_t *pair_a, *pair_b, *pair_ptr;
   /* DP_PREC_BF16 node-side kernel only: the edge embedding once more as bf16 rows of 32 (64 bytes: features 0..19 | 0 ... ), plus ONE
    * flag row (all zero but feature 20 = 1.0) at row index emb_flag_row that stands for "this edge does not exist" (dp_forward: written by
-   * the edge-embedding kernels beside edge_emb; standalone callers: dp_edge_emb_bf16) */
+   * the edge-embedding kernels beside edge_emb; standalone callers: dp_edge_emb_bf16).  DP_PREC_F16X3: rows of 64 fp16 (128 bytes: hi limbs |
+   * lo limbs, dp_edge_emb_f16) */
   const uint16_t* edge_emb_bf;
   int32_t emb_flag_row;
   int32_t no_tail;           /* node-side only, a HINT: 1 = the caller guarantees that no pose of the batch ends on a pass of <= 16 edge slots
@@ -165,6 +171,15 @@ int dp_pack_conv_weights_node_bf16(int32_t kind, const float* fc0_w, const float
                                    const float* bn_scale, float* w1b, float* w2b);
 /* DEVICE: emb [n_rows, 20] fp32 -> out [(n_rows + 1), 32] bf16 (round to nearest even), row n_rows = the flag row (DpConvArgs.edge_emb_bf) */
 int dp_edge_emb_bf16(const float* emb, int32_t n_rows, uint16_t* out, void* stream);
+/* the same for the DP_PREC_F16X3 node-side kernel: two-limb fp16 MFMA fragments (w2h: W2 * 2^w, the exponent w in the image's header; sizes in
+ * FLOATS of the blob); DpConvArgs.w1n / w2n point at these images when DpConvArgs.precision == DP_PREC_F16X3 */
+int dp_conv_w1h_floats(int32_t kind);
+int dp_conv_w2h_floats(int32_t kind);
+int dp_pack_conv_weights_node_f16(int32_t kind, const float* fc0_w, const float* fc0_b, const float* fc3_w, const float* fc3_b,
+                                  const float* bn_scale, float* w1h, float* w2h);
+/* DEVICE: emb [n_rows, 20] fp32 -> out [(n_rows + 1), 64] fp16: per row the hi limbs (20 features | zeros to 32) then the lo limbs (32), row
+ * n_rows = the flag row (hi feature 20 = 1.0); DpConvArgs.edge_emb_bf of a DP_PREC_F16X3 launch */
+int dp_edge_emb_f16(const float* emb, int32_t n_rows, uint16_t* out, void* stream);
 /* `bn_scale` (HOST, [D_out], the `scale` output of dp_pack_bn; NULL = ones) is folded into the packed second layer: the node-side
  * kernel applies the scatter mean and the BatchNorm scale inside its operands and only ADDS bn_shift in its epilogue, which is what lets
  * several convs share one set of accumulators (below).  DpConvArgs.bn_scale is therefore ignored by the node-side kernel. */
@@ -277,6 +292,8 @@ typedef struct DpConvW {
                                  kernel in an fp32 model (phore-phore: low degree; torsion bonds) then run their radial contraction as a 3-way
                                  bf16 split with 6 cross products on the bf16 pipe (16x the fp32 MFMA rate) - ~2^-24 relative per product, fp32
                                  accumulate, held to the same tolerances as the fp32 kernel (DpWork.edge_bf16x6 = 0 turns it off) */
+  const float *w1h, *w2h;     /* the node-side convs of an fp32 model once more as two-limb fp16 fragments (dp_pack_conv_weights_node_f16), or NULL:
+                                 DP_PREC_F16X3, fp32-grade on the 16-bit matrix pipe (DpWork.node_f16 = 0 turns it off) */
 } DpConvW;
 
 /* Device pointers into the uploaded parameter blob.  Reference names: score_model_phore.py:248-291, 524-641. */
@@ -323,8 +340,9 @@ typedef struct DpWork {
   float* pp_emb;                    /* [n_pp,20] */
   float *x_emb, *x_sh, *x_nsh;      /* [n_x,20], [n_x,9], [n_x,9] */
   float* x_ew;                      /* [n_x] exp(total_weight) */
-  uint16_t *x_emb_bf, *ll_emb_bf;   /* [(n_x + 1), 32], [(ll_cap + 1), 32] bf16 images of x_emb / ll_emb + flag row (DpConvArgs.edge_emb_bf): written
-                                       by the edge-embedding kernels when the model's precision is DP_PREC_BF16, untouched otherwise */
+  uint16_t *x_emb_bf, *ll_emb_bf;   /* [(n_x + 1), 64], [(ll_cap + 1), 64] 16-bit images of x_emb / ll_emb + flag row (DpConvArgs.edge_emb_bf), written by the
+                                       edge-embedding kernels for the node-side convs that read them: bf16 rows of 32 when the model's precision is
+                                       DP_PREC_BF16, two-limb fp16 rows of 64 for DP_PREC_F16X3 (fp32 model, node_f16), untouched otherwise */
   float *h_l[2], *h_p[2];           /* [n_lig,100], [n_ph,100] ping-pong */
   float *c_emb, *c_sh;              /* [n_lig,20], [n_lig,9] centre edges */
   float* gpred;                     /* [B,12] */
@@ -363,6 +381,9 @@ typedef struct DpWork {
   int32_t conv_fuse;                /* node-side convs of a layer that scatter onto the same nodes: 0 = one fused launch per side (default),
                                        1 = one launch per conv, 2 = the two cross convs fused but the ligand-ligand conv on its own launch,
                                        3 = fused launches but never the conv split of small batches (1-3: A/B runs and tests) */
+  int32_t node_f16;                 /* 1 = the node-side convs of an fp32 model use DpConvW.w1h / w2h when present and the launch is not path-split:
+                                       DP_PREC_F16X3, fp32-grade two-limb fp16 operands on the 16-bit matrix pipe (the default dp_work_bind sets);
+                                       0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
 } DpWork;
 
 typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */

@@ -59,7 +59,8 @@ def test_build_identity_and_ablation_builds_are_refused(monkeypatch):
 
 
 def test_workspace_defaults_are_positive_sense():
-    """dp_work_bind initialises DpWork.edge_bf16x6 = 1 (ABI 9: 1 = the fp32-grade bf16x6 split on the edge-side convs of an fp32 model, 0 = exact fp32)"""
+    """dp_work_bind initialises DpWork.edge_bf16x6 = 1 (ABI 9: 1 = the fp32-grade bf16x6 split on the edge-side convs of an fp32 model, 0 = exact fp32)
+    and DpWork.node_f16 = 1 (ABI 10: 1 = the fp32-grade two-limb fp16 split on the node-side convs of an fp32 model, 0 = exact fp32 MFMA)"""
     L = engine._declare()
     b = engine.DpBatch()
     b.B, b.n_lig, b.n_ph, b.n_bond, b.n_tor, b.n_pp, b.n_x, b.ll_cap = 2, 10, 12, 20, 4, 30, 120, 300
@@ -67,7 +68,7 @@ def test_workspace_defaults_are_positive_sense():
     w = engine.DpWork()
     ptrs = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
     assert L.dp_work_bind(C.byref(b), 1 << 20, n, C.byref(w), *[C.byref(p) for p in ptrs]) == 0
-    assert w.edge_bf16x6 == 1 and w.conv_fuse == 0 and w.aux_mode == 0
+    assert w.edge_bf16x6 == 1 and w.node_f16 == 1 and w.conv_fuse == 0 and w.aux_mode == 0
 
 
 def test_struct_layouts_match_the_compiler():
@@ -93,7 +94,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
     base = 1 << 20                                                            # a fake (aligned) device address: bind touches no memory
     assert L.dp_work_bind(C.byref(b), base, n1, C.byref(w), *[C.byref(p) for p in ptrs]) == 0
     fields = [getattr(w, n) for n, _ in engine.DpWork._fields_ if n not in ("h_l", "h_p", "prof_start", "prof_stop", "prof_layer",
-                                                                            "prof_conv", "prof_events", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "path_split", "edge_bf16x6", "ll_node_max_atoms", "aux_mode")]
+                                                                            "prof_conv", "prof_events", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "path_split", "edge_bf16x6", "ll_node_max_atoms", "aux_mode", "node_f16")]
     fields += list(w.h_l) + list(w.h_p) + [p.value for p in ptrs]
     assert all(f is not None and base <= f < base + n1 and f % 256 == 0 for f in fields) and len(set(fields)) == len(fields)
     assert L.dp_work_bind(C.byref(b), base, n1 - 1, C.byref(w), *[C.byref(p) for p in ptrs]) == -3
@@ -112,6 +113,8 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
         names = [sg.name.decode() for sg in segs]
         assert len(set(names)) == n and "p2l_conv.3.w2p" in names and ("p2l_conv.3.w2n" in names) == (prec in (_lib.PREC_F32, _lib.PREC_BF16))
         assert ("ph_conv.0.w2x" in names) == ("tor_conv.w2x" in names) == (prec == _lib.PREC_F32) and "ph_conv.3.w2x" not in names
+        # the node-side families of an fp32 model carry the two-limb fp16 images too (DP_PREC_F16X3), phore-phore (edge-side) does not
+        assert ("p2l_conv.3.w2h" in names) == ("lig_conv.0.w1h" in names) == (prec == _lib.PREC_F32) and "ph_conv.0.w2h" not in names
 
 
 def test_pack_bn_matches_the_python_packer():

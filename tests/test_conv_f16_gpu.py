@@ -1,0 +1,264 @@
+"""DP_PREC_F16X3: the fp32-GRADE node-side conv on the 16-bit matrix pipe (dp_conv_node_f16_impl.h: every GEMM operand as two fp16 limbs,
+cross products on v_mfma_f32_16x16x32_f16, fp32 accumulate), through the C ABI, against the fp64 oracle (oracle/e3.py: the reference
+operator, /root/reference/src/models/score_model_phore.py:134-149) at the SAME tolerance as the exact-fp32 kernels of tests/test_conv_gpu.py:
+2e-5 of the output's largest magnitude."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffphore_amd import _lib, packing, weights  # noqa: E402
+from test_conv_gpu import _dev, _i32, _oracle_conv, _run  # noqa: E402
+
+TOL = 2e-5
+
+
+def _emb_h(emb_dev):
+    """[n + 1, 64] two-limb fp16 image (+ flag row) of an edge-embedding table, made by the library's own conversion kernel"""
+    n = emb_dev.shape[0]
+    out = torch.zeros((n + 1) * 64, dtype=torch.int16, device="cuda")
+    _lib.check(_lib.lib().dp_edge_emb_f16(emb_dev.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "dp_edge_emb_f16")
+    return out, n
+
+
+def test_edge_emb_f16_rows():
+    g = torch.Generator().manual_seed(1)
+    emb = torch.randn(37, 20, generator=g) * torch.logspace(-6, 3, 37).unsqueeze(1)       # 1e-6 .. 1e3: normal, subnormal and large limbs
+    out, n = _emb_h(_dev(emb))
+    got = out.cpu().view(n + 1, 64)
+    hi = emb.to(torch.float16)
+    lo = (emb - hi.float()).to(torch.float16)
+    assert torch.equal(got[:n, :20], hi.view(torch.int16)) and torch.equal(got[:n, 32:52], lo.view(torch.int16))
+    assert int(got[:n, 20:32].abs().sum()) == 0 and int(got[:n, 52:].abs().sum()) == 0
+    flag = torch.zeros(64, dtype=torch.int16)
+    flag[20] = 0x3C00
+    assert torch.equal(got[n], flag)
+    # two limbs carry >= 21 significant bits; where the lo limb is a subnormal fp16 the error is absolute: half of 2^-24
+    rec = hi.double() + lo.double()
+    assert ((rec - emb.double()).abs() <= torch.clamp(emb.double().abs() * 2.0 ** -21, min=2.0 ** -25)).all()
+
+
+def _cross_case(kind, mode, seed, NL, NP, feat_scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    sd = weights.init_state_dict(11)
+    fam = "phore_to_lig_conv_layers" if mode == "p2l" else "lig_to_phore_norm_conv_layers"
+    if kind == 3 and mode == "l2p":
+        fam = "lig_to_phore_conv_layers"
+    prefix = f"encoder.{fam}.{kind}"
+    dims = _lib.conv_dims(kind)
+    B = len(NL)
+    lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+    ph_ptr = np.concatenate([[0], np.cumsum(NP)])
+    x_ptr = np.concatenate([[0], np.cumsum(np.asarray(NL) * np.asarray(NP))])
+    hl = torch.randn(int(lig_ptr[-1]), dims["d_in"], generator=g) * feat_scale
+    hp = torch.randn(int(ph_ptr[-1]), dims["d_in"], generator=g) * feat_scale
+    E = int(x_ptr[-1])
+    emb = torch.randn(E, 20, generator=g)
+    sh = torch.randn(E, 9, generator=g)
+    sh[:, 0] = 1.0
+    src = torch.cat([torch.arange(lig_ptr[b], lig_ptr[b + 1]).repeat_interleave(NP[b]) for b in range(B)])
+    dst = torch.cat([torch.arange(ph_ptr[b], ph_ptr[b + 1]).repeat(NL[b]) for b in range(B)])
+    attr = torch.cat([emb, hl[src, :20], hp[dst, :20]], 1)
+    pk = packing.pack_conv(sd, prefix, kind, _lib.PREC_F32, node_f16=True)
+    if mode == "p2l":
+        ref = _oracle_conv(sd, prefix, kind, hp[dst], attr, sh, src, hl.shape[0])
+        n_out, gt, scat_ptr, m, mx = hl.shape[0], hp, lig_ptr, _lib.EDGES_P2L, max(NL)
+    else:
+        ref = _oracle_conv(sd, prefix, kind, hl[src], attr, sh, dst, hp.shape[0])
+        n_out, gt, scat_ptr, m, mx = hp.shape[0], hl, ph_ptr, _lib.EDGES_L2P, max(NP)
+    nb = _lib.lib().dp_conv_node_max_nodes()
+    resid = torch.randn(n_out, dims["d_in"], generator=g)
+    emb_d = _dev(emb)
+    embh, flag_row = _emb_h(emb_d)
+    base = dict(kind=kind, mode=m, B=B, slices=(mx + nb - 1) // nb, precision=_lib.PREC_F16X3, max_scatter=mx, scat_ptr=_dev(_i32(scat_ptr)),
+                lig_ptr=_dev(_i32(lig_ptr)), ph_ptr=_dev(_i32(ph_ptr)), x_ptr=_dev(_i32(x_ptr)), gather_tab=_dev(gt), gather_stride=dims["d_in"],
+                attr1_tab=_dev(hl), attr1_stride=dims["d_in"], attr2_tab=_dev(hp), attr2_stride=dims["d_in"], attr_swap=0,
+                edge_emb=emb_d, edge_emb_bf=embh, emb_flag_row=flag_row, edge_sh=_dev(sh), sh_stride=9, w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]),
+                w1n=_dev(pk["w1h"]), w2n=_dev(pk["w2h"]), bn_scale=_dev(pk["bn_scale"]), bn_shift=_dev(pk["bn_shift"]), out_stride=dims["d_out"],
+                accumulate=0, resid=_dev(resid), resid_stride=dims["d_in"], resid_width=dims["d_in"], algo=_lib.ALGO_NODE)
+    return base, ref, resid, dims, n_out, pk
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", ["p2l", "l2p"])
+def test_conv_node_f16_dense_cross(kind, mode):
+    """ragged poses: 1 node, < 8, 8..16, > 16 nodes; 5 / 17 / 32 / 33 / 79 edges per node = full, half and several passes; residual + accumulate"""
+    base, ref, resid, dims, n_out, _ = _cross_case(kind, mode, 1700 + kind, [7, 30, 13, 1, 40, 17], [32, 5, 79, 33, 17, 48])
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    _run(dict(base, out=out), keep)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    scale = ref.abs().max().item()
+    err = (got - want).abs().max().item() / scale
+    print(f"kind {kind} {mode}: f16x3 node-side kernel vs fp64 oracle {err:.2e}")
+    assert err < TOL, err
+    _run(dict(base, out=out, accumulate=1), keep)
+    err = (out.cpu().double() - (want + ref)).abs().max().item() / scale
+    assert err < 2 * TOL, err
+    # reruns are bit-identical (fixed summation order, no atomics)
+    out3 = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    _run(dict(base, out=out3), keep)
+    assert torch.equal(out3.cpu().double(), got)
+
+
+@pytest.mark.parametrize("scale", [1e-3, 30.0])
+def test_conv_node_f16_feature_magnitudes(scale):
+    """features far from O(1): the limbs of small values keep an absolute precision of 2^-25, large ones stay below fp16's 65504"""
+    base, ref, resid, dims, n_out, _ = _cross_case(3, "p2l", 77, [30, 9], [32, 20], feat_scale=scale)
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    _run(dict(base, out=out, resid=None, resid_width=0), keep)
+    got = out.cpu().double()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"feature scale {scale}: {err:.2e}")
+    assert err < TOL, err
+
+
+def test_conv_node_f16_neighbour_nan_does_not_leak():
+    """a pose whose features are NaN (a diverged ligand in a screening batch) leaves the poses packed around it untouched: gathers past a pose's
+    last node read 0 through the pose-limited buffer resource, never the next pose's rows"""
+    base, ref, resid, dims, n_out, _ = _cross_case(2, "p2l", 78, [12, 20, 9], [20, 17, 40])
+    gt = base["gather_tab"].clone()
+    ph_ptr = base["ph_ptr"].cpu().numpy()
+    gt[ph_ptr[1]:ph_ptr[2]] = float("nan")                       # pose 1's pharmacophore features
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    _run(dict(base, out=out, gather_tab=gt, attr2_tab=gt), keep)
+    got = out.cpu().double()
+    lig_ptr = base["lig_ptr"].cpu().numpy()
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    good = np.r_[0:lig_ptr[1], lig_ptr[2]:lig_ptr[3]]
+    assert torch.isfinite(got[good]).all()
+    assert (got[good] - want[good]).abs().max().item() / ref.abs().max().item() < TOL
+    assert not torch.isfinite(got[lig_ptr[1]:lig_ptr[2]]).all()
+
+
+def _ll_case(kind, seed, NL):
+    g = torch.Generator().manual_seed(seed)
+    sd = weights.init_state_dict(11)
+    prefix = f"encoder.lig_conv_layers.{kind}"
+    dims = _lib.conv_dims(kind)
+    B = len(NL)
+    lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+    N = int(lig_ptr[-1])
+    h = torch.randn(N, dims["d_in"], generator=g)
+    rowptr, rowend, nbr, scat, pair_rad, pair_bond = [], [], [], [], [], []
+    pair_ptr = np.concatenate([[0], np.cumsum(np.asarray(NL) ** 2)])
+    e0 = 0
+    for b in range(B):
+        n = NL[b]
+        adj = (torch.rand(n, n, generator=g) < 0.6).numpy()
+        np.fill_diagonal(adj, False)
+        bond = (torch.rand(n, n, generator=g) < 0.08).numpy() & ~np.eye(n, dtype=bool)
+        adj[3 % n] = False
+        if n > 5:
+            adj[5], bond[5] = False, False
+        pr, pb_ = -np.ones((n, n), dtype=np.int32), -np.ones((n, n), dtype=np.int32)
+        for a_ in range(n):
+            rowptr.append(e0)
+            for y in np.nonzero(bond[a_])[0]:
+                pb_[a_, y] = e0
+                nbr.append(int(lig_ptr[b]) + int(y)); scat.append(int(lig_ptr[b]) + a_)
+                e0 += 1
+            for y in np.nonzero(adj[a_])[0]:
+                pr[a_, y] = e0
+                nbr.append(int(lig_ptr[b]) + int(y)); scat.append(int(lig_ptr[b]) + a_)
+                e0 += 1
+            rowend.append(e0)
+        pair_rad.append(pr.reshape(-1)); pair_bond.append(pb_.reshape(-1))
+    E = e0
+    nbr_t, scat_t = torch.tensor(nbr), torch.tensor(scat)
+    pos = torch.randn(N, 3, generator=g)
+    from oracle import e3
+    sh = e3.spherical_harmonics_lmax2((pos[nbr_t] - pos[scat_t]).double()).float()
+    emb = torch.randn(E, 20, generator=g)
+    attr = torch.cat([emb, h[scat_t, :20], h[nbr_t, :20]], 1)
+    ref = _oracle_conv(sd, prefix, kind, h[nbr_t], attr, sh, scat_t, N)
+    pk = packing.pack_conv(sd, prefix, kind, _lib.PREC_F32, node_f16=True)
+    nb = _lib.lib().dp_conv_node_max_nodes()
+    resid = torch.randn(N, dims["d_in"], generator=g)
+    emb_d = _dev(emb)
+    embh, flag_row = _emb_h(emb_d)
+    args = dict(kind=kind, B=B, precision=_lib.PREC_F16X3, max_scatter=max(NL), scat_ptr=_dev(_i32(lig_ptr)), lig_ptr=_dev(_i32(lig_ptr)),
+                rowptr=_dev(_i32(rowptr)), rowend=_dev(_i32(rowend)), nbr=_dev(_i32(nbr)), edge_scat=_dev(_i32(scat)),
+                gather_tab=_dev(h), gather_stride=dims["d_in"], attr1_tab=_dev(h), attr1_stride=dims["d_in"], attr2_tab=_dev(h),
+                attr2_stride=dims["d_in"], attr_swap=0, edge_emb=emb_d, edge_emb_bf=embh, emb_flag_row=flag_row, edge_sh=_dev(sh), sh_stride=9,
+                w1p=_dev(pk["w1p"]), w2p=_dev(pk["w2p"]), w1n=_dev(pk["w1h"]), w2n=_dev(pk["w2h"]), bn_scale=_dev(pk["bn_scale"]),
+                bn_shift=_dev(pk["bn_shift"]), out_stride=dims["d_out"], accumulate=0, resid=_dev(resid), resid_stride=dims["d_in"],
+                resid_width=dims["d_in"], pair_a=_dev(_i32(np.concatenate(pair_rad))), pair_b=_dev(_i32(np.concatenate(pair_bond))),
+                pair_ptr=_dev(_i32(pair_ptr)), mode=_lib.EDGES_LLPAIR, algo=_lib.ALGO_NODE, slices=(max(NL) + nb - 1) // nb)
+    return args, ref, resid, dims, N, h
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_conv_node_f16_ligand_pairs(kind):
+    """pair-dense ligand-ligand mode: radius + bond edges on one pair add their hidden vectors; atoms without edges; <= 32 and > 32 atoms"""
+    args, ref, resid, dims, N, _ = _ll_case(kind, 1900 + kind, [9, 30, 1, 45, 17])
+    out = torch.full((N, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    _run(dict(args, out=out), keep)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    err = (got - want).abs().max().item() / ref.abs().max().item()
+    print(f"kind {kind} ligand pairs: f16x3 vs fp64 oracle {err:.2e}")
+    assert err < TOL, err
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_conv_node_f16_fused_ligand_side(kind):
+    """dp_tp_conv_node_fused: ligand-ligand + phore->ligand + phore->ligand(normals) in one launch (three W2 images with their own exponents, one
+    common accumulator scale) == the sum of the three oracle convs (score_model_phore.py:703-706)"""
+    NL, NP = [9, 30, 1, 24, 17], [32, 5, 40, 33, 16]
+    ll, ref_ll, resid, dims, N, h = _ll_case(kind, 2300 + kind, NL)
+    g = torch.Generator().manual_seed(2400 + kind)
+    sd = weights.init_state_dict(11)
+    B = len(NL)
+    lig_ptr = np.concatenate([[0], np.cumsum(NL)])
+    ph_ptr = np.concatenate([[0], np.cumsum(NP)])
+    x_ptr = np.concatenate([[0], np.cumsum(np.asarray(NL) * np.asarray(NP))])
+    hp = torch.randn(int(ph_ptr[-1]), dims["d_in"], generator=g)
+    E = int(x_ptr[-1])
+    emb = torch.randn(E, 20, generator=g)
+    src = torch.cat([torch.arange(lig_ptr[b], lig_ptr[b + 1]).repeat_interleave(NP[b]) for b in range(B)])
+    dst = torch.cat([torch.arange(ph_ptr[b], ph_ptr[b + 1]).repeat(NL[b]) for b in range(B)])
+    attr = torch.cat([emb, h[src, :20], hp[dst, :20]], 1)
+    emb_d = _dev(emb)
+    embh, flag_row = _emb_h(emb_d)
+    keep = []
+    convs, want = [ll], ref_ll.clone()
+    for i, fam in enumerate(("phore_to_lig_conv_layers", "phore_to_lig_norm_conv_layers")):
+        sh = torch.randn(E, 9, generator=g)
+        sh[:, 0] = 1.0
+        prefix = f"encoder.{fam}.{kind}"
+        # different magnitudes of the second layer per conv: the three images get different exponents
+        sd2 = dict(sd)
+        sd2[prefix + ".fc.3.weight"] = sd[prefix + ".fc.3.weight"] * (0.1 if i == 0 else 7.0)
+        pk = packing.pack_conv(sd2, prefix, kind, _lib.PREC_F32, node_f16=True)
+        want += _oracle_conv(sd2, prefix, kind, hp[dst], attr, sh, src, N)
+        convs.append(dict(ll, mode=_lib.EDGES_P2L, ph_ptr=_dev(_i32(ph_ptr)), x_ptr=_dev(_i32(x_ptr)), gather_tab=_dev(hp), attr2_tab=_dev(hp),
+                          edge_emb=emb_d, edge_emb_bf=embh, emb_flag_row=flag_row, edge_sh=_dev(sh), w1n=_dev(pk["w1h"]), w2n=_dev(pk["w2h"]),
+                          bn_shift=_dev(pk["bn_shift"]), pair_a=None, pair_b=None, pair_ptr=None))
+    out = torch.full((N, dims["d_out"]), float("nan")).cuda()
+    arr = (_lib.DpConvArgs * 3)()
+    for i in range(3):
+        for k_, v in dict(convs[i], out=out, accumulate=0).items():
+            if torch.is_tensor(v):
+                keep.append(v)
+                v = v.data_ptr()
+            setattr(arr[i], k_, v)
+    _lib.check(_lib.lib().dp_tp_conv_node_fused(arr, 3, torch.cuda.current_stream().cuda_stream), "dp_tp_conv_node_fused")
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    want[:, :dims["d_in"]] += resid.double()
+    err = (got - want).abs().max().item() / scale
+    print(f"kind {kind} fused ligand side: f16x3 vs fp64 oracle {err:.2e}")
+    assert err < TOL, err

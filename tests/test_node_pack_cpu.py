@@ -157,3 +157,53 @@ def test_bf16_node_packing_and_model_vs_oracle(kind, mode):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     print(f"kind {kind} {mode}: bf16 model vs fp64 oracle {err:.2e}")
     assert err < 2e-2, err
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", ["p2l", "l2p"])
+def test_f16_node_packing_vs_oracle(kind, mode):
+    """DP_PREC_F16X3: the packed two-limb fp16 fragments (dp_pack_conv_weights_node_f16), un-permuted with the kernel's index formulas
+    (tests/f16_model.py), reproduce the fp64 oracle's conv to 1e-6 (the limbs carry >= 21 bits: hi = rne16(v), lo = rne16(v - hi)); the header
+    exponent w puts the largest |W2 * 2^w| into (1024, 2048]; the "edge does not exist" row of the first layer is -60000 in units of 16 W1."""
+    from f16_model import FLAG_W, node_conv_f16_images, unpack_w1h, unpack_w2h
+    L = _lib.lib()
+    sd = dict(weights.init_state_dict(11))
+    fam = "phore_to_lig_conv_layers" if mode == "p2l" else "lig_to_phore_conv_layers"
+    prefix = f"encoder.{fam}.{kind}"
+    sd[prefix + ".fc.3.weight"] = sd[prefix + ".fc.3.weight"] * (3.0 if mode == "p2l" else 0.02)       # two different exponents
+    pk = packing.pack_conv(sd, prefix, kind, _lib.PREC_F32, node_f16=True)
+    assert pk["w1h"].numel() == L.dp_conv_w1h_floats(kind) and pk["w2h"].numel() == L.dp_conv_w2h_floats(kind)
+    W1, l1 = unpack_w1h(pk["w1h"].numpy())
+    assert np.all(W1[0, :, 20] == FLAG_W) and np.all(l1[1][0, :, 20] == 0.0)
+    # the host's fp16 conversion rounds to nearest: the hi limb is within half an fp16 ulp of the value, the lo limb within half an ulp of the rest
+    def half_ulp(x):
+        return np.spacing(np.abs(x).astype(np.float16)).astype(np.float64) / 2
+    v = l1[0] + l1[1]
+    assert np.all(np.abs(v - l1[0]) <= half_ulp(l1[0])) and np.mean(l1[0] == v.astype(np.float32).astype(np.float16).astype(np.float64)) > 0.999
+    ref1 = 16.0 * sd[prefix + ".fc.0.weight"].double().numpy()[:, :20]
+    assert np.all(np.abs(W1[0, :60, :20] - ref1) <= half_ulp(l1[1][0, :60, :20]) + 2.0 ** -25)
+    wexp, W2, l2 = unpack_w2h(kind, pk["w2h"].numpy())
+    mx = max(np.abs(w).max() for w in W2) * 2.0 ** wexp
+    assert 1024.0 < mx <= 2048.0, (wexp, mx)
+    for limbs in l2:
+        assert np.all(np.abs(limbs[1]) <= half_ulp(limbs[0]))
+    dims = _lib.conv_dims(kind)
+    g = torch.Generator().manual_seed(50 + kind)
+    NL, NP = 5, 37
+    hl, hp = torch.randn(NL, dims["d_in"], generator=g), torch.randn(NP, dims["d_in"], generator=g)
+    E = NL * NP
+    emb, sh = torch.randn(E, 20, generator=g), torch.randn(E, 9, generator=g)
+    sh[:, 0] = 1.0
+    src, dst = torch.arange(NL).repeat_interleave(NP), torch.arange(NP).repeat(NL)
+    attr = torch.cat([emb, hl[src, :20], hp[dst, :20]], 1)
+    if mode == "p2l":
+        ref = _oracle_conv(sd, prefix, kind, hp[dst], attr, sh, src, NL).numpy()
+        got = node_conv_f16_images(kind, pk["w1h"].numpy(), pk["w2h"].numpy(), pk["bn_shift"].numpy(), emb.numpy(), hl[src, :20].numpy(),
+                                   hp[dst, :20].numpy(), hp[dst].numpy(), sh.numpy(), src.numpy(), NL, s_img=1)
+    else:
+        ref = _oracle_conv(sd, prefix, kind, hl[src], attr, sh, dst, NP).numpy()
+        got = node_conv_f16_images(kind, pk["w1h"].numpy(), pk["w2h"].numpy(), pk["bn_shift"].numpy(), emb.numpy(), hp[dst, :20].numpy(),
+                                   hl[src, :20].numpy(), hl[src].numpy(), sh.numpy(), dst.numpy(), NP, s_img=2)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print(f"kind {kind} {mode}: unpacked f16x3 images vs fp64 oracle {err:.2e} (w = {wexp})")
+    assert err < 2e-6, err

@@ -114,3 +114,50 @@ def test_repeated_ordered_bond_is_flagged_by_both_packers():
     g["ligand"].edge_mask = torch.cat([torch.as_tensor(g["ligand"].edge_mask), torch.zeros(1, dtype=torch.bool)])
     for hp in ("native", "numpy"):
         assert not PackedBatch(gs, "cpu", upload=False, host_pack=hp).ll_pairs_ok
+
+
+class _PlainGraph:
+    """a graph type WITHOUT a custom __deepcopy__ (stands for PyG's HeteroData, which the reference uses): default copy / pickle walk __dict__"""
+
+    def __init__(self, g):
+        self.g = g
+
+    def __getitem__(self, k):
+        return self.g[k]
+
+
+def test_a_packed_graph_still_pickles_and_deepcopies():
+    """the cached host view (_dp_view: a ctypes struct of pointers) is a cache, not state: pickle / deepcopy of a graph that went through
+    PackedBatch drop it (it is rebuilt at the next packing) instead of failing with 'ctypes objects containing pointers cannot be pickled'"""
+    import copy
+    import pickle
+    gs = synthetic.synthetic_pairs(35, 2, 12, 3, 10)
+    a = PackedBatch(gs, "cpu", upload=False, host_pack="native")
+    assert gs[0]._dp_view is not None
+    g2 = pickle.loads(pickle.dumps(gs[0]))
+    assert getattr(g2, "_dp_view", None) is None
+    g3 = copy.deepcopy(gs[1])
+    assert getattr(g3, "_dp_view", None) is None
+    b = PackedBatch([g2, g3], "cpu", upload=False, host_pack="native")
+    assert all(np.array_equal(x, y) for x, y in zip(_native_arrays(a).values(), _native_arrays(b).values()))
+    # a wrapper type with default copy semantics around a packed graph
+    w = _PlainGraph(gs[0])
+    object.__setattr__(w, "_dp_view", gs[0]._dp_view)
+    assert copy.deepcopy(w)._dp_view is None and pickle.loads(pickle.dumps(w))._dp_view is None
+
+
+def test_numpy_statics_are_tracked_by_content():
+    """mask_rotate kept as an ndarray (the reference's layout) has no version counter: an in-place edit must still rebuild the view"""
+    gs = synthetic.synthetic_pairs(36, 1, 12, 3, 10)
+    g = gs[0]
+    mr = g["ligand"].mask_rotate
+    g["ligand"].mask_rotate = np.ascontiguousarray((mr[0] if isinstance(mr, (list, tuple)) else mr).numpy() if torch.is_tensor(mr[0] if isinstance(mr, (list, tuple)) else mr) else np.asarray(mr))
+    a = PackedBatch([g], "cpu", upload=False, host_pack="native")
+    v0 = g._dp_view
+    m = g["ligand"].mask_rotate
+    m[0, 0] = not m[0, 0]
+    b = PackedBatch([g], "cpu", upload=False, host_pack="native")
+    assert g._dp_view is not v0
+    c = PackedBatch([g], "cpu", upload=False, host_pack="numpy")
+    assert np.array_equal(_native_arrays(b)["mask_rotate"], c._host["mask_rotate"].numpy().reshape(-1))
+    assert not np.array_equal(_native_arrays(a)["mask_rotate"], _native_arrays(b)["mask_rotate"])

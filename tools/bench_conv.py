@@ -32,8 +32,13 @@ def main():
         _lib.LIB_PATH = a.lib
     dims = _lib.conv_dims(a.kind)
     sd = weights.init_state_dict(1)
-    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PRECISIONS[a.prec], node_side=a.algo == "node" and a.prec == "f32",
-                           node_bf16=a.algo == "node" and a.prec == "bf16")
+    f16 = a.prec == "f16x3"        # the fp32-grade two-limb fp16 node-side kernel (DP_PREC_F16X3): weights of an fp32 model
+    if f16 and a.algo != "node":
+        raise SystemExit("--prec f16x3 is a node-side kernel: add --algo node")
+    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PREC_F32 if f16 else _lib.PRECISIONS[a.prec],
+                           node_side=a.algo == "node" and a.prec == "f32", node_bf16=a.algo == "node" and a.prec == "bf16", node_f16=f16)
+    if f16:
+        pk["w1n"], pk["w2n"] = pk["w1h"], pk["w2h"]
     B, NL, NP = a.B, a.nl, a.np
     dev = "cuda"
     lig_ptr = torch.arange(B + 1, dtype=torch.int32) * NL
@@ -51,7 +56,7 @@ def main():
     args = _lib.DpConvArgs()
     args.kind, args.B, args.slices = a.kind, B, a.slices
     args.phase_split = a.phase_split
-    args.precision = _lib.PRECISIONS[a.prec]
+    args.precision = _lib.PREC_F16X3 if f16 else _lib.PRECISIONS[a.prec]
     args.max_scatter = NL if a.mode == "p2l" else NP
     args.mode = _lib.EDGES_P2L if a.mode == "p2l" else _lib.EDGES_L2P
     args.scat_ptr = keep["lig_ptr"].data_ptr() if a.mode == "p2l" else keep["ph_ptr"].data_ptr()
@@ -65,6 +70,10 @@ def main():
         emb_bf = torch.zeros((E + 1) * 32, dtype=torch.int16, device=dev)
         _lib.check(_lib.lib().dp_edge_emb_bf16(emb.data_ptr(), E, emb_bf.data_ptr(), torch.cuda.current_stream().cuda_stream), "dp_edge_emb_bf16")
         args.edge_emb_bf, args.emb_flag_row = emb_bf.data_ptr(), E
+    if f16:
+        emb_h = torch.zeros((E + 1) * 64, dtype=torch.int16, device=dev)
+        _lib.check(_lib.lib().dp_edge_emb_f16(emb.data_ptr(), E, emb_h.data_ptr(), torch.cuda.current_stream().cuda_stream), "dp_edge_emb_f16")
+        args.edge_emb_bf, args.emb_flag_row = emb_h.data_ptr(), E
     args.w1p, args.w2p = keep["w1p"].data_ptr(), keep["w2p"].data_ptr()
     if a.algo == "node":
         nb = _lib.lib().dp_conv_node_max_nodes()
