@@ -63,7 +63,9 @@ def build(force=False, verbose=True):
         objs.append(o)
         is_host = os.path.basename(s) == "dp_host.hip"
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(d) for d in _deps(s)) or (is_host and host_stale):
-            cmd = [HIPCC] + FLAGS + ([f'-DDP_SOURCE_HASH="{shash}"'] if is_host else []) + ["-c", s, "-o", o]
+            # the two-limb fp16 kernels spell v_fma_mixlo_f16 / v_fma_mixhi_f16 as scalar C (dp_conv_node_f16_impl.h): SLP would re-pack them
+            extra = ["-fno-slp-vectorize"] if os.path.basename(s).startswith("dp_conv_node_f16_k") else []
+            cmd = [HIPCC] + FLAGS + extra + ([f'-DDP_SOURCE_HASH="{shash}"'] if is_host else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

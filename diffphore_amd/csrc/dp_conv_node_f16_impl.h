@@ -16,9 +16,9 @@
 //     registers one limb of 16 nodes took.  GEMM-B's N = 16 is then (8 nodes) x (2 limbs of T): node slot n < 8 of the T image holds hi(T),
 //     slot n + 8 holds lo(T) of the same node, so ONE MFMA per W2 limb covers W2_limb x (T_hi | T_lo) - two MFMAs give all four cross
 //     products - and the two column halves of the accumulators are added once, in the epilogue.  The launch has twice the workgroups.
-//   * limb extraction on the VALU: v_cvt_pk_f16_f32 (hi of a pair), two v_fma_mix_f32 (v * 1.0 - hi: the fp16 half is read in place; for the
-//     one-term tensor-product operands x * s - hi, i.e. the exact residual of the product), v_cvt_pk_f16_f32 (lo): 3 extra instructions per
-//     pair of values against the bf16 kernel's single conversion.
+//   * limb extraction on the VALU: v_cvt_pk_f16_f32 (hi of a pair), then v_fma_mixlo_f16 + v_fma_mixhi_f16 (f16(v * 1.0 - hi) written into the
+//     two halves of one register, the fp16 half of hi read in place; for the one-term tensor-product operands f16(x * s - hi) with the product
+//     exact inside the fma): 2 extra instructions per pair of values against the bf16 kernel's single conversion.
 //   * exact power-of-two scales keep the limbs inside fp16's range: W2 (path coefficient, CG norm, BatchNorm scale folded) is stored as
 //     W2 * 2^w with max |W2 * 2^w| in (1024, 2048] (w in the image header), the hidden vectors carry 2^(S - w) / degree with S = min over the
 //     launch's convs of w + 5, so that every conv of a fused launch accumulates out * 2^S; the epilogue multiplies by 2^-S.  W1 is stored
@@ -73,34 +73,57 @@ __device__ __forceinline__ unsigned pkh(float lo, float hi) {       // v_cvt_pk_
   const f16x2 v = __builtin_convertvector((f32x2){lo, hi}, f16x2);
   return __builtin_bit_cast(unsigned, v);
 }
-// v - (float)half of `hpk` in ONE instruction (v_fma_mix_f32 reads the fp16 half in place); exact: hi is within half an ulp16 of v
-__device__ __forceinline__ float res_lo(float v, unsigned hpk) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hpk));
-  return r;
+// Limb extraction.  hi limbs of a pair: v_cvt_pk_f16_f32.  lo limbs: v_fma_mixlo_f16 / v_fma_mixhi_f16 compute f16(a * b - (float)half) from
+// fp32 sources with the fp16 half read IN PLACE, and write one half of the destination (the other half is preserved): two instructions give the
+// packed lo limbs of a pair - no unpack, no second conversion.  The residual v - hi is exact (hi is within half an fp16 ulp of v).
+// Written as plain C that the backend's mad-mix patterns turn into exactly those instructions - (_Float16)fma(v, one, -(float)h) with an OPAQUE
+// one (a literal 1.0 would be folded into a subtraction and lose the pattern) - in translation units built with -fno-slp-vectorize (the SLP
+// vectoriser would pack the two scalar fmas into v_pk_fma_f32 + unpack + convert).  NOT inline asm: an instruction that writes a 16-bit half
+// needs one wait state before a dependent instruction (gfx940 dst-sel forwarding), and the compiler only knows that for instructions it
+// emitted itself - behind an inline-asm v_fma_mixhi_f16 it guards VALU / MFMA consumers but not an LDS store of the result (measured: the
+// ds_write stored the stale half).  The helpers work on TWO pairs at a time, in an order that leaves an independent instruction between
+// dependent ones, so the wait states cost nothing.
+__device__ __forceinline__ float opaque_one() {
+  float o = 1.0f;
+  asm("" : "+s"(o));
+  return o;
 }
-__device__ __forceinline__ float res_hi(float v, unsigned hpk) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hpk));
-  return r;
-}
-// x * s - (float)half: the residual of the exact product (one rounding)
-__device__ __forceinline__ float resp_lo(float x, float s, unsigned hpk) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(hpk));
-  return r;
-}
-__device__ __forceinline__ float resp_hi(float x, float s, unsigned hpk) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(hpk));
-  return r;
-}
+__device__ __forceinline__ unsigned hbits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
 struct HL { unsigned h, l; };
-__device__ __forceinline__ HL split2(float v0, float v1) {
-  HL r;
-  r.h = pkh(v0, v1);
-  r.l = pkh(res_lo(v0, r.h), res_hi(v1, r.h));
-  return r;
+struct HL2 { unsigned h0, h1, l0, l1; };
+// two pairs (v0, v1), (v2, v3) -> hi / lo limbs, 6 instructions
+__device__ __forceinline__ HL2 split4(float v0, float v1, float v2, float v3) {
+  const float one = opaque_one();
+  const f16x2 h0 = __builtin_convertvector((f32x2){v0, v1}, f16x2), h1 = __builtin_convertvector((f32x2){v2, v3}, f16x2);
+  f16x2 l0, l1;
+  l0[0] = (_Float16)__builtin_fmaf(v0, one, -(float)h0[0]);
+  l1[0] = (_Float16)__builtin_fmaf(v2, one, -(float)h1[0]);
+  l0[1] = (_Float16)__builtin_fmaf(v1, one, -(float)h0[1]);
+  l1[1] = (_Float16)__builtin_fmaf(v3, one, -(float)h1[1]);
+  return HL2{hbits(h0), hbits(h1), hbits(l0), hbits(l1)};
+}
+// two pairs of PRODUCTS (x0 s0, x1 s1) = xa * sa, (x2 s2, x3 s3) = xb * sb: hi = rne16(fl32(x s)), lo = rne16(x s - hi) with the product EXACT inside
+// the fma (so hi + lo also recovers what the fp32 rounding of the product dropped), 8 instructions.  hi is computed ONCE, from the packed fp32
+// products: written as (_Float16)(x * s) per element the backend selects v_cvt_pk(v_mul, v_mul) for the limb that feeds the MFMA and
+// v_fma_mixlo_f16(x, s, 0) for the copy the residual subtracts - two roundings of the same product that differ in rare cases by an fp16 ulp
+// (measured: 1e-5 instead of 3e-7 of the output's magnitude).
+__device__ __forceinline__ HL2 split4_mul(f32x2 xa, f32x2 sa, f32x2 xb, f32x2 sb) {
+  const f32x2 pa = xa * sa, pb = xb * sb;
+  const f16x2 h0 = __builtin_convertvector(pa, f16x2), h1 = __builtin_convertvector(pb, f16x2);
+  f16x2 l0, l1;
+  l0[0] = (_Float16)__builtin_fmaf(xa[0], sa[0], -(float)h0[0]);
+  l1[0] = (_Float16)__builtin_fmaf(xb[0], sb[0], -(float)h1[0]);
+  l0[1] = (_Float16)__builtin_fmaf(xa[1], sa[1], -(float)h0[1]);
+  l1[1] = (_Float16)__builtin_fmaf(xb[1], sb[1], -(float)h1[1]);
+  return HL2{hbits(h0), hbits(h1), hbits(l0), hbits(l1)};
+}
+__device__ __forceinline__ HL split2(float v0, float v1) {         // one pair (cold paths)
+  const float one = opaque_one();
+  const f16x2 h = __builtin_convertvector((f32x2){v0, v1}, f16x2);
+  f16x2 l;
+  l[0] = (_Float16)__builtin_fmaf(v0, one, -(float)h[0]);
+  l[1] = (_Float16)__builtin_fmaf(v1, one, -(float)h[1]);
+  return HL{hbits(h), hbits(l)};
 }
 __device__ __forceinline__ f16x8 as_h(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h(a), as_h(b), c, 0, 0, 0); }
@@ -128,7 +151,7 @@ __device__ __forceinline__ Grp grp_of8(const DpConvArgs& a, int bid) {     // as
 
 template <int KIND, int MODE, bool HALF, int P>
 struct StageH {
-  static __device__ __forceinline__ void run(const DpConvArgs& a, const XSrc& xs, int q, int lane, const u32x4 (&hid)[2 * NBH],
+  static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t wrs, const XSrc& xs, int q, int lane, const u32x4 (&hid)[2 * NBH],
                                              unsigned tl_base, unsigned dummy_base, const float* sS, f32x4 (&acc)[n_acc4<KIND>()],
                                              f32x2 (&xr)[2][3][4]) {
     using S = Spec<KIND>;
@@ -158,14 +181,17 @@ struct StageH {
         for (int tl = 0; tl < NTILE; ++tl)
           twr[tl] = (colv ? tl_base + (unsigned)((tl * TCOLS + c) * COLB) : dummy_base + (unsigned)(c * 8)) + (unsigned)(g * 128);
         // the supertile's W2 fragments (GEMM-B's A operands: 2 limbs x 5 K chunks x MT), requested before GEMM-A, which hides the L2 round trip
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w2n) + w2h_path_off<KIND>(P) + (size_t)(st * 2 * SUPER_CH * MT) * 256 + q * 64 + lane_l;
+        // (through a buffer resource: one VGPR offset per lane, the fragment's offset is wave-uniform - no 64-bit address arithmetic per load)
+        const unsigned wvoff = (unsigned)(q * 64 + lane_l) * 16u;
+        const unsigned wsoff = uni((unsigned)(w2h_path_off<KIND>(P) + st * (2 * SUPER_CH * MT * 256)) * 16u);
         u32x4 wall[2][SUPER_CH][MT];
 #pragma unroll
         for (int lb = 0; lb < 2; ++lb)
 #pragma unroll
           for (int ch = 0; ch < SUPER_CH; ++ch)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) wall[lb][ch][mt] = wsrc[((lb * SUPER_CH + ch) * MT + mt) * 256];
+            for (int mt = 0; mt < MT; ++mt)
+              wall[lb][ch][mt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff + (unsigned)(((lb * SUPER_CH + ch) * MT + mt) * 256 * 16), 0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM-A: three MFMAs per (node, tile); T leaves as two fp16 limbs ---------------------------------------------------------
         // node nn's MFMAs go into a ring of two accumulator sets, their results are split / stored one node LATER (behind the next node's
@@ -175,9 +201,9 @@ struct StageH {
 #pragma unroll
           for (int tl = 0; tl < NTILE; ++tl) {
             const f32x4 D = Dq[nn & 1][tl];
-            const HL a01 = split2(D[0], D[1]), a23 = split2(D[2], D[3]);
-            *lds_ptr(twr[tl] + (unsigned)(nn << 3)) = u32x2{a01.h, a23.h};
-            *lds_ptr(twr[tl] + (unsigned)((nn + NBH) << 3)) = u32x2{a01.l, a23.l};
+            const HL2 t = split4(D[0], D[1], D[2], D[3]);
+            *lds_ptr(twr[tl] + (unsigned)(nn << 3)) = u32x2{t.h0, t.h1};
+            *lds_ptr(twr[tl] + (unsigned)((nn + NBH) << 3)) = u32x2{t.l0, t.l1};
           }
         };
         if constexpr (needs_s<ZT>()) {
@@ -205,27 +231,32 @@ struct StageH {
             for (int tl = 0; tl < NTILE; ++tl) {
               zh[tl] = u32x4{0u, 0u, 0u, 0u};
               zl[tl] = u32x4{0u, 0u, 0u, 0u};
+              // edge slots 2 jp, 2 jp + 1 of the lane = components (2 jp & 3, + 1) of the factor quad of 16-edge tile jp >> 1
+              auto spair = [&](int t, int jp) { const f32x4 q4 = sv[cur][t][jp >> 1]; return (jp & 1) ? f32x2{q4[2], q4[3]} : f32x2{q4[0], q4[1]}; };
+              if constexpr (NTERM == 1) {
 #pragma unroll
-              for (int jp = 0; jp < NJ / 2; ++jp) {
-                // edge slots 2 jp, 2 jp + 1 of the lane = components (2 jp & 3, + 1) of the factor quad of 16-edge tile jp >> 1
-                auto spair = [&](int t) { const f32x4 q4 = sv[cur][t][jp >> 1]; return (jp & 1) ? f32x2{q4[2], q4[3]} : f32x2{q4[0], q4[1]}; };
-                if constexpr (NTERM == 1) {
-                  // one-term operand: hi = rne16(x * s), lo = rne16(x * s - hi) with the product exact inside the fma
-                  const f32x2 x2 = xa[tl][0][jp], s2 = spair(0);
-                  const f32x2 zz = x2 * s2;
-                  const unsigned h = pkh(zz[0], zz[1]);
-                  zh[tl][jp] = h;
-                  zl[tl][jp] = pkh(resp_lo(x2[0], s2[0], h), resp_hi(x2[1], s2[1], h));
-                } else {
-                  f32x2 zz = xa[tl][0][jp] * spair(0);
+                for (int j2 = 0; j2 < NJ / 4; ++j2) {           // two pairs at a time (see split4_mul)
+                  const HL2 r = split4_mul(xa[tl][0][2 * j2], spair(0, 2 * j2), xa[tl][0][2 * j2 + 1], spair(0, 2 * j2 + 1));
+                  zh[tl][2 * j2] = r.h0; zh[tl][2 * j2 + 1] = r.h1;
+                  zl[tl][2 * j2] = r.l0; zl[tl][2 * j2 + 1] = r.l1;
+                }
+              } else {
+                // term by term over all pairs (independent chains side by side), then the limbs of two pairs at a time
+                f32x2 zz[NJ / 2];
 #pragma unroll
-                  for (int t = 1; t < NTERM; ++t) {
-                    if (term_sign<ZT>(t) < 0) zz = __builtin_elementwise_fma(-xa[tl][t][jp], spair(t), zz);
-                    else zz = __builtin_elementwise_fma(xa[tl][t][jp], spair(t), zz);
+                for (int jp = 0; jp < NJ / 2; ++jp) zz[jp] = xa[tl][0][jp] * spair(0, jp);
+#pragma unroll
+                for (int t = 1; t < NTERM; ++t)
+#pragma unroll
+                  for (int jp = 0; jp < NJ / 2; ++jp) {
+                    if (term_sign<ZT>(t) < 0) zz[jp] = __builtin_elementwise_fma(-xa[tl][t][jp], spair(t, jp), zz[jp]);
+                    else zz[jp] = __builtin_elementwise_fma(xa[tl][t][jp], spair(t, jp), zz[jp]);
                   }
-                  const HL s = split2(zz[0], zz[1]);
-                  zh[tl][jp] = s.h;
-                  zl[tl][jp] = s.l;
+#pragma unroll
+                for (int j2 = 0; j2 < NJ / 4; ++j2) {
+                  const HL2 r = split4(zz[2 * j2][0], zz[2 * j2][1], zz[2 * j2 + 1][0], zz[2 * j2 + 1][1]);
+                  zh[tl][2 * j2] = r.h0; zh[tl][2 * j2 + 1] = r.h1;
+                  zl[tl][2 * j2] = r.l0; zl[tl][2 * j2 + 1] = r.l1;
                 }
               }
             }
@@ -250,25 +281,47 @@ struct StageH {
             zh[tl] = u32x4{0u, 0u, 0u, 0u};
             zl[tl] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int jp = 0; jp < NJ / 2; ++jp) {
-              const HL s = split2(xa[tl][0][jp][0], xa[tl][0][jp][1]);
-              zh[tl][jp] = s.h;
-              zl[tl][jp] = s.l;
+            for (int j2 = 0; j2 < NJ / 4; ++j2) {
+              const HL2 r = split4(xa[tl][0][2 * j2][0], xa[tl][0][2 * j2][1], xa[tl][0][2 * j2 + 1][0], xa[tl][0][2 * j2 + 1][1]);
+              zh[tl][2 * j2] = r.h0; zh[tl][2 * j2 + 1] = r.h1;
+              zl[tl][2 * j2] = r.l0; zl[tl][2 * j2 + 1] = r.l1;
             }
           }
+          // nodes in PAIRS: the three dependent MFMAs of a (node, tile) chain are issued round-robin over the pair's 2 x NTILE chains, and the
+          // previous pair's results are split / stored in their shadow (there is no z arithmetic here to hide the MFMA latency behind)
+          f32x4 Dp[2][2][NTILE];
+          auto store_p = [&](int np) {
 #pragma unroll
-          for (int nn = 0; nn < NBH; ++nn) {
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_h(hid[NBH + nn], zh[tl], f32x4{0.f, 0.f, 0.f, 0.f});
+              for (int tl = 0; tl < NTILE; ++tl) {
+                const f32x4 D = Dp[np & 1][k][tl];
+                const HL2 t = split4(D[0], D[1], D[2], D[3]);
+                const int nn = 2 * np + k;
+                *lds_ptr(twr[tl] + (unsigned)(nn << 3)) = u32x2{t.h0, t.h1};
+                *lds_ptr(twr[tl] + (unsigned)((nn + NBH) << 3)) = u32x2{t.l0, t.l1};
+              }
+          };
 #pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_h(hid[nn], zl[tl], Dq[nn & 1][tl]);
+          for (int np = 0; np < NBH / 2; ++np) {
 #pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_h(hid[nn], zh[tl], Dq[nn & 1][tl]);
-            if (nn > 0) store_t(nn - 1);
+            for (int tl = 0; tl < NTILE; ++tl)
+#pragma unroll
+              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_h(hid[NBH + 2 * np + k], zh[tl], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int tl = 0; tl < NTILE; ++tl)
+#pragma unroll
+              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_h(hid[2 * np + k], zl[tl], Dp[np & 1][k][tl]);
+#pragma unroll
+            for (int tl = 0; tl < NTILE; ++tl)
+#pragma unroll
+              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_h(hid[2 * np + k], zh[tl], Dp[np & 1][k][tl]);
+            if (np > 0) store_p(np - 1);
             __builtin_amdgcn_sched_barrier(0);
           }
+          store_p(NBH / 2 - 1);
         }
-        store_t(NBH - 1);
+        if constexpr (needs_s<ZT>()) store_t(NBH - 1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM-B: out[w][slot] += W2_limb[w][(u,k)] (T_hi | T_lo)[(u,k)][slot], K = (two in-channels) x (the wave's 16 hidden rows) ----------
         {
@@ -299,14 +352,14 @@ struct StageH {
           }
         }
       }
-      StageH<KIND, MODE, HALF, P + 1>::run(a, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr);
+      StageH<KIND, MODE, HALF, P + 1>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr);
     }
   }
 };
 
 // one pass (32 edge slots per node; HALF: 16) of one conv: stage the SH factors, GEMM1 -> hid (two fp16 limbs, A fragments), then the path stages
 template <int KIND, int MODE, bool HALF>
-__device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t ers, const Grp& grp, const Wg& r, int et, int tid,
+__device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t ers, __amdgpu_buffer_rsrc_t wrs, const Grp& grp, const Wg& r, int et, int tid,
                                          float* s_T, float* s_S, const float* s_inv, f32x4 (&acc)[n_acc4<KIND>()]) {
   const int lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
   constexpr int NT2 = HALF ? 1 : 2;
@@ -327,9 +380,9 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
     f32x4 hi = *reinterpret_cast<const f4u*>(rowp + (g < 2 ? o + 4 : 16));
     if (g >= 2) hi = f32x4{(g == 2 && bias) ? 1.f : 0.f, 0.f, 0.f, 0.f};
     if (g == 3) lo = f32x4{0.f, 0.f, 0.f, 0.f};
-    const HL s0 = split2(lo[0], lo[1]), s1 = split2(lo[2], lo[3]), s2 = split2(hi[0], hi[1]), s3 = split2(hi[2], hi[3]);
-    fh = u32x4{s0.h, s1.h, s2.h, s3.h};
-    fl = u32x4{s0.l, s1.l, s2.l, s3.l};
+    const HL2 s0 = split4(lo[0], lo[1], lo[2], lo[3]), s1 = split4(hi[0], hi[1], hi[2], hi[3]);
+    fh = u32x4{s0.h0, s0.h1, s1.h0, s1.h1};
+    fl = u32x4{s0.l0, s0.l1, s1.l0, s1.l1};
   };
   u32x4 ag_h[NT2], ag_l[NT2], as_h, as_l;
   {
@@ -438,13 +491,13 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
     }
     if (HALF || t2 == 1) {
       const float inv = s_inv[nn];               // 2^(S - w) / (16 degree): scatter MEAN and the conv's scale, applied to the hidden vectors
-      const HL p0 = split2(hf[0] * inv, hf[1] * inv), p1 = split2(hf[2] * inv, hf[3] * inv);
-      hid[nn] = u32x4{p0.h, p1.h, 0u, 0u};
-      hid[NBH + nn] = u32x4{p0.l, p1.l, 0u, 0u};
+      const HL2 p0 = split4(hf[0] * inv, hf[1] * inv, hf[2] * inv, hf[3] * inv);
+      hid[nn] = u32x4{p0.h0, p0.h1, 0u, 0u};
+      hid[NBH + nn] = u32x4{p0.l0, p0.l1, 0u, 0u};
       if constexpr (!HALF) {
-        const HL p2 = split2(hf[4] * inv, hf[5] * inv), p3 = split2(hf[6] * inv, hf[7] * inv);
-        hid[nn][2] = p2.h; hid[nn][3] = p3.h;
-        hid[NBH + nn][2] = p2.l; hid[NBH + nn][3] = p3.l;
+        const HL2 p1 = split4(hf[4] * inv, hf[5] * inv, hf[6] * inv, hf[7] * inv);
+        hid[nn][2] = p1.h0; hid[nn][3] = p1.h1;
+        hid[NBH + nn][2] = p1.l0; hid[NBH + nn][3] = p1.l1;
       }
     }
   };
@@ -473,7 +526,7 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
   if constexpr (MODE == LL) __syncthreads();      // s_pair lives in wave 0's T image: every wave is done reading it before T tiles land there
   const unsigned tl_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(q * TIMG_B);
   const unsigned dummy_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(4 * TIMG_B);
-  StageH<KIND, MODE, HALF, 0>::run(a, xs, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0);
+  StageH<KIND, MODE, HALF, 0>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0);
 }
 
 // every pass of one conv of the (possibly fused) launch; `hs` = 2^(S - w) of this conv
@@ -493,10 +546,11 @@ __device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, in
   const int g_row0 = MODE == DP_EDGES_P2L ? r.p0 : r.l0;
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.gather_tab + (size_t)g_row0 * a.gather_stride, (unsigned)r.En * (unsigned)a.gather_stride * 4u);
   const __amdgpu_buffer_rsrc_t ers = make_rsrc(a.edge_emb_bf, (unsigned)(a.emb_flag_row + 1) * (unsigned)(EMBH_ROW * 2));
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w2n, (unsigned)w2h_quads<KIND>() * 16u);          // the conv's W2 image (GEMM-B's A fragments)
 #pragma unroll 1
   for (int et = 0; et < n_et; ++et) {
-    if (r.En - 32 * et <= 16) pass_f16<KIND, MODE, true>(a, xrs, ers, grp, r, et, tid, s_T, s_S, s_inv, acc);
-    else pass_f16<KIND, MODE, false>(a, xrs, ers, grp, r, et, tid, s_T, s_S, s_inv, acc);
+    if (r.En - 32 * et <= 16) pass_f16<KIND, MODE, true>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc);
+    else pass_f16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc);
   }
 }
 
