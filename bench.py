@@ -46,6 +46,10 @@ NODE_MFMA_PER_WAVE = {0: 208 + 6 * 128 + 400, 1: 208 + 13 * 128 + 840, 2: 208 + 
 # the bf16-operand kernel (dp_conv_node_bf16_impl.h): GEMM1 32 edge tiles + 3 node tiles, GEMM-A ONE 16x16x32 MFMA per (node, column tile), GEMM-B
 # 5 K chunks x M tiles x m components per supertile
 NODE_MFMA_PER_WAVE_BF16 = {0: 35 + 16 * 6 + 50, 1: 35 + 16 * 13 + 105, 2: 35 + 16 * 20 + 160, 3: 35 + 16 * 26 + 210}
+# the fp32-grade two-limb fp16 kernel (dp_conv_node_f16_impl.h, DP_PREC_F16X3), per wave per 32-edge pass of an 8-NODE group: GEMM1 (16 edge tiles +
+# 3 node tiles) x 3 cross products, GEMM-A 3 MFMAs per (node, column tile), GEMM-B 2 W2 limbs x (5 K chunks x M tiles x m components) per supertile
+# (the two T limbs ride in the N dimension).  Kind 3: 1 101 = SQ_INSTS_MFMA / waves of profiles/r5_f16_node_pmc.csv
+NODE_MFMA_PER_WAVE_F16 = {0: 57 + 24 * 6 + 100, 1: 57 + 24 * 13 + 210, 2: 57 + 24 * 20 + 320, 3: 57 + 24 * 26 + 420}
 MFMA_F32_PEAK_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0                                    # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
@@ -270,21 +274,25 @@ def main():
             self.sps = [_step_params(t, S, self.sched, self.sched, self.sched, t2s, margs, False, False) for t in range(S)]
             self.T_dev = torch.tensor([[float(self.sched[t])] * 3 for t in range(S)], dtype=torch.float32, device=dev)   # diffusion times, resident
 
-        def timed_run(self, mdl, conv_algo, steps, warmup, prof=True, edge_x6=None, table_steps=0):
-            """-> dict.  `edge_x6`: "0" forces exact fp32 on the edge-side convs of an fp32 model (DIFFPHORE_EDGE_X6); `table_steps` > 0 adds an
-            untimed pass that brackets EVERY tensor-product launch of the interaction layers (DpWork.prof_events) for the per-launch table."""
+        def timed_run(self, mdl, conv_algo, steps, warmup, prof=True, edge_x6=None, table_steps=0, node_f16=None):
+            """-> dict.  `edge_x6`: "0" forces exact fp32 on the edge-side convs of an fp32 model (DIFFPHORE_EDGE_X6), `node_f16`: "0" forces the
+            exact-fp32 MFMA kernel on its node-side convs (DIFFPHORE_NODE_F16); `table_steps` > 0 adds an untimed pass that brackets EVERY
+            tensor-product launch of the interaction layers (DpWork.prof_events) for the per-launch table."""
             pb, B, S_total, zs, sps, nT = self.pb, self.B, self.S_total, self.zs, self.sps, self.nT
-            keep = os.environ.get("DIFFPHORE_EDGE_X6")
-            if edge_x6 is not None:
-                os.environ["DIFFPHORE_EDGE_X6"] = edge_x6
+            envs = {"DIFFPHORE_EDGE_X6": edge_x6, "DIFFPHORE_NODE_F16": node_f16}
+            keep = {k_: os.environ.get(k_) for k_ in envs}
+            for k_, v_ in envs.items():
+                if v_ is not None:
+                    os.environ[k_] = v_
             try:
                 eng = Engine(mdl, pb, conv_algo=conv_algo)
             finally:
-                if edge_x6 is not None:
-                    if keep is None:
-                        os.environ.pop("DIFFPHORE_EDGE_X6", None)
-                    else:
-                        os.environ["DIFFPHORE_EDGE_X6"] = keep
+                for k_, v_ in envs.items():
+                    if v_ is not None:
+                        if keep[k_] is None:
+                            os.environ.pop(k_, None)
+                        else:
+                            os.environ[k_] = keep[k_]
             ev = HipEvents(steps if prof else 0)
 
             def reset():
@@ -367,7 +375,10 @@ def main():
                 te_.destroy()
                 table = [{"layer": layer, "first_conv": f, "convs": n, "node_side": bool(ns), "ms": float(np.nanmean(acc[(layer, f)]))}
                          for (layer, f), (n, ns) in sorted(launches.items())]
-            return dict(elapsed=el, kernel_ms=kms, bad=nbad, finite=fin, algo=eng.conv_algo, edge_side_convs=eng.edge_side_convs,
+            # what the node-side launches of THIS batch run: the two-limb fp16 kernel has no path-split form (small batches stay on the fp32 kernel)
+            nsc = eng.node_side_convs if (eng.conv_algo == "node" and not (eng.node_side_convs == "f16x3" and eng.path_split_on())) else \
+                ("f32" if eng.node_side_convs == "f16x3" else eng.node_side_convs)
+            return dict(elapsed=el, kernel_ms=kms, bad=nbad, finite=fin, algo=eng.conv_algo, edge_side_convs=eng.edge_side_convs, node_side_convs=nsc,
                         rank_seconds=rank_s, launch_table=table)
 
     t2s = t_to_sigma_fn(margs)
@@ -390,18 +401,20 @@ def main():
     if not a.no_alt and a.config == 2 and a.precision is None and a.conv_algo is None:
         # informational passes (never the headline `value`): other precisions / the other conv formulation, same workload
         alt = []
-        for prec, algo, x6, what in (
-                ("f32", None, "0", "exact fp32 MFMA EVERYWHERE (DIFFPHORE_EDGE_X6=0: the edge-side convs - phore-phore, torsion bonds - on the fp32 pipe too)"),
-                ("f32", "edge" if algo_used != "edge" else "node", None, "fp32 model, the other conv formulation"),
-                ("bf16x9", None, None, "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
-                ("bf16x6", None, None, "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances"),
-                ("bf16", None, None, "plain bf16 operands, fp32 accumulate (configs[4]'s precision) on the configs[1] batch: bf16-grade, 2^-9 per operand")):
+        for prec, algo, x6, f16, what in (
+                ("f32", None, "0", "0", "exact fp32 MFMA EVERYWHERE (DIFFPHORE_NODE_F16=0 DIFFPHORE_EDGE_X6=0: node-side convs on v_mfma_f32_16x16x4_f32, the "
+                                        "edge-side convs - phore-phore, torsion bonds - on the fp32 pipe too)"),
+                ("f32", None, None, "0", "round 4's default: node-side convs exact fp32 MFMA (DIFFPHORE_NODE_F16=0), edge-side convs bf16x6"),
+                ("f32", "edge" if algo_used != "edge" else "node", None, None, "fp32 model, the other conv formulation"),
+                ("bf16x9", None, None, None, "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
+                ("bf16x6", None, None, None, "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances"),
+                ("bf16", None, None, None, "plain bf16 operands, fp32 accumulate (configs[4]'s precision) on the configs[1] batch: bf16-grade, 2^-9 per operand")):
             try:
-                r2 = wl.timed_run(model_for(prec), algo, a.steps, a.warmup, edge_x6=x6)
+                r2 = wl.timed_run(model_for(prec), algo, a.steps, a.warmup, edge_x6=x6, node_f16=f16)
             except Exception as e:      # noqa: BLE001 - an informational pass must never sink the headline line
                 alt.append({"precision": prec, "conv_algo": algo, "error": str(e)[:200]})
                 continue
-            alt.append({"precision": f"{prec} ({what})", "conv_algo": r2["algo"], "edge_side_convs": r2["edge_side_convs"],
+            alt.append({"precision": f"{prec} ({what})", "conv_algo": r2["algo"], "edge_side_convs": r2["edge_side_convs"], "node_side_convs": r2["node_side_convs"],
                         "value": total_poses * a.steps / r2["elapsed"], "ms_per_step": r2["elapsed"] / a.steps * 1e3, "kernel_ms": r2["kernel_ms"],
                         "finite": r2["finite"], "kabsch_flagged_poses": r2["bad"]})
 
@@ -469,7 +482,7 @@ def main():
             g = lib.unit(i)
             t_load[0] += time.perf_counter() - t1
             return g
-        n_done = [0]
+        n_done, n_failed = [0], [0]
         per_batch = workloads.DEFAULT_UNITS[c] * workloads.SAMPLES
         D.screen(2, load, m, sargs, samples_per_complex=2, max_poses=per_batch, seed=1, on_result=lambda i, arr: None)      # warm-up
         torch.cuda.synchronize()
@@ -479,6 +492,9 @@ def main():
         marks = []          # (seconds since the call, poses delivered so far) per finished complex
 
         def sink(i, arr):
+            if arr is None:                     # a unit screen() gave up on (reason in its `failed` list): counted, not timed as work
+                n_failed[0] += 1
+                return
             n_done[0] += arr.shape[0]
             marks.append((time.perf_counter() - t0, n_done[0]))
         D.screen(n_lib, load, m, sargs, costs=[lib.cost(i) for i in range(n_lib)], samples_per_complex=workloads.SAMPLES, max_poses=per_batch,
@@ -491,7 +507,7 @@ def main():
         e2e_screen = {"what": f"distributed.screen (streaming) over a lazily built configs[{c - 1}] library: {n_lib} units x {workloads.SAMPLES} samples, "
                               f"device batches of {per_batch} poses, on-device start randomisation + noise (seed)", "poses": n_done[0],
                       "steps": sargs.inference_steps, "precision": prec_c, "seconds": dt, "value": n_done[0] * sargs.inference_steps / dt,
-                      "unit": "pose-steps/s", "first_batch_delivered_s": round(t_fill, 3), "steady_value": steady,
+                      "unit": "pose-steps/s", "failed_units": n_failed[0], "first_batch_delivered_s": round(t_fill, 3), "steady_value": steady,
                       "steady_note": "poses after the first device batch / time after its delivery: the rate of a long library, where the start-up "
                                      "(units of the first batch built and packed before anything runs) is paid once; a kernel trace of this call "
                                      "shows no GPU idle gap >= 0.3 ms between the first launch and the last write-back (tools/trace_gaps.py)",
@@ -502,7 +518,9 @@ def main():
 
     def launch_work(pbx, ecounts, layer, convs, prec):
         """Work of ONE launch of interaction layer `layer` that carries `convs` (numbering of DpWork.prof_conv): node-form algorithmic flops
-        (DESIGN.md 5.1), SURVEY.md 8d's edge-side flops and operator-boundary bytes, and the MFMA flops the node-side kernel issues."""
+        (DESIGN.md 5.1), SURVEY.md 8d's edge-side flops and operator-boundary bytes, and the MFMA flops the node-side kernel issues.
+        `prec`: which node-side kernel - "f32" (fp32 MFMA, 16-node groups), "bf16" (bf16 operands, 16-node groups) or "f16x3" (two fp16 limbs
+        per operand, 8-node groups)."""
         nl_, np__ = [int(x) for x in pbx.nl], [int(x) for x in pbx.np_]
         nB = len(nl_)
         n_x_, n_ll_ = int(pbx.x_ptr[-1]), ecounts["ll"]
@@ -512,18 +530,19 @@ def main():
         gather = {c: (sum(nl_) if c in (0, 4, 5) else sum(np__)) for c in convs}
         n_edges = sum(edges.values())
         node_flops = sum(edges[c] * 2 * 61 * (20 + NODE_COLS[layer]) + n_scat * 2 * 61 * (21 + NODE_W[layer]) + gather[c] * 2 * 61 * 20 for c in convs)
-        bf = prec == "bf16"
+        bf = prec in ("bf16", "f16x3")            # 16x16x32 MFMAs on the 16-bit pipe
+        grp = 8 if prec == "f16x3" else 16        # scatter nodes per workgroup
 
-        def pass_units(n_slots):      # 32-slot passes of a node; fp32 kernel: a last pass of <= 16 slots is half a pass (bf16: GEMM-A / GEMM-B MFMAs are not halved)
+        def pass_units(n_slots):      # 32-slot passes of a node; fp32 kernel: a last pass of <= 16 slots is half a pass (16-bit kernels: GEMM-A / GEMM-B MFMAs are not halved)
             full, rem = divmod(n_slots, 32)
             return full + (0 if rem == 0 else (0.5 if (rem <= 16 and not bf) else 1.0))
         scat_i = nl_ if lig_side else np__
         slots = {c: (nl_ if (c == 0 or not lig_side) else np__) for c in convs}
-        passes = sum(((scat_i[i] + 15) // 16) * pass_units(slots[c][i]) for c in convs for i in range(nB))
-        per_wave = (NODE_MFMA_PER_WAVE_BF16 if bf else NODE_MFMA_PER_WAVE)[layer]
+        passes = sum(((scat_i[i] + grp - 1) // grp) * pass_units(slots[c][i]) for c in convs for i in range(nB))
+        per_wave = {"bf16": NODE_MFMA_PER_WAVE_BF16, "f16x3": NODE_MFMA_PER_WAVE_F16}.get(prec, NODE_MFMA_PER_WAVE)[layer]
         issued = passes * 4 * per_wave * (16384.0 if bf else 2048.0)
         return dict(edges=n_edges, node_flops=node_flops, edge_flops=ALG_FLOPS_PER_EDGE[layer] * n_edges, alg_bytes=ALG_BYTES_PER_EDGE[layer] * n_edges,
-                    issued_flops=issued, workgroups=int(sum((n + 15) // 16 for n in scat_i)))
+                    issued_flops=issued, workgroups=int(sum((n + grp - 1) // grp for n in scat_i)))
 
     def step_weighted(pbx, ecounts, table, prec, peak):
         """sum of node-form flops / sum of launch time over every NODE-SIDE launch of a step (from the per-launch table)"""
@@ -590,12 +609,15 @@ def main():
     # accumulators, so the algorithmic work of the launch is the sum over its convs.  Edge-side it is the single conv.
     first, count, launch_node = prof_launch
     convs = list(range(first, first + count))
-    wk = launch_work(pb, edge_counts, PROF_LAYER, convs, precision)
+    node_kern = main["node_side_convs"] if precision == "f32" else precision        # which node-side kernel ran: f32 | f16x3 | bf16
+    wk = launch_work(pb, edge_counts, PROF_LAYER, convs, node_kern)
     launch_edges, alg_bytes, flops = wk["edges"], wk["alg_bytes"], wk["edge_flops"]
     conv_names = {0: "ligand-ligand", 1: "phore->ligand", 2: "phore->ligand(normals)"}
     kernel_name = (f"layer-{PROF_LAYER} ligand-side launch = {' + '.join(conv_names[c] for c in convs)}"
-                   + (" fused into one node-side launch" if count > 1 else "") + f", conv_algo={algo_used}, precision={precision}")
-    peak = MFMA_BF16_PEAK_TFLOPS if precision != "f32" else MFMA_F32_PEAK_TFLOPS
+                   + (" fused into one node-side launch" if count > 1 else "") + f", conv_algo={algo_used}, precision={precision}"
+                   + (f", node-side kernel {node_kern}" if launch_node else ""))
+    on16 = precision != "f32" or (launch_node and node_kern == "f16x3")        # the launch's MFMAs run on the 16-bit matrix pipe
+    peak = MFMA_BF16_PEAK_TFLOPS if on16 else MFMA_F32_PEAK_TFLOPS
     if launch_node:
         rf_flops = wk["node_flops"]
         rf_note = (f"node-side formulation, summed over the {count} conv(s) of the launch: 2*61*(20+{NODE_COLS[PROF_LAYER]}) flop per edge (edge part of radial layer 1 + "
@@ -605,7 +627,8 @@ def main():
         rf_issue = {"executed_flops_per_launch": issued, "achieved": issued / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
                     "frac": issued / (kern_ms * 1e-3) / 1e12 / peak if kern_ms > 0 else None, "workgroups": wk["workgroups"],
                     "note": "MFMA flops actually issued (padding included; fp32 kernel: a half pass counted as half of a 32-slot pass, the lig-lig "
-                            "conv's second layer-1 sweep over bond edges not counted) / launch time = matrix-pipe occupancy"}
+                            "conv's second layer-1 sweep over bond edges not counted; f16x3 kernel: 3 limb products per GEMM1 / GEMM-A MFMA, 2 W2 limbs "
+                            "x (T_hi | T_lo in N) per GEMM-B MFMA) / launch time = matrix-pipe occupancy"}
     else:
         rf_flops, rf_note, rf_issue = flops, "SURVEY.md 8d: 2*(60*60+60*numel)+TP flop per edge-conv (edge-side formulation)", None
     traffic, traffic_src = measured_traffic(a.config, B, precision, algo_used) if world == 1 else (None, None)
@@ -615,8 +638,12 @@ def main():
         dtype = {"f32": "f32", "bf16x9": "f32 (bf16x9 split, exact products, fp32 accumulate)",
                  "bf16x6": "f32 (bf16x6 split, ~2^-24 products, fp32 accumulate)", "bf16x3": "bf16x3 split (~2^-17 products), fp32 accumulate",
                  "bf16": "bf16 operands, fp32 accumulate"}[precision]
-        if precision == "f32" and main["edge_side_convs"] != "f32":
-            dtype = "f32 (node-side convs: exact fp32 MFMA; edge-side convs = phore-phore, torsion bonds [, ligand-ligand above 32 atoms]: bf16x6 split, ~2^-24 products, fp32 accumulate)"
+        if precision == "f32" and (main["edge_side_convs"] != "f32" or main["node_side_convs"] != "f32"):
+            nd = ("f16x3 = every GEMM operand as two fp16 limbs (22 significand bits, exact power-of-two scales), limb cross products on "
+                  "v_mfma_f32_16x16x32_f16, fp32 accumulate" if main["node_side_convs"] == "f16x3" else "exact fp32 MFMA")
+            ed = ("bf16x6 split, ~2^-24 products, fp32 accumulate" if main["edge_side_convs"] != "f32" else "exact fp32 MFMA")
+            dtype = (f"f32-grade (fp32 model held to the fp32 parity tolerances; node-side convs: {nd}; edge-side convs = phore-phore, torsion bonds "
+                     f"[, ligand-ligand above 32 atoms]: {ed}; exact-fp32-MFMA-everywhere arm: value_exact_fp32)")
         rank_rate = [p_ * a.steps / t_ for p_, t_ in zip(rank_poses, main["rank_seconds"])]
         out = {
             "metric": "poses/sec (samples x steps) on the reverse-diffusion hot path",
@@ -631,7 +658,10 @@ def main():
                        "poses_per_gpu": B, "poses_total": total_poses, f"poses_per_sec_at_{S_total}_steps": total_poses * a.steps / elapsed / S_total,
                        "parallelism": f"independent poses sharded over {world} GPU(s), RCCL weight broadcast only",
                        "kabsch_flagged_poses": bad, "finite": finite, "precision": precision, "conv_algo": algo_used,
-                       "edge_side_convs": main["edge_side_convs"],
+                       "edge_side_convs": main["edge_side_convs"], "node_side_convs": main["node_side_convs"],
+                       "node_side_convs_note": "what the node-side launches (ligand-ligand + cross convs: 21 per forward) run: 'f16x3' = the fp32-grade two-limb "
+                                               "fp16 kernel (dp_conv_node_f16_impl.h; library default DpWork.node_f16 = 1, same parity tolerances as fp32: "
+                                               "tests/test_conv_f16_gpu.py 2-4e-7 of max vs the fp64 oracle), 'f32' = v_mfma_f32_16x16x4_f32 (DIFFPHORE_NODE_F16=0)",
                        "edge_side_convs_note": "what the convs that stay on the edge-side kernel (phore-phore, torsion bonds; ligand-ligand above 32 atoms) run: "
                                                "'bf16x6' = 3-way bf16 operand split, 6 cross products, fp32 accumulate (fp32-grade: same parity tolerances; the "
                                                "library default, DpWork.edge_bf16x6 = 1), 'f32' = exact fp32 MFMA (alt_runs[0] times that arm)",
@@ -649,7 +679,7 @@ def main():
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": rf_flops / (kern_ms * 1e-3) / 1e12 / peak if kern_ms > 0 else None,
                          "alg_flops_per_launch": rf_flops, "flop_count": rf_note,
-                         "step_weighted": step_weighted(pb, edge_counts, main["launch_table"], precision, peak),
+                         "step_weighted": step_weighted(pb, edge_counts, main["launch_table"], node_kern, peak),
                          "edge_side_count": {"achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
                                              "frac": flops / (kern_ms * 1e-3) / 1e12 / peak if kern_ms > 0 else None,
                                              "note": "SURVEY.md 8d's per-edge count (radial GEMM per edge) x edges / launch time: what an edge-side "
@@ -662,10 +692,21 @@ def main():
                          "hbm_equivalent": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                                             "note": "algorithmic bytes of the e3nn operator boundary (per-edge weights counted as "
                                                     "HBM input, SURVEY.md 8d) / launch time; the metric's 'fused TP-scatter HBM GB/s'"},
+                         "fp32_pipe_equivalent": ({"frac": rf_flops / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                                   "note": "the same algorithmic flops against the fp32-input MFMA peak (157.3 TFLOP/s), the pipe that bounded this "
+                                                           "launch through round 4 (0.44): what moving the association to the 16-bit pipe bought"}
+                                                  if (on16 and precision == "f32" and kern_ms > 0) else None),
+                         "bound_note": ("the f16x3 kernel is bound by VALU ISSUE (limb extraction: v_cvt_pk_f16_f32 + v_fma_mixlo/mixhi_f16 per operand pair, "
+                                        "the tensor-product operand z built per node), not by the matrix pipe: SQ_VALU_MFMA_BUSY / (4 SQ_BUSY_CU) and the "
+                                        "instruction mix in profiles/r5_f16_node_pmc.csv, timing ablations in profiles/r5_experiments.md") if (on16 and precision == "f32") else None,
                          "traffic_note": (f"HBM bytes per launch from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), {traffic_src}, "
                                           f"kernel sources {kernel_source_hash()}") if traffic is not None else
                                          "null: no committed PMC profile matches this library build / workload (profiles/conv_hbm_traffic.json)"},
         }
+        if alt and "value" in alt[0]:
+            # the exact-fp32-MFMA-everywhere arm as top-level fields (the driver record keeps only the head of config.alt_runs)
+            out["value_exact_fp32"] = alt[0]["value"]
+            out["ms_per_step_exact_fp32"] = alt[0]["ms_per_step"]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(graphs, sd, cfg, margs, a.cpu_poses, a.cpu_steps, S_total)
         print(json.dumps(out), flush=True)

@@ -135,7 +135,7 @@ __device__ __forceinline__ void load_x2(const XSrc& xs, int lane_l, int st, f32x
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int t = 0; t < NTERM; ++t) {
-#if DP_BABL == 1
+#if DP_BABL == 1 || (defined(DPF_ABL) && DPF_ABL == 1)
           v[t][j] = __builtin_bit_cast(float, vt[t] + xs.soff[j]);
 #else
           v[t][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xs.rs, vt[t], xs.soff[j], 0));

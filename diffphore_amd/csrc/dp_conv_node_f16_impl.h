@@ -31,6 +31,10 @@
 #pragma once
 #include "dp_conv_node_bf16_impl.h"
 
+#ifndef DPF_ABL     // timing ablations of THIS kernel (tools/build_variant.sh; results are wrong by construction): 1 no gathered-operand loads, 2 no SH-factor
+#define DPF_ABL 0   // reads, 3 no z arithmetic / limb extraction, 4 no GEMM-A MFMAs, 5 no T split / stores, 6 no T reads, 7 no GEMM-B MFMAs, 8 no W2 loads,
+#endif              // 9 no edge-embedding loads (GEMM1)
+
 namespace dpf {
 using namespace dpn;
 using dpb::u32x4;
@@ -60,6 +64,37 @@ constexpr int HDR_QUADS = 4;          // header of the W2 image (16-byte quads):
 constexpr int A0 = 5;                 // T carries 2^(A0 + w_min - w) <= 2^5
 constexpr float W1_SCALE = 16.f;      // first layer stored as 16 W1
 constexpr float FLAG_W = -60000.f;    // W1 row of the "edge does not exist" flag (in units of 16 W1)
+
+// The gathered features of the pass's 32 edge slots are staged in LDS once per pass and workgroup (they are the same rows for every scatter node
+// of the group and for all four waves), in two halves of 50 input columns: every layer kind's paths read columns 0..49 first and 50..99 last
+// (dp_spec.h), so the buffer is re-filled once per pass, between those two groups of paths.  [32 rows][XROW floats]; 52 = 50 + 2: a row is a
+// whole number of 16-byte quads, and two rows read by one ds_read_b32 (lane groups g, g + 1: rows 4 apart = 208 dwords = 16 banks) never share
+// a bank for the <= 15 consecutive columns a tile touches.
+constexpr int XHALF = 50;             // input columns per staged half
+constexpr int XROW = 52;              // floats per staged row
+constexpr int XQUADS = XROW / 4;      // 16-byte quads per staged row
+template <int KIND> constexpr int x_half_of(int p) { return Spec<KIND>::P[p].in_off >= XHALF ? 1 : 0; }
+template <int KIND> constexpr bool x_halves_ok() {
+  using S = Spec<KIND>;
+  for (int i = 0; i < S::NPATH; ++i) {
+    const int lo = S::P[i].in_off, hi = lo + S::P[i].mul_in * d_in_of(S::P[i].ztype);
+    if (lo < XHALF && hi > XHALF) return false;                       // a path's columns lie inside one half
+    if (hi - XHALF * x_half_of<KIND>(i) > XHALF) return false;
+    if (i > 0 && x_half_of<KIND>(i) < x_half_of<KIND>(i - 1)) return false;     // ... and the halves are visited in order
+  }
+  return true;
+}
+static_assert(x_halves_ok<0>() && x_halves_ok<1>() && x_halves_ok<2>() && x_halves_ok<3>(), "paths read input columns 0..49, then 50..99");
+// all 256 threads: rows 32 et .. 32 et + 31 of the pose's gather table (through the pose-limited buffer resource: a row past the pose's last node
+// reads 0), columns 50 half .. 50 half + 51
+__device__ __forceinline__ void stage_x(__amdgpu_buffer_rsrc_t xrs, unsigned gstride4, int et, int half, int tid, float* s_X) {
+#pragma unroll
+  for (int idx = tid; idx < 32 * XQUADS; idx += 256) {
+    const int row = idx / XQUADS, qd = idx - row * XQUADS;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (unsigned)(32 * et + row) * gstride4 + (unsigned)((XHALF * half + 4 * qd) * 4), 0, 0);
+    *reinterpret_cast<u32x4*>(s_X + row * XROW + 4 * qd) = v;
+  }
+}
 
 template <int KIND> constexpr int w2h_path_off(int p) {             // in 16-byte quads
   int o = HDR_QUADS;
@@ -127,6 +162,22 @@ __device__ __forceinline__ HL split2(float v0, float v1) {         // one pair (
 }
 __device__ __forceinline__ f16x8 as_h(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h(a), as_h(b), c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma_a(u32x4 a, u32x4 b, f32x4 c) {      // GEMM-A
+#if DPF_ABL == 4
+  asm volatile("" ::"v"(a), "v"(b));
+  return c + f32x4{__builtin_bit_cast(float, b[0]), 1.f, 2.f, 3.f};
+#else
+  return mfma_h(a, b, c);
+#endif
+}
+__device__ __forceinline__ f32x4 mfma_b(u32x4 a, u32x4 b, f32x4 c) {      // GEMM-B
+#if DPF_ABL == 7
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+#else
+  return mfma_h(a, b, c);
+#endif
+}
 // hi*hi + hi*lo + lo*hi, smallest terms first
 __device__ __forceinline__ f32x4 mfma3(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x4 c) {
   c = mfma_h(al, bh, c);
@@ -151,9 +202,9 @@ __device__ __forceinline__ Grp grp_of8(const DpConvArgs& a, int bid) {     // as
 
 template <int KIND, int MODE, bool HALF, int P>
 struct StageH {
-  static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t wrs, const XSrc& xs, int q, int lane, const u32x4 (&hid)[2 * NBH],
-                                             unsigned tl_base, unsigned dummy_base, const float* sS, f32x4 (&acc)[n_acc4<KIND>()],
-                                             f32x2 (&xr)[2][3][4]) {
+  static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t wrs, __amdgpu_buffer_rsrc_t xrs, unsigned gstride4, int et, int tid, float* sX, int q,
+                                             int lane, const u32x4 (&hid)[2 * NBH], unsigned tl_base, unsigned dummy_base, const float* sS,
+                                             f32x4 (&acc)[n_acc4<KIND>()]) {
     using S = Spec<KIND>;
     if constexpr (P < S::NPATH) {
       constexpr PathC pc = S::P[P];
@@ -161,6 +212,11 @@ struct StageH {
       constexpr bool VEC = d_out_of(ZT) == 3;
       constexpr int NG = VEC ? 3 : 1, NTERM = n_terms<ZT>(), MT = path_mt<KIND>(P), AB = acc_base<KIND>(P), NTILE = VEC ? 2 : 1;
       constexpr int NJ = HALF ? 4 : 8, NT2 = HALF ? 1 : 2;
+      if constexpr (P > 0 && x_half_of<KIND>(P) != x_half_of<KIND>(P > 0 ? P - 1 : 0)) {
+        __syncthreads();                            // every wave is done with the first half of the input columns
+        stage_x(xrs, gstride4, et, 1, tid, sX);
+        __syncthreads();
+      }
 #pragma unroll 1
       for (int st = 0; st < st_count<KIND>(P); ++st) {
         int lane_l = lane;
@@ -168,13 +224,31 @@ struct StageH {
         const int g = lane_l >> 4, c = lane_l & 15;
         const int m = VEC ? (c >= 10 ? 2 : (c >= 5 ? 1 : 0)) : 0;
         const bool colv = VEC ? c < 15 : c < 10;
+        // gathered operand of the lane's column in both tiles, for the lane's 8 (HALF: 4) edge slots, as pairs of consecutive slots (the operand
+        // layout of v_pk_*_f32), from the staged rows: slot pair jp = rows 16 (jp >> 1) + 4 g + 2 (jp & 1), + 1 (the same rows for every node)
         f32x2 xa[NTILE][NTERM][NJ / 2];
+        {
+          constexpr int DIN = d_in_of(ZT);
+          const int ul = VEC ? c - 5 * m : c;
 #pragma unroll
-        for (int tl = 0; tl < NTILE; ++tl)
+          for (int tl = 0; tl < NTILE; ++tl) {
+            const int u = colv ? SUPER_NU * st + 5 * tl + ul : 0;
+            const float* xb = sX + (4 * g) * XROW + (pc.in_off - XHALF * x_half_of<KIND>(P)) + u * DIN;
 #pragma unroll
-          for (int t = 0; t < NTERM; ++t)
+            for (int t = 0; t < NTERM; ++t) {
+              const float* xt = xb + term_of<ZT>(t, m).xcomp;
 #pragma unroll
-            for (int jp = 0; jp < NJ / 2; ++jp) xa[tl][t][jp] = xr[tl][t][jp];
+              for (int jp = 0; jp < NJ / 2; ++jp) {
+                const int row = 16 * (jp >> 1) + 2 * (jp & 1);
+#if DPF_ABL == 1
+                xa[tl][t][jp] = f32x2{(float)(size_t)xt, (float)row};
+#else
+                xa[tl][t][jp] = f32x2{xt[row * XROW], xt[(row + 1) * XROW]};
+#endif
+              }
+            }
+          }
+        }
         // T image: byte address of (column, k quad g, node slot) = column * 520 + g * 128 + slot * 8; slot nn = hi limb, slot nn + 8 = lo limb
         unsigned twr[NTILE];
 #pragma unroll
@@ -191,7 +265,11 @@ struct StageH {
           for (int ch = 0; ch < SUPER_CH; ++ch)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
+#if DPF_ABL == 8
+              wall[lb][ch][mt] = u32x4{wvoff, wsoff, (unsigned)ch, (unsigned)(lb + mt)};
+#else
               wall[lb][ch][mt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff + (unsigned)(((lb * SUPER_CH + ch) * MT + mt) * 256 * 16), 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM-A: three MFMAs per (node, tile); T leaves as two fp16 limbs ---------------------------------------------------------
         // node nn's MFMAs go into a ring of two accumulator sets, their results are split / stored one node LATER (behind the next node's
@@ -201,9 +279,13 @@ struct StageH {
 #pragma unroll
           for (int tl = 0; tl < NTILE; ++tl) {
             const f32x4 D = Dq[nn & 1][tl];
+#if DPF_ABL == 5
+            asm volatile("" ::"v"(D), "v"(twr[tl]));
+#else
             const HL2 t = split4(D[0], D[1], D[2], D[3]);
             *lds_ptr(twr[tl] + (unsigned)(nn << 3)) = u32x2{t.h0, t.h1};
             *lds_ptr(twr[tl] + (unsigned)((nn + NBH) << 3)) = u32x2{t.l0, t.l1};
+#endif
           }
         };
         if constexpr (needs_s<ZT>()) {
@@ -215,7 +297,12 @@ struct StageH {
 #pragma unroll
             for (int t = 0; t < NTERM; ++t)
 #pragma unroll
-              for (int t2 = 0; t2 < NT2; ++t2) sv[t][t2] = *reinterpret_cast<const f32x4*>(sbase + (2 * nn + t2) * (SCOMP * 64) + soff[t]);
+              for (int t2 = 0; t2 < NT2; ++t2)
+#if DPF_ABL == 2
+                sv[t][t2] = f32x4{(float)soff[t], (float)nn, 1.f, 2.f};
+#else
+                sv[t][t2] = *reinterpret_cast<const f32x4*>(sbase + (2 * nn + t2) * (SCOMP * 64) + soff[t]);
+#endif
           };
           constexpr int SD = (VEC && NTERM == 3) ? 1 : 2;
           f32x4 sv[SD][NTERM][NT2];
@@ -231,6 +318,11 @@ struct StageH {
             for (int tl = 0; tl < NTILE; ++tl) {
               zh[tl] = u32x4{0u, 0u, 0u, 0u};
               zl[tl] = u32x4{0u, 0u, 0u, 0u};
+#if DPF_ABL == 3
+              zh[tl] = __builtin_bit_cast(u32x4, f32x4{xa[tl][0][0][0], xa[tl][NTERM - 1][NJ / 2 - 1][1], sv[cur][0][0][0], sv[cur][NTERM - 1][NT2 - 1][3]});
+              zl[tl] = zh[tl];
+              continue;
+#endif
               // edge slots 2 jp, 2 jp + 1 of the lane = components (2 jp & 3, + 1) of the factor quad of 16-edge tile jp >> 1
               auto spair = [&](int t, int jp) { const f32x4 q4 = sv[cur][t][jp >> 1]; return (jp & 1) ? f32x2{q4[2], q4[3]} : f32x2{q4[0], q4[1]}; };
               if constexpr (NTERM == 1) {
@@ -265,11 +357,11 @@ struct StageH {
               if (nn + 1 < NBH) loadS(nn + 1, sv[0]);
             }
 #pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_h(hid[NBH + nn], zh[tl], f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_a(hid[NBH + nn], zh[tl], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_h(hid[nn], zl[tl], Dq[nn & 1][tl]);
+            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_a(hid[nn], zl[tl], Dq[nn & 1][tl]);
 #pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_h(hid[nn], zh[tl], Dq[nn & 1][tl]);
+            for (int tl = 0; tl < NTILE; ++tl) Dq[nn & 1][tl] = mfma_a(hid[nn], zh[tl], Dq[nn & 1][tl]);
             if (nn > 0) store_t(nn - 1);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -296,10 +388,14 @@ struct StageH {
 #pragma unroll
               for (int tl = 0; tl < NTILE; ++tl) {
                 const f32x4 D = Dp[np & 1][k][tl];
+#if DPF_ABL == 5
+                asm volatile("" ::"v"(D), "v"(twr[tl]));
+#else
                 const HL2 t = split4(D[0], D[1], D[2], D[3]);
                 const int nn = 2 * np + k;
                 *lds_ptr(twr[tl] + (unsigned)(nn << 3)) = u32x2{t.h0, t.h1};
                 *lds_ptr(twr[tl] + (unsigned)((nn + NBH) << 3)) = u32x2{t.l0, t.l1};
+#endif
               }
           };
 #pragma unroll
@@ -307,15 +403,15 @@ struct StageH {
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl)
 #pragma unroll
-              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_h(hid[NBH + 2 * np + k], zh[tl], f32x4{0.f, 0.f, 0.f, 0.f});
+              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_a(hid[NBH + 2 * np + k], zh[tl], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl)
 #pragma unroll
-              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_h(hid[2 * np + k], zl[tl], Dp[np & 1][k][tl]);
+              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_a(hid[2 * np + k], zl[tl], Dp[np & 1][k][tl]);
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl)
 #pragma unroll
-              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_h(hid[2 * np + k], zh[tl], Dp[np & 1][k][tl]);
+              for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_a(hid[2 * np + k], zh[tl], Dp[np & 1][k][tl]);
             if (np > 0) store_p(np - 1);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -325,20 +421,21 @@ struct StageH {
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM-B: out[w][slot] += W2_limb[w][(u,k)] (T_hi | T_lo)[(u,k)][slot], K = (two in-channels) x (the wave's 16 hidden rows) ----------
         {
-          constexpr int PN = P + 1;
           const unsigned rbase = tl_base + (unsigned)(g * 128 + c * 8);          // GEMM-B view: node slot c, k quad g; the column is an immediate offset
           auto readT = [&](int ch, u32x4 (&tb)[NG]) {
 #pragma unroll
             for (int grp = 0; grp < NG; ++grp) {
+#if DPF_ABL == 6
+              const u32x2 lo = {rbase + ch, (unsigned)grp}, hi = {rbase, 7u};
+#else
               const u32x2 lo = *lds_ptr(rbase + (unsigned)(t_col<VEC>(2 * ch, grp) * COLB));
               const u32x2 hi = *lds_ptr(rbase + (unsigned)(t_col<VEC>(2 * ch + 1, grp) * COLB));
+#endif
               tb[grp] = u32x4{lo.x, lo.y, hi.x, hi.y};
             }
           };
           u32x4 tb[2][NG];
           readT(0, tb[0]);
-          if (st + 1 < st_count<KIND>(P)) dpb::load_x2<KIND, MODE, HALF, P>(xs, lane_l, st + 1, xr);
-          else dpb::load_x2<KIND, MODE, HALF, PN>(xs, lane_l, 0, xr);
 #pragma unroll
           for (int ch = 0; ch < SUPER_CH; ++ch) {
             if (ch + 1 < SUPER_CH) readT(ch + 1, tb[(ch + 1) & 1]);
@@ -347,12 +444,12 @@ struct StageH {
 #pragma unroll
               for (int grp = 0; grp < NG; ++grp)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[AB + grp * MT + mt] = mfma_h(wall[lb][ch][mt], tb[ch & 1][grp], acc[AB + grp * MT + mt]);
+                for (int mt = 0; mt < MT; ++mt) acc[AB + grp * MT + mt] = mfma_b(wall[lb][ch][mt], tb[ch & 1][grp], acc[AB + grp * MT + mt]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
-      StageH<KIND, MODE, HALF, P + 1>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr);
+      StageH<KIND, MODE, HALF, P + 1>::run(wrs, xrs, gstride4, et, tid, sX, q, lane, hid, tl_base, dummy_base, sS, acc);
     }
   }
 };
@@ -360,7 +457,7 @@ struct StageH {
 // one pass (32 edge slots per node; HALF: 16) of one conv: stage the SH factors, GEMM1 -> hid (two fp16 limbs, A fragments), then the path stages
 template <int KIND, int MODE, bool HALF>
 __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t ers, __amdgpu_buffer_rsrc_t wrs, const Grp& grp, const Wg& r, int et, int tid,
-                                         float* s_T, float* s_S, const float* s_inv, f32x4 (&acc)[n_acc4<KIND>()]) {
+                                         float* s_T, float* s_S, float* s_X, const float* s_inv, f32x4 (&acc)[n_acc4<KIND>()]) {
   const int lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
   constexpr int NT2 = HALF ? 1 : 2;
   constexpr int NSTEP = NBH * NT2;
@@ -398,7 +495,10 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
     const int srow = grp.n_lo + (c < grp.n_loc ? c : 0);
     attr_frag(s_tab + (size_t)srow * s_stride, true, as_h, as_l);
   }
-  // ---- stage the SH-derived factors of the pass (fp32) and, in the pair mode, the pass's pair -> edge-slot entries ----------------
+  // ---- stage the first half of the gathered rows, the SH-derived factors of the pass (fp32) and, in the pair mode, the pass's pair ->
+  // edge-slot entries ------------------------------------------------------------------------------------------------------------------------
+  const unsigned gstride4 = uni((unsigned)a.gather_stride * 4u);
+  stage_x(xrs, gstride4, et, 0, tid, s_X);
   constexpr int SLOTS = HALF ? 16 : 32;
 #pragma unroll
   for (int idx = tid; idx < NBH * SLOTS; idx += 256) {
@@ -454,8 +554,13 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
     }
     if (frow < 0) frow = a.emb_flag_row;
     const unsigned off = (unsigned)frow * (unsigned)(EMBH_ROW * 2) + (unsigned)(16 * g);
+#if DPF_ABL == 9
+    eh = u32x4{off, 0u, 0u, 7u};
+    el = u32x4{off, 1u, 0u, 7u};
+#else
     eh = __builtin_amdgcn_raw_buffer_load_b128(ers, off, 0, 0);
     el = __builtin_amdgcn_raw_buffer_load_b128(ers, off, 64, 0);            // (soffset = 64: the lo limbs of the same features)
+#endif
   };
   constexpr int PF = 3;
   u32x4 ea_h[PF + 1], ea_l[PF + 1], eb_h[PF + 1], eb_l[PF + 1];
@@ -466,13 +571,6 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
     if constexpr (MODE == LL) load_a(s0, 1, eb_h[s0], eb_l[s0]);
   }
   u32x4 hid[2 * NBH];
-  f32x2 xr0[2][3][4];
-  XSrc xs;
-  xs.rs = xrs;
-  const unsigned gstride4 = uni((unsigned)a.gather_stride * 4u);
-  xs.voff_row = (unsigned)(32 * et + 4 * g) * gstride4;                         // relative to the pose's first gather row (the resource's base)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) xs.soff[j] = (unsigned)(16 * (j >> 2) + (j & 3)) * gstride4;
   float hf[8];
   f32x4 Dg[2], Dg2[2];
   bool has2[2] = {false, false};
@@ -508,7 +606,6 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
       load_a(step + PF, 0, ea_h[(step + PF) % (PF + 1)], ea_l[(step + PF) % (PF + 1)]);
       if constexpr (MODE == LL) load_a(step + PF, 1, eb_h[(step + PF) % (PF + 1)], eb_l[(step + PF) % (PF + 1)]);
     }
-    if (step == NSTEP - 3) dpb::load_x2<KIND, MODE, HALF, 0>(xs, lane, 0, xr0);          // first supertile's operands: behind the last emb request
     const float us_n = sT[nn * 16 + c];
     const f32x4 init = {us_n + ug[t2][0], us_n + ug[t2][1], us_n + ug[t2][2], us_n + ug[t2][3]};
     Dg[step & 1] = mfma3(ea_h[step % (PF + 1)], ea_l[step % (PF + 1)], Wemb_h, Wemb_l, init);
@@ -526,12 +623,12 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
   if constexpr (MODE == LL) __syncthreads();      // s_pair lives in wave 0's T image: every wave is done reading it before T tiles land there
   const unsigned tl_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(q * TIMG_B);
   const unsigned dummy_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(4 * TIMG_B);
-  StageH<KIND, MODE, HALF, 0>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0);
+  StageH<KIND, MODE, HALF, 0>::run(wrs, xrs, gstride4, et, tid, s_X, q, lane, hid, tl_base, dummy_base, s_S, acc);
 }
 
 // every pass of one conv of the (possibly fused) launch; `hs` = 2^(S - w) of this conv
 template <int KIND, int MODE>
-__device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, int tid, float hs, float* s_T, float* s_S, float* s_inv,
+__device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, int tid, float hs, float* s_T, float* s_S, float* s_X, float* s_inv,
                                          f32x4 (&acc)[n_acc4<KIND>()]) {
   const Wg r = wg_of<MODE>(a, grp.pose);
   __syncthreads();                                 // the previous conv's GEMM1 is done with s_inv
@@ -549,8 +646,8 @@ __device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, in
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w2n, (unsigned)w2h_quads<KIND>() * 16u);          // the conv's W2 image (GEMM-B's A fragments)
 #pragma unroll 1
   for (int et = 0; et < n_et; ++et) {
-    if (r.En - 32 * et <= 16) pass_f16<KIND, MODE, true>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc);
-    else pass_f16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc);
+    if (r.En - 32 * et <= 16) pass_f16<KIND, MODE, true>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
+    else pass_f16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
   }
 }
 
@@ -560,6 +657,7 @@ template <int KIND, bool HAS_LL, int XMODE>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_f16_kernel(FusedArgs fa) {
   __shared__ __attribute__((aligned(128))) float s_T[4 * TIMG_F + TDUM_B / 4];   // wave-private T images (fp16, hi | lo node slots) + the dummy column; reused for the reduction
   __shared__ __attribute__((aligned(16))) float s_S[NBH * SCOMP * 32];         // per-edge sh factors of the current pass (fp32)
+  __shared__ __attribute__((aligned(16))) float s_X[32 * XROW];               // the pass's gathered rows, one half of the input columns at a time
   __shared__ float s_inv[NBH];
   using S = Spec<KIND>;
   static_assert(4 * NB * S::D_OUT <= 4 * TIMG_F, "reduction scratch fits in the T images");
@@ -574,11 +672,11 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_f16_kernel(FusedArgs fa) 
   float w_min = w2_exponent(fa.conv[0]);
   for (int k = 1; k < n_conv; ++k) w_min = fminf(w_min, w2_exponent(fa.conv[k]));
   const float s_exp = w_min + (float)A0;
-  if constexpr (HAS_LL) conv_f16<KIND, LL>(fa.conv[0], grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(fa.conv[0]))), s_T, s_S, s_inv, acc);
+  if constexpr (HAS_LL) conv_f16<KIND, LL>(fa.conv[0], grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(fa.conv[0]))), s_T, s_S, s_X, s_inv, acc);
 #pragma unroll 1
   for (int cx = 0; cx < fa.n_x; ++cx) {
     const DpConvArgs& a = fa.conv[(HAS_LL ? 1 : 0) + cx];
-    conv_f16<KIND, XMODE>(a, grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(a))), s_T, s_S, s_inv, acc);
+    conv_f16<KIND, XMODE>(a, grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(a))), s_T, s_S, s_X, s_inv, acc);
   }
   // ---- sum the four k-partials and the two limb halves of the node slots, un-scale, BatchNorm shift, residual stream ----------------------
   {

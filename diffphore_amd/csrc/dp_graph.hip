@@ -155,16 +155,24 @@ __device__ __forceinline__ void store_flag_row_bf16(uint16_t* __restrict__ tab, 
 __device__ __forceinline__ void store_row_f16x2(uint16_t* __restrict__ dst, const float* v) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   typedef float f2 __attribute__((ext_vector_type(2)));
-  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  uint32_t hi[12], lo[12];
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    const h2 hi = __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, h2);
-    const h2 lo = __builtin_convertvector((f2){v[2 * i] - (float)hi[0], v[2 * i + 1] - (float)hi[1]}, h2);
-    d[i] = __builtin_bit_cast(uint32_t, hi);
-    d[16 + i] = __builtin_bit_cast(uint32_t, lo);
+    const h2 h = __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, h2);
+    const h2 l = __builtin_convertvector((f2){v[2 * i] - (float)h[0], v[2 * i + 1] - (float)h[1]}, h2);
+    hi[i] = __builtin_bit_cast(uint32_t, h);
+    lo[i] = __builtin_bit_cast(uint32_t, l);
   }
+  hi[10] = hi[11] = lo[10] = lo[11] = 0u;
+  u4* d = reinterpret_cast<u4*>(dst);                    // 128-byte rows of a 256-byte aligned table: eight 16-byte stores
 #pragma unroll
-  for (int i = 10; i < 16; ++i) { d[i] = 0u; d[16 + i] = 0u; }
+  for (int i = 0; i < 3; ++i) {
+    d[i] = u4{hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
+    d[4 + i] = u4{lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]};
+  }
+  d[3] = u4{0u, 0u, 0u, 0u};
+  d[7] = u4{0u, 0u, 0u, 0u};
 }
 __device__ __forceinline__ void store_flag_row_f16x2(uint16_t* __restrict__ tab, int n_rows, int tid) {
   if (tid < 64) tab[(size_t)n_rows * 64 + tid] = tid == 20 ? (uint16_t)0x3C00 : (uint16_t)0;

@@ -211,11 +211,22 @@ int dp_work_init(const DpBatch* b, DpWork* k, void* stream) {
 #ifndef DP_BABL
 #define DP_BABL 0
 #endif
+#ifndef DPF_ABL
+#define DPF_ABL 0
+#endif
+#ifdef DP_SPLIT_LEAN
+#define DP_SPLIT_LEAN_ON 1
+#else
+#define DP_SPLIT_LEAN_ON 0
+#endif
+// The switches are seen as THIS translation unit was compiled: tools/build_variant.sh therefore always recompiles dp_host.hip with the variant's
+// flags (and a variant source hash), so that a timing / ablation build cannot pass for the product library.
 int dp_build_info(DpBuildInfo* out) {
   if (!out) return DP_E_BADARG;
   memset(out, 0, sizeof(*out));
   out->abi_version = DP_ABI_VERSION;
-  out->nabl = DP_NABL ? DP_NABL : (DP_BABL ? 100 + DP_BABL : 0);      // (bf16 node-kernel ablations are reported as 100 + n)
+  // (bf16 node-kernel ablations are reported as 100 + n, f16x3 node-kernel ablations as 200 + n, the lean path-split experiment as 300)
+  out->nabl = DP_NABL ? DP_NABL : (DP_BABL ? 100 + DP_BABL : (DPF_ABL ? 200 + DPF_ABL : (DP_SPLIT_LEAN_ON ? 300 : 0)));
   out->ablate = DP_ABLATE;
 #ifdef DP_PROF
   out->prof = 1;

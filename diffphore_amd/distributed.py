@@ -239,7 +239,13 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
             out = []
             for c, i in enumerate(loaded[k]):
                 lo, hi = c * samples_per_complex, (c + 1) * samples_per_complex
-                out.append((i, None if any(status[lo:hi]) else torch.stack([p["ligand"].pos for p in part[lo:hi]]).numpy()))
+                st = [int(x) for x in status[lo:hi]]
+                if any(x & 2 for x in st):
+                    # status bit 1 (DpWork.status): the ligand graph repeats an ordered atom pair - deterministic, a new noise key cannot help:
+                    # fail the unit at once with its own reason instead of re-sampling it `retries` times as a Kabsch failure
+                    bad[i] = "ligand graph repeats an ordered atom pair (not representable in the node-side pair tables; status bit 1)"
+                    continue
+                out.append((i, None if any(st) else torch.stack([p["ligand"].pos for p in part[lo:hi]]).numpy()))
             k += 1
             flagged += settle(out, final)
             report_bad()

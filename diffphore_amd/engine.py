@@ -836,6 +836,7 @@ class Engine:
         if ps not in ("auto", "1", "0"):
             raise ValueError(f"DIFFPHORE_PATH_SPLIT must be auto, 1 or 0 (got {ps!r})")
         self.ws.struct.path_split = {"auto": 0, "1": 1, "0": 2}[ps]
+        self._ps_B, self._ps_nl = int(pb.B), int(max(pb.nl))
         self._handles = None
         self._graph = None
         # second stream (DpWork.aux_stream): 'auto' runs the phore-side convs and the torsion head beside the ligand-side convs when one
@@ -870,6 +871,14 @@ class Engine:
                 self.L.dp_sample_graph_destroy(self._graph)
             except Exception:      # noqa: BLE001
                 pass
+
+    def path_split_on(self) -> bool:
+        """whether the ligand-side node-side launches of this batch take the path split (dp_graph.hip: node_path_split_auto - two workgroups per
+        node group while B x groups <= 256); such launches run the exact-fp32 kernel even with DpWork.node_f16 = 1"""
+        ps = int(self.ws.struct.path_split)
+        if ps:
+            return ps == 1
+        return self._ps_B * ((self._ps_nl + 15) // 16) <= 256
 
     def launch_of(self, layer: int, conv: int):
         """(first, count, node_side) of the dp_forward launch that carries conv `conv` of interaction layer `layer` (conv numbering of

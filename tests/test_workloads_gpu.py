@@ -46,7 +46,7 @@ def _start_and_noise(poses, keys, S):
                 tor=torch.from_numpy(np.concatenate(ztor, 1)))
 
 
-@pytest.mark.parametrize("cfg_id,precision,tol", [(4, "f32", 1e-4), (5, "bf16x3", 5e-3), (5, "bf16", 1e-2)])
+@pytest.mark.parametrize("cfg_id,precision,tol", [(4, "f32", 1e-4), (5, "bf16x3", 5e-3), (5, "bf16", 6e-3)])
 def test_config_workload_matches_oracle(cfg_id, precision, tol, monkeypatch):
     """2 complexes x 40 samples of the configs[3] / configs[4] generators, first steps of their schedules (20 / 100 steps), HIP vs the
     fp64 oracle on a sample of the poses; configs[4] runs BASELINE's 'bf16 mixed precision': `bf16` = plain bf16 operands with fp32
@@ -82,12 +82,18 @@ def test_config_workload_matches_oracle(cfg_id, precision, tol, monkeypatch):
 
 
 # bounds of the full 100-step configs[4] run below, per precision: (every pose after 20 steps, every pose after 100 steps), Angstrom RMSD from the
-# fp64 oracle with the same start poses and noise.  Measured on MI355X (printed by the test): f32 ..., bf16x3 ..., bf16 ...
-FULL_RUN_BOUNDS = {"f32": (1e-4, 1e-3), "bf16x3": (5e-3, 5e-2), "bf16": (5e-2, 5e-1)}
+# fp64 oracle with the same start poses and noise.  Measured on MI355X (printed by the test, profiles/r5_configs4_100step.txt), max over the 6 poses
+# after 20 / 100 steps:   f32 (library default: f16x3 node-side + bf16x6 edge-side convs) 9.3e-5 / 8.9e-5;  f32-f16x3 (f16x3 node-side convs, exact
+# fp32 edge-side) and f32-exact (exact fp32 MFMA everywhere): see the profile;  bf16x3 9.5e-5 / 9.1e-5;  bf16 7.4e-4 / 1.6e-3.
+# (One pose of the six sits at 9e-5 from step 20 on in every arm that runs the phore-phore convs as a bf16 split, and at 8e-6 in the exact arm;
+# the other five stay below 5.4e-5 over all 100 steps.)
+FULL_RUN_BOUNDS = {"f32": (1.5e-4, 3e-4), "f32-f16x3": (1.5e-4, 3e-4), "f32-exact": (5e-5, 1e-4), "bf16x3": (1.5e-4, 3e-4), "bf16": (2.5e-3, 5e-3)}
+# environment of the fp32 arms: DIFFPHORE_NODE_F16 (two-limb fp16 node-side kernel), DIFFPHORE_EDGE_X6 (bf16x6 edge-side convs)
+FP32_ARMS = {"f32": {}, "f32-f16x3": {"DIFFPHORE_EDGE_X6": "0"}, "f32-exact": {"DIFFPHORE_NODE_F16": "0", "DIFFPHORE_EDGE_X6": "0"}}
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
-def test_configs4_full_100_step_schedule_vs_oracle(precision):
+@pytest.mark.parametrize("precision", ["f32", "f32-f16x3", "f32-exact", "bf16x3", "bf16"])
+def test_configs4_full_100_step_schedule_vs_oracle(precision, monkeypatch):
     """BASELINE configs[4] over its WHOLE calibrated schedule (100 reverse steps, /root/reference/src/utils/sampling.py:204-255 accumulates every
     step's error): 6 poses (3 samples of 2 target-fishing complexes), same start poses and pre-drawn noise for the HIP path and the fp64
     oracle, compared every 20 steps.  Prints the RMSD growth; asserts the per-precision bounds of FULL_RUN_BOUNDS at 20 and at 100 steps."""
@@ -104,7 +110,9 @@ def test_configs4_full_100_step_schedule_vs_oracle(precision):
     args = _args()
     noise = _start_and_noise(poses, [4000 + i for i in range(len(poses))], S_total)
     sd = weights.init_state_dict()
-    m = TensorProductScoreModel(device="cuda", precision=precision).load_state_dict(sd)
+    for k_, v_ in FP32_ARMS.get(precision, {}).items():          # which kernels the fp32 model's convs run on
+        monkeypatch.setenv(k_, v_)
+    m = TensorProductScoreModel(device="cuda", precision="f32" if precision in FP32_ARMS else precision).load_state_dict(sd)
     om = OracleScoreModel(sd, config.ModelConfig(), dtype=torch.float64, tables=load_tables())
     # ONE 100-step call each (the schedule's last step is special: dt = t); intermediate coordinates through the reference's own
     # `keep_update` bookkeeping on the HIP side (diffusion_utils.py:71-77: docked_poses per step) and the oracle's pos_trace
