@@ -17,6 +17,12 @@
 // DpWork.ll_node_max_atoms overrides it.
 #define DP_NODE_LL_MAX_ATOMS 32
 #endif
+#ifndef DP_NODE_LL_MAX_ATOMS_F16
+// ... with the fp32 node-side kernel.  The two-limb fp16 kernel (DP_PREC_F16X3, ~1.5x shorter per pass) keeps the ligand-ligand conv
+// node-side up to three 32-slot passes: 256 x 80 atoms 40.3k -> 41.6k pose-steps/s, the 15-45-atom virtual-screen batch 53.3k -> 55.6k
+// against the edge-side bf16x6 form (round 5, tools/gpu_ab_env.sh)
+#define DP_NODE_LL_MAX_ATOMS_F16 96
+#endif
 
 namespace dp {
 
@@ -663,7 +669,6 @@ __global__ void tor_head_kernel(DpBatch b, DpWeights w, DpWork k, float* __restr
 extern "C" {
 
 // node-side convs: two workgroups per node group (DpConvArgs.path_split) while one per group leaves half of the 256 CUs x 2 slots idle
-static int node_path_split_auto(int B, int slices) { return (long long)B * slices <= 256 ? 1 : 0; }
 
 static int dp_check_batch(const DpBatch* b) {
   if (!b || b->B <= 0) return DP_E_BADARG;
@@ -682,13 +687,21 @@ int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream) {
   return (int)hipGetLastError();
 }
 
+// Path split (two workgroups per 16-node group + one workgroup per conv, fp32 kernels only) for launches that cannot fill the chip.  With the
+// two-limb fp16 kernel available (8-node groups = twice the workgroups, ~1.5x shorter) the split only pays for the smallest batches
+// (profiles/r5_batch_sweep.csv, 30-atom ligands: 40 poses 0.96 -> 0.75 ms per step, 128 poses 1.84 -> 1.20 with the unsplit f16x3 launches; 8-20 poses
+// 0.68-0.71 either way)
+static int node_path_split_auto(int B, int slices, bool f16_avail) { return (long long)B * slices <= (f16_avail ? 48 : 256) ? 1 : 0; }
 // which formulation the convs of a forward take (shared by dp_forward and dp_forward_launch_of)
 static bool plan_node_side(const DpBatch* b, const DpWeights* w, const DpWork* k) {
   return dp_resolve_conv_algo(k->conv_algo, w->precision, b->B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
 }
 static bool plan_node_ll(const DpBatch* b, const DpWeights* w, const DpWork* k) {
+  // (the cap depends on which node-side kernel the ligand-side launch would run: the f16x3 one unless the launch takes the small-batch path split)
+  const bool f16 = w->precision == DP_PREC_F32 && k->node_f16 != 0 && w->lig_conv[0].w2h != nullptr && k->x_emb_bf != nullptr && k->ll_emb_bf != nullptr &&
+                   !(k->path_split == 1 || (k->path_split != 2 && node_path_split_auto(b->B, (b->max_nl + 15) / 16, true)));
   return plan_node_side(b, w, k) && w->lig_conv[0].w2n != nullptr && b->llp_ptr != nullptr && k->ll_pair_rad != nullptr &&
-         k->ll_pair_bond != nullptr && b->max_nl <= (k->ll_node_max_atoms > 0 ? k->ll_node_max_atoms : DP_NODE_LL_MAX_ATOMS);
+         k->ll_pair_bond != nullptr && b->max_nl <= (k->ll_node_max_atoms > 0 ? k->ll_node_max_atoms : (f16 ? DP_NODE_LL_MAX_ATOMS_F16 : DP_NODE_LL_MAX_ATOMS));
 }
 
 int dp_forward_launch_of(const DpBatch* b, const DpWeights* w, const DpWork* k, int32_t layer, int32_t conv, int32_t* first, int32_t* count,
@@ -742,8 +755,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   // node-side convs of an fp32 model at fp32 grade on the 16-bit matrix pipe (DP_PREC_F16X3, two fp16 limbs per operand) when the blob carries
   // those images; the kernel has no path-split / conv-split form, so launches that take the path split (small batches) stay on the fp32 kernel
   const int nb_ = dp_conv_node_max_nodes();
-  auto split_of = [&](int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B, slices_)); };
   const bool f16_ok = node_side && w->precision == DP_PREC_F32 && k->node_f16 != 0 && w->p2l_conv[0].w2h != nullptr && k->x_emb_bf != nullptr;
+  auto split_of = [&](int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B, slices_, f16_ok)); };
   const bool f16_lig = f16_ok && !split_of((b->max_nl + nb_ - 1) / nb_) && (!node_ll || (w->lig_conv[0].w2h != nullptr && k->ll_emb_bf != nullptr));
   const bool f16_ph = f16_ok && !split_of((b->max_np + nb_ - 1) / nb_);
   // the 16-bit images of the edge embeddings are written only for the convs that read them (DP_PREC_BF16 or DP_PREC_F16X3, node-side)
@@ -780,7 +793,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while (B * slices < 512 && slices < 8) ++slices;
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
-  auto node_path_split = [&](int B_, int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B_, slices_)); };
+  auto node_path_split = [&](int B_, int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B_, slices_, f16_ok)); };
   // the convs that stay edge-side in an fp32 model (phore-phore, torsion bonds) take the bf16x6 form of their radial contraction when the
   // blob carries it (DpConvW.w2x): same tolerances, 16x the matrix rate per product
   const bool edge_x6 = w->precision == DP_PREC_F32 && k->edge_bf16x6 != 0;

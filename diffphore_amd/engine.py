@@ -850,7 +850,10 @@ class Engine:
             self.enable_two_streams(1 if two == "graph" else 0)
         elif two == "auto":
             try:
-                self.enable_two_streams(0 if (pb.B < TWO_STREAM_MAX_POSES or ragged) else 1)
+                # (round 5: with the f16x3 node-side kernels - bound by instruction issue, not by the matrix pipe - the two sides of a layer overlap
+                #  at every size: 256 x 80-atom ligands 36.4k -> 40.6k pose-steps/s, 512 x 30 atoms 138.7k either way)
+                f16 = self.node_side_convs == "f16x3" and self.conv_algo == "node"
+                self.enable_two_streams(0 if (pb.B < TWO_STREAM_MAX_POSES or ragged or f16) else 1)
             except _lib.DiffPhoreLibraryError:          # an optimisation only: a single stream computes the same result
                 self._handles = None
         _lib.check(self.L.dp_prepare(C.byref(pb.struct), C.byref(model.struct), C.byref(self.ws.struct), _stream()), "dp_prepare")
@@ -874,11 +877,13 @@ class Engine:
 
     def path_split_on(self) -> bool:
         """whether the ligand-side node-side launches of this batch take the path split (dp_graph.hip: node_path_split_auto - two workgroups per
-        node group while B x groups <= 256); such launches run the exact-fp32 kernel even with DpWork.node_f16 = 1"""
+        node group while B x groups <= 256, <= 48 when the f16x3 kernel is available); such launches run the exact-fp32 kernel even with
+        DpWork.node_f16 = 1"""
         ps = int(self.ws.struct.path_split)
         if ps:
             return ps == 1
-        return self._ps_B * ((self._ps_nl + 15) // 16) <= 256
+        f16 = self.node_side_convs == "f16x3"
+        return self._ps_B * ((self._ps_nl + 15) // 16) <= (48 if f16 else 256)
 
     def launch_of(self, layer: int, conv: int):
         """(first, count, node_side) of the dp_forward launch that carries conv `conv` of interaction layer `layer` (conv numbering of
