@@ -593,7 +593,7 @@ def main():
                     tr5, tr5_src = measured_traffic(5, w2.B, prec_c, r2["algo"]) if world == 1 else (None, None)
                     rec["roofline"] = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel_ms": km, "traffic": tr5,
                                        "traffic_note": (f"HBM bytes per launch from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE), {tr5_src}: mostly scratch - the "
-                                                        "kernel parks 89-163 registers (128 fp32 accumulators + 64 hidden-vector registers of 256)") if tr5 is not None else None,
+                                                        "kernels park 138 / 242 / 214 registers (fused ligand-side launches of layers 1-3; cross pairs 69-100: tools/kernel_meta.py)") if tr5 is not None else None,
                                        "kernel": f"layer-{PROF_LAYER} ligand-side launch ({n5} conv(s)), bf16 operands / fp32 accumulate, node-side={bool(ns5)}",
                                        "achieved": wk["node_flops"] / (km * 1e-3) / 1e12, "frac": wk["node_flops"] / (km * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                        "issued_frac": wk["issued_flops"] / (km * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
@@ -643,7 +643,7 @@ def main():
                   "v_mfma_f32_16x16x32_f16, fp32 accumulate" if main["node_side_convs"] == "f16x3" else "exact fp32 MFMA")
             ed = ("bf16x6 split, ~2^-24 products, fp32 accumulate" if main["edge_side_convs"] != "f32" else "exact fp32 MFMA")
             dtype = (f"f32-grade (fp32 model held to the fp32 parity tolerances; node-side convs: {nd}; edge-side convs = phore-phore, torsion bonds "
-                     f"[, ligand-ligand above 32 atoms]: {ed}; exact-fp32-MFMA-everywhere arm: value_exact_fp32)")
+                     f"[, ligand-ligand above 96 atoms]: {ed}; exact-fp32-MFMA-everywhere arm: value_exact_fp32)")
         rank_rate = [p_ * a.steps / t_ for p_, t_ in zip(rank_poses, main["rank_seconds"])]
         out = {
             "metric": "poses/sec (samples x steps) on the reverse-diffusion hot path",
@@ -662,7 +662,7 @@ def main():
                        "node_side_convs_note": "what the node-side launches (ligand-ligand + cross convs: 21 per forward) run: 'f16x3' = the fp32-grade two-limb "
                                                "fp16 kernel (dp_conv_node_f16_impl.h; library default DpWork.node_f16 = 1, same parity tolerances as fp32: "
                                                "tests/test_conv_f16_gpu.py 2-4e-7 of max vs the fp64 oracle), 'f32' = v_mfma_f32_16x16x4_f32 (DIFFPHORE_NODE_F16=0)",
-                       "edge_side_convs_note": "what the convs that stay on the edge-side kernel (phore-phore, torsion bonds; ligand-ligand above 32 atoms) run: "
+                       "edge_side_convs_note": "what the convs that stay on the edge-side kernel (phore-phore, torsion bonds; ligand-ligand above 96 atoms, 32 with the fp32 node-side kernel) run: "
                                                "'bf16x6' = 3-way bf16 operand split, 6 cross products, fp32 accumulate (fp32-grade: same parity tolerances; the "
                                                "library default, DpWork.edge_bf16x6 = 1), 'f32' = exact fp32 MFMA (alt_runs[0] times that arm)",
                        "library": dict(_build_info()),

@@ -33,7 +33,7 @@
 
 #ifndef DPF_ABL     // timing ablations of THIS kernel (tools/build_variant.sh; results are wrong by construction): 1 no gathered-operand loads, 2 no SH-factor
 #define DPF_ABL 0   // reads, 3 no z arithmetic / limb extraction, 4 no GEMM-A MFMAs, 5 no T split / stores, 6 no T reads, 7 no GEMM-B MFMAs, 8 no W2 loads,
-#endif              // 9 no edge-embedding loads (GEMM1)
+#endif              // 9 no edge-embedding loads (GEMM1), 10 z built for every fourth node only (bound of a z build shared by the four waves)
 
 namespace dpf {
 using namespace dpn;
@@ -307,15 +307,24 @@ struct StageH {
           constexpr int SD = (VEC && NTERM == 3) ? 1 : 2;
           f32x4 sv[SD][NTERM][NT2];
           loadS(0, sv[0]);
+#if DPF_ABL == 10
+          u32x4 zh_keep[NTILE], zl_keep[NTILE];
+#endif
 #pragma unroll
           for (int nn = 0; nn < NBH; ++nn) {
             const int cur = SD == 2 ? (nn & 1) : 0;
             if constexpr (SD == 2) {
               if (nn + 1 < NBH) loadS(nn + 1, sv[(nn + 1) & 1]);
             }
+#if DPF_ABL == 10        // upper bound of a z build shared by the four waves: only every fourth node builds its z (the others reuse it)
+            static_assert(true, "");
+#endif
             u32x4 zh[NTILE], zl[NTILE];
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl) {
+#if DPF_ABL == 10
+              if ((nn & 3) != 0) { zh[tl] = zh_keep[tl]; zl[tl] = zl_keep[tl]; continue; }
+#endif
               zh[tl] = u32x4{0u, 0u, 0u, 0u};
               zl[tl] = u32x4{0u, 0u, 0u, 0u};
 #if DPF_ABL == 3
@@ -352,6 +361,12 @@ struct StageH {
                 }
               }
             }
+#if DPF_ABL == 10
+            if ((nn & 3) == 0) {
+#pragma unroll
+              for (int tl = 0; tl < NTILE; ++tl) { zh_keep[tl] = zh[tl]; zl_keep[tl] = zl[tl]; }
+            }
+#endif
             if constexpr (SD == 1) {
               __builtin_amdgcn_sched_barrier(0);
               if (nn + 1 < NBH) loadS(nn + 1, sv[0]);

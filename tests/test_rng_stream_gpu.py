@@ -239,15 +239,25 @@ def test_screen_stream_equals_one_call_and_keeps_two_batches_alive():
     assert worst < 2e-5 and all(r.shape == (NS, lib.sizes(i)[0], 3) for i, r in res.items())
 
 
-def test_screen_isolates_failing_units(monkeypatch):
-    """one bad ligand must not end a library run (the reference wraps every complex in try / except and retries SVD failures,
+@pytest.mark.parametrize("kernels", ["f32", "f16x3", "bf16"])
+def test_screen_isolates_failing_units(monkeypatch, kernels):
+    """(`kernels`: the node-side conv kernels the batch runs - the exact-fp32 ones (these 6-pose batches take the path split), the two-limb fp16
+    ones (path split off) or the bf16 model's.  ADVICE r4: the 16-bit kernels gathered the rows behind a pose's last node from the NEXT pose of
+    the batch; with a NaN unit next to a healthy one that leaked 0 x NaN into the healthy unit - their gathers are now limited to the pose.)
+    ADVICE r3: one bad ligand must not end a library run (the reference wraps every complex in try / except and retries SVD failures,
     src/inference.py:200-219).  A unit whose loader raises, a unit over the kernel limits and a unit whose Kabsch alignment can never
     succeed (non-finite coordinates: flagged on every retry) are reported as failures - exactly once each, with their reasons - while
     every other unit is delivered and equals the run of a clean library (the noise is keyed by seed and pose uid)."""
     from diffphore_amd import distributed as D
     lib = synthetic.ScreenLibrary(4, 8)
     args, NS = _args(), 3
-    m = _model()
+    if kernels == "f16x3":
+        monkeypatch.setenv("DIFFPHORE_PATH_SPLIT", "0")
+    if kernels == "bf16":
+        from diffphore_amd.score_model import TensorProductScoreModel
+        m = TensorProductScoreModel(device="cuda", precision="bf16").load_state_dict(weights.init_state_dict())
+    else:
+        m = _model()
     big = max(range(8), key=lambda i: lib.sizes(i)[0])                # the unit with the most atoms plays "over the limits"
     monkeypatch.setitem(D.LIMITS, "atoms", lib.sizes(big)[0] - 1)
     if any(lib.sizes(i)[0] > D.LIMITS["atoms"] for i in range(8) if i != big):

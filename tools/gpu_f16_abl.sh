@@ -3,6 +3,6 @@
 export PYTHONPATH=$PWD
 run() { python tools/bench_conv.py --algo node --prec f16x3 --kind 3 --mode p2l --iters 50 "$@" 2>&1 | tail -1 | python -c "import sys, json; print(round(json.loads(sys.stdin.read())['ms'], 4))"; }
 echo "base $(run)"
-for n in 1 2 3 4 5 6 7 8 9; do
+for n in 1 2 3 4 5 6 7 8 9 10; do
   [ -f build_abl/libfabl$n.so ] && echo "abl$n $(DIFFPHORE_LIB=build_abl/libfabl$n.so run)"
 done
