@@ -38,7 +38,7 @@ EDGE_SET = {LIG3: ("ll", "x", "x"), LIG2: ("x", "x"), PH2: ("x", "x"), "lig-lig"
 
 
 def short(name):
-    name = name.replace("void ", "").replace("dp::", "").replace("dpn::", "").replace("dpb::", "")
+    name = name.replace("void ", "").replace("dp::", "").replace("dpn::", "").replace("dpb::", "").replace("dpf::", "")
     return name.split("(")[0][:60]
 
 
