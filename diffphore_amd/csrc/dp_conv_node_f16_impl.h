@@ -642,7 +642,7 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
 }
 
 // every pass of one conv of the (possibly fused) launch; `hs` = 2^(S - w) of this conv
-template <int KIND, int MODE>
+template <int KIND, int MODE, bool HALFOK>
 __device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, int tid, float hs, float* s_T, float* s_S, float* s_X, float* s_inv,
                                          f32x4 (&acc)[n_acc4<KIND>()]) {
   const Wg r = wg_of<MODE>(a, grp.pose);
@@ -661,14 +661,20 @@ __device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, in
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w2n, (unsigned)w2h_quads<KIND>() * 16u);          // the conv's W2 image (GEMM-B's A fragments)
 #pragma unroll 1
   for (int et = 0; et < n_et; ++et) {
-    if (r.En - 32 * et <= 16) pass_f16<KIND, MODE, true>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
-    else pass_f16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
+    // HALFOK = false: the lean instantiation for launches whose poses never end on a short pass (FusedArgs.lean, from DpConvArgs.no_tail): half the
+    // code, fewer registers parked across it; on such a batch the two instantiations are bit-identical
+    if constexpr (HALFOK) {
+      if (r.En - 32 * et <= 16) pass_f16<KIND, MODE, true>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
+      else pass_f16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
+    } else {
+      pass_f16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
+    }
   }
 }
 
 __device__ __forceinline__ float w2_exponent(const DpConvArgs& a) { return *reinterpret_cast<const float*>(a.w2n); }
 
-template <int KIND, bool HAS_LL, int XMODE>
+template <int KIND, bool HAS_LL, int XMODE, bool HALFOK>
 __global__ __launch_bounds__(256, 2) void tp_conv_node_f16_kernel(FusedArgs fa) {
   __shared__ __attribute__((aligned(128))) float s_T[4 * TIMG_F + TDUM_B / 4];   // wave-private T images (fp16, hi | lo node slots) + the dummy column; reused for the reduction
   __shared__ __attribute__((aligned(16))) float s_S[NBH * SCOMP * 32];         // per-edge sh factors of the current pass (fp32)
@@ -687,11 +693,11 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_f16_kernel(FusedArgs fa) 
   float w_min = w2_exponent(fa.conv[0]);
   for (int k = 1; k < n_conv; ++k) w_min = fminf(w_min, w2_exponent(fa.conv[k]));
   const float s_exp = w_min + (float)A0;
-  if constexpr (HAS_LL) conv_f16<KIND, LL>(fa.conv[0], grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(fa.conv[0]))), s_T, s_S, s_X, s_inv, acc);
+  if constexpr (HAS_LL) conv_f16<KIND, LL, HALFOK>(fa.conv[0], grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(fa.conv[0]))), s_T, s_S, s_X, s_inv, acc);
 #pragma unroll 1
   for (int cx = 0; cx < fa.n_x; ++cx) {
     const DpConvArgs& a = fa.conv[(HAS_LL ? 1 : 0) + cx];
-    conv_f16<KIND, XMODE>(a, grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(a))), s_T, s_S, s_X, s_inv, acc);
+    conv_f16<KIND, XMODE, HALFOK>(a, grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(a))), s_T, s_S, s_X, s_inv, acc);
   }
   // ---- sum the four k-partials and the two limb halves of the node slots, un-scale, BatchNorm shift, residual stream ----------------------
   {
@@ -728,13 +734,17 @@ __global__ __launch_bounds__(256, 2) void tp_conv_node_f16_kernel(FusedArgs fa) 
   }
 }
 
-template <int KIND> int launch_f16(const FusedArgs& fa, int xmode, hipStream_t st) {
+template <int KIND, bool HALFOK> int launch_f16_h(const FusedArgs& fa, int xmode, hipStream_t st) {
   const DpConvArgs& a = fa.conv[0];
   const dim3 grid((unsigned)(a.B * a.slices * 2)), block(256);
-  if (fa.n_ll) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, true, DP_EDGES_P2L>), grid, block, 0, st, fa);
-  else if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_P2L>), grid, block, 0, st, fa);
-  else hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_L2P>), grid, block, 0, st, fa);
+  if (fa.n_ll) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, true, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
+  else if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
+  else hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_L2P, HALFOK>), grid, block, 0, st, fa);
   return (int)hipGetLastError();
+}
+// the lean instantiation when every conv of the launch carries DpConvArgs.no_tail (a hint: the general kernel is always correct)
+template <int KIND> int launch_f16(const FusedArgs& fa, int xmode, hipStream_t st) {
+  return fa.lean ? launch_f16_h<KIND, false>(fa, xmode, st) : launch_f16_h<KIND, true>(fa, xmode, st);
 }
 
 }  // namespace dpf

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--phase-split", type=int, default=0)
     ap.add_argument("--algo", default="edge", choices=["edge", "node"])
     ap.add_argument("--path-split", type=int, default=0, help="node-side: two workgroups per node group, half of the out slots each")
+    ap.add_argument("--no-tail", type=int, default=0, help="DpConvArgs.no_tail: 1 = the lean node-side instantiation (no pose ends on a pass of <= 16 slots)")
     ap.add_argument("--prof", action="store_true", help="print the cycle-stamp breakdown (library built with -DDP_PROF)")
     ap.add_argument("--lib", default=None, help="alternative libdiffphore_hip.so (ablation builds)")
     a = ap.parse_args()
@@ -80,6 +81,7 @@ def main():
         args.algo, args.w1n, args.w2n = _lib.ALGO_NODE, keep["w1n"].data_ptr(), keep["w2n"].data_ptr()
         args.slices = (args.max_scatter + nb - 1) // nb
         args.path_split = a.path_split
+        args.no_tail = a.no_tail
     args.bn_scale, args.bn_shift = keep["bn_scale"].data_ptr(), keep["bn_shift"].data_ptr()
     args.out, args.out_stride, args.accumulate = out.data_ptr(), dims["d_out"], 0
     L = _lib.lib()
