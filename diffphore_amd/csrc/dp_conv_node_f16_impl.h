@@ -44,7 +44,6 @@ using dpb::lds_ptr;
 using dpb::XSrc;
 using dpb::uni;
 using dpb::make_rsrc;
-using dpb::relu1;
 using dpb::t_col;
 using dpb::term_sign;
 using dpb::st_count;
@@ -104,6 +103,9 @@ template <int KIND> constexpr int w2h_path_off(int p) {             // in 16-byt
 template <int KIND> constexpr int w2h_quads() { return w2h_path_off<KIND>(Spec<KIND>::NPATH); }
 constexpr int W1H_QUADS = 3 * 2 * 4 * 64;                            // three images (edge embedding, attr1, attr2) x 2 limbs x 4 waves
 
+// ReLU as ONE instruction: v_med3_f32 x, 0, FLT_MAX (with +inf as the upper bound this toolchain folds the median into a maximum and emits
+// v_max x, x (canonicalise) + v_max x, 0 for a value that comes out of an MFMA)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 3.40282347e38f); }
 __device__ __forceinline__ unsigned pkh(float lo, float hi) {       // v_cvt_pk_f16_f32 (round to nearest even)
   const f16x2 v = __builtin_convertvector((f32x2){lo, hi}, f16x2);
   return __builtin_bit_cast(unsigned, v);
