@@ -591,18 +591,22 @@ def test_configs0_real_example_inputs(golden_dir, monkeypatch):
         assert np.abs(pos[0] - pos[1]).max() > 1e-2
 
 
-@pytest.mark.parametrize("algo", ["node", "edge"])
+@pytest.mark.parametrize("algo", ["node", "node-f16x3", "edge"])
 def test_fuzz_shapes_soak(algo, monkeypatch):
     """tools/fuzz_shapes.py as a test: random ragged batches (ligands of 2-70 atoms = up to three ligand-ligand passes of the node-side
     kernel, pharmacophores of 7-110 nodes = up to four cross passes) through the HIP forward vs the fp64 oracle.  A batch may deviate
-    only if the oracle recorded a decision margin within fp32 rounding for one of its poses (a tie: either branch is legitimate)."""
+    only if the oracle recorded a decision margin within fp32 rounding for one of its poses (a tie: either branch is legitimate).
+    `node-f16x3`: these 1-5-pose batches would take the small-batch path split (exact-fp32 node-side kernels); with the split switched off they
+    run the two-limb fp16 kernels that large batches run - same bound."""
     import importlib.util
     import os
     import types
     spec = importlib.util.spec_from_file_location("fuzz_shapes", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_shapes.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo)
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", algo.split("-")[0])
+    if algo == "node-f16x3":
+        monkeypatch.setenv("DIFFPHORE_PATH_SPLIT", "0")
     worst, findings = fz.run(types.SimpleNamespace(batches=8, seed=1234, precision="f32", only=-1))
     assert not findings, findings
     assert max(worst.values()) < 3e-4, worst
