@@ -404,7 +404,7 @@ def main():
         for prec, algo, x6, f16, what in (
                 ("f32", None, "0", "0", "exact fp32 MFMA EVERYWHERE (DIFFPHORE_NODE_F16=0 DIFFPHORE_EDGE_X6=0: node-side convs on v_mfma_f32_16x16x4_f32, the "
                                         "edge-side convs - phore-phore, torsion bonds - on the fp32 pipe too)"),
-                ("f32", None, None, "0", "round 4's default: node-side convs exact fp32 MFMA (DIFFPHORE_NODE_F16=0), edge-side convs bf16x6"),
+                ("f32", None, None, "0", "round 4's node-side kernels: node-side convs exact fp32 MFMA (DIFFPHORE_NODE_F16=0), edge-side convs as in the headline"),
                 ("f32", "edge" if algo_used != "edge" else "node", None, None, "fp32 model, the other conv formulation"),
                 ("bf16x9", None, None, None, "3-way bf16 split of both operands, all 9 cross products: every fp32 x fp32 product exact, fp32 accumulate"),
                 ("bf16x6", None, None, None, "same split, the 6 largest cross products (~2^-24 relative); passes the same parity tolerances"),
@@ -641,7 +641,8 @@ def main():
         if precision == "f32" and (main["edge_side_convs"] != "f32" or main["node_side_convs"] != "f32"):
             nd = ("f16x3 = every GEMM operand as two fp16 limbs (22 significand bits, exact power-of-two scales), limb cross products on "
                   "v_mfma_f32_16x16x32_f16, fp32 accumulate" if main["node_side_convs"] == "f16x3" else "exact fp32 MFMA")
-            ed = ("bf16x6 split, ~2^-24 products, fp32 accumulate" if main["edge_side_convs"] != "f32" else "exact fp32 MFMA")
+            ed = ("f16x3 = both operands of the radial contraction as two fp16 limbs, 3 cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate"
+                  if main["edge_side_convs"] == "f16x3" else (main["edge_side_convs"] + " split" if main["edge_side_convs"] != "f32" else "exact fp32 MFMA"))
             dtype = (f"f32-grade (fp32 model held to the fp32 parity tolerances; node-side convs: {nd}; edge-side convs = phore-phore, torsion bonds "
                      f"[, ligand-ligand above 96 atoms]: {ed}; exact-fp32-MFMA-everywhere arm: value_exact_fp32)")
         rank_rate = [p_ * a.steps / t_ for p_, t_ in zip(rank_poses, main["rank_seconds"])]
@@ -663,8 +664,8 @@ def main():
                                                "fp16 kernel (dp_conv_node_f16_impl.h; library default DpWork.node_f16 = 1, same parity tolerances as fp32: "
                                                "tests/test_conv_f16_gpu.py 2-4e-7 of max vs the fp64 oracle), 'f32' = v_mfma_f32_16x16x4_f32 (DIFFPHORE_NODE_F16=0)",
                        "edge_side_convs_note": "what the convs that stay on the edge-side kernel (phore-phore, torsion bonds; ligand-ligand above 96 atoms, 32 with the fp32 node-side kernel) run: "
-                                               "'bf16x6' = 3-way bf16 operand split, 6 cross products, fp32 accumulate (fp32-grade: same parity tolerances; the "
-                                               "library default, DpWork.edge_bf16x6 = 1), 'f32' = exact fp32 MFMA (alt_runs[0] times that arm)",
+                                               "'f16x3' = 2-way fp16 operand split, 3 cross products, fp32 accumulate (fp32-grade: same parity tolerances; the library default, "
+                                               "DpWork.edge_bf16x6 = 1 - the 3-way bf16 split 'bf16x6' until round 4), 'f32' = exact fp32 MFMA (alt_runs[0] times that arm)",
                        "library": dict(_build_info()),
                        "ranks": {"pose_steps_per_s": rank_rate, "seconds": main["rank_seconds"], "poses": rank_poses,
                                  "imbalance_max_over_mean": (max(main["rank_seconds"]) / (sum(main["rank_seconds"]) / len(main["rank_seconds"]))),

@@ -24,6 +24,7 @@
 
 #include "../../include/diffphore_amd.h"
 #include "dp_spec.h"
+#include "dp_f16.h"
 
 #ifndef DP_ABLATE
 #define DP_ABLATE 0
@@ -685,9 +686,55 @@ template <int KIND, int NS> void pack_w2_bf16(const float* fc3_w, const float* f
       }
 }
 
+// DP_PREC_F16X3 on this kernel: the tiles of pack_w2_bf16<KIND, 2> with fp16 parts of W2 * 2^w (w = the largest exponent that keeps every
+// element <= 2048; exact) and one trailing quad whose float[0] is w.  The kernel never reads the trailer: the host multiplies the conv's BatchNorm
+// scale by 2^-w (the contraction, the segmented mean and the scale are linear in W2), diffphore_amd/packing.py.
+template <int KIND> void pack_w2_f16(const float* fc3_w, const float* fc3_b, unsigned short* out) {
+  using G = Geo<KIND>;
+  using S = Spec<KIND>;
+  constexpr int NS = 2;
+  const size_t total = (size_t)G::NT * TILE_QUADS<KIND, NS> * 8 + 8;
+  for (size_t i = 0; i < total; ++i) out[i] = 0;
+  auto value = [&](int tile, int b, int lane, int j) -> double {
+    const int c = lane & 31, half = lane >> 5;
+    const int r = (c & 3) + 4 * (c >> 3), chalf = (c >> 2) & 1;
+    const Triple tr = triple_at<KIND>(tile * 16 + r);
+    if (!tr.valid) return 0.0;
+    const PathC& p = S::P[tr.p];
+    const int u = chalf * (p.mul_in / 2) + tr.q;
+    const int widx = p.w_off + u * p.mul_out + tr.w;
+    const double scale = __builtin_sqrt((double)(2 * (d_out_of(p.ztype) == 3 ? 1 : 0) + 1) / (double)p.fan_in) * cg_const(p.ztype);
+    const int unit = unit_of_row<KIND>(hid_row_b(b, half, j));
+    if (unit >= 0 && unit < S::HID) return scale * (double)fc3_w[widx * S::HID + unit];
+    if (unit == S::HID) return scale * (double)fc3_b[widx];
+    return 0.0;
+  };
+  double mx = 0.0;
+  for (int tile = 0; tile < G::NT; ++tile)
+    for (int b = 0; b < NKB<KIND>; ++b)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) { const double v = __builtin_fabs(value(tile, b, lane, j)); if (v > mx) mx = v; }
+  const int wexp = f16_image_exponent(mx);
+  const double sc = __builtin_ldexp(1.0, wexp);
+  for (int tile = 0; tile < G::NT; ++tile)
+    for (int b = 0; b < NKB<KIND>; ++b)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          unsigned short hi, lo;
+          f16_split((float)(sc * value(tile, b, lane, j)), hi, lo);
+          out[((size_t)tile * TILE_QUADS<KIND, NS> + ((size_t)b * NS + 0) * 64 + lane) * 8 + j] = hi;
+          out[((size_t)tile * TILE_QUADS<KIND, NS> + ((size_t)b * NS + 1) * 64 + lane) * 8 + j] = lo;
+        }
+  float* trailer = reinterpret_cast<float*>(out + (size_t)G::NT * TILE_QUADS<KIND, NS> * 8);
+  trailer[0] = (float)wexp;
+}
+
 template <int KIND, int NS> struct HidB { bf16x8 v[NKB<KIND>][NS]; };
 
-template <int KIND, int NS>
+// F16 (DP_PREC_F16X3 on this kernel, round 5): the parts are fp16 (11 significand bits each: two parts = 22 bits, fp32-grade with 3 cross
+// products instead of the 6 of the 3-way bf16 split).  The hidden activations are relu outputs of O(1): no scale needed on this side; the packed
+// weights carry 2^w (pack_w2_f16), which the host folds into the conv's BatchNorm scale (DpConvW.bn_scale_x)
+template <int KIND, int NS, bool F16 = false>
 __device__ __forceinline__ void split_hidden(const float (&hid)[32], HidB<KIND, NS>& hb) {
 #pragma unroll
   for (int b = 0; b < NKB<KIND>; ++b) {
@@ -697,9 +744,15 @@ __device__ __forceinline__ void split_hidden(const float (&hid)[32], HidB<KIND, 
       float rem = hid[8 * b + j];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const unsigned short h = f32_to_bf16_rne(rem);
-        rem -= bf16_to_f32(h);
-        q[s][j] = h;
+        if constexpr (F16) {
+          const _Float16 h = (_Float16)rem;               // round to nearest even
+          rem -= (float)h;
+          q[s][j] = __builtin_bit_cast(unsigned short, h);
+        } else {
+          const unsigned short h = f32_to_bf16_rne(rem);
+          rem -= bf16_to_f32(h);
+          q[s][j] = h;
+        }
       }
     }
 #pragma unroll
@@ -746,7 +799,12 @@ __device__ __forceinline__ void lds_read_q(bf16x8& dst, unsigned addr, int off) 
 template <int N> __device__ __forceinline__ void lds_landed(bf16x8& w) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(N)); }
 
 template <int NS> constexpr int WREGS = NS == 1 ? 2 : NS;      // operand registers of the pipe (NS = 1: two, so that one read stays in flight)
-template <int KIND, int NS, int B, bool FULL = false>      // FULL (NS == 3 only): all 9 cross products = exact fp32 products
+typedef _Float16 f16x8_e __attribute__((ext_vector_type(8)));
+template <bool F16> __device__ __forceinline__ f32x16 mma32(bf16x8 a, bf16x8 b, f32x16 c) {      // the same registers read as bf16 or as fp16 operands
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_e, a), __builtin_bit_cast(f16x8_e, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int KIND, int NS, int B, bool FULL = false, bool F16 = false>      // FULL (NS == 3 only): all 9 cross products = exact fp32 products
 struct OperandPipe {
   static __device__ __forceinline__ void run(unsigned la, bf16x8 (&W)[WREGS<NS>], const HidB<KIND, NS>& hb, f32x16& D) {
     constexpr int NB = NKB<KIND>;
@@ -758,9 +816,9 @@ struct OperandPipe {
           if constexpr (NB > 1) lds_read_q(W[1], la, 1024);
         }
         lds_landed<(B + 1 < NB) ? 1 : 0>(W[B & 1]);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[B & 1], hb.v[B][0], D, 0, 0, 0);
+        D = mma32<F16>(W[B & 1], hb.v[B][0], D);
         if constexpr (B + 2 < NB) lds_read_q(W[B & 1], la, (B + 2) * 1024);
-        OperandPipe<KIND, NS, B + 1, FULL>::run(la, W, hb, D);
+        OperandPipe<KIND, NS, B + 1, FULL, F16>::run(la, W, hb, D);
       }
     } else if constexpr (B < NB) {
       constexpr bool more = B + 1 < NB;
@@ -772,22 +830,22 @@ struct OperandPipe {
       if constexpr (NS == 3) {
         lds_landed<NS - 1>(W[2]);
         if constexpr (FULL) {
-          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[B][2], D, 0, 0, 0);
-          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[B][1], D, 0, 0, 0);
+          D = mma32<F16>(W[2], hb.v[B][2], D);
+          D = mma32<F16>(W[2], hb.v[B][1], D);
         }
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], hb.v[B][0], D, 0, 0, 0);
+        D = mma32<F16>(W[2], hb.v[B][0], D);
         bf16x8 n2;
         if constexpr (more) lds_read_q(n2, la, ((B + 1) * NS + 2) * 1024);
         lds_landed<more ? NS - 1 : 1>(W[1]);
-        if constexpr (FULL) D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][2], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][1], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][0], D, 0, 0, 0);
+        if constexpr (FULL) D = mma32<F16>(W[1], hb.v[B][2], D);
+        D = mma32<F16>(W[1], hb.v[B][1], D);
+        D = mma32<F16>(W[1], hb.v[B][0], D);
         bf16x8 n1;
         if constexpr (more) lds_read_q(n1, la, ((B + 1) * NS + 1) * 1024);
         lds_landed<more ? NS - 1 : 0>(W[0]);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][2], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][1], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][0], D, 0, 0, 0);
+        D = mma32<F16>(W[0], hb.v[B][2], D);
+        D = mma32<F16>(W[0], hb.v[B][1], D);
+        D = mma32<F16>(W[0], hb.v[B][0], D);
         if constexpr (more) {
           lds_read_q(W[0], la, ((B + 1) * NS + 0) * 1024);
           W[2] = n2;
@@ -795,18 +853,18 @@ struct OperandPipe {
         }
       } else {
         lds_landed<NS - 1>(W[1]);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], hb.v[B][0], D, 0, 0, 0);
+        D = mma32<F16>(W[1], hb.v[B][0], D);
         bf16x8 n1;
         if constexpr (more) lds_read_q(n1, la, ((B + 1) * NS + 1) * 1024);
         lds_landed<more ? NS - 1 : 0>(W[0]);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][1], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], hb.v[B][0], D, 0, 0, 0);
+        D = mma32<F16>(W[0], hb.v[B][1], D);
+        D = mma32<F16>(W[0], hb.v[B][0], D);
         if constexpr (more) {
           lds_read_q(W[0], la, ((B + 1) * NS + 0) * 1024);
           W[1] = n1;
         }
       }
-      OperandPipe<KIND, NS, B + 1, FULL>::run(la, W, hb, D);
+      OperandPipe<KIND, NS, B + 1, FULL, F16>::run(la, W, hb, D);
     }
   }
 };
@@ -814,7 +872,7 @@ struct OperandPipe {
 // Stage TILE of the split-bf16 pipeline.  The packed weights stream L2 -> LDS through a RING-deep ring filled by LDS-DMA
 // RING-1 tiles ahead (an L2 round trip under load is ~2k cycles, longer than one bf16 tile), so a tile costs:
 //   issue DMA(tile+RING-1) | ds_read operands | 12 or 24 bf16 MFMAs | VALU contraction | counted vmcnt | s_barrier.
-template <int KIND, int NS, int TILE, bool FULL = false>
+template <int KIND, int NS, int TILE, bool FULL = false, bool F16 = false>
 struct StageB {
   static __device__ __forceinline__ void run(gptrq w2p, int wave, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
                                              const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
@@ -856,13 +914,13 @@ struct StageB {
 #pragma unroll
       for (int b = 0; b < NKB<KIND>; ++b) {
         if constexpr (NS == 3) {
-          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][2], hb.v[b][0], D, 0, 0, 0);
-          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][1], hb.v[b][1], D, 0, 0, 0);
-          D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][0], hb.v[b][2], D, 0, 0, 0);
+          D = mma32<F16>(hb.v[b][2], hb.v[b][0], D);
+          D = mma32<F16>(hb.v[b][1], hb.v[b][1], D);
+          D = mma32<F16>(hb.v[b][0], hb.v[b][2], D);
         }
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][1], hb.v[b][0], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][0], hb.v[b][1], D, 0, 0, 0);
-        D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb.v[b][0], hb.v[b][0], D, 0, 0, 0);
+        D = mma32<F16>(hb.v[b][1], hb.v[b][0], D);
+        D = mma32<F16>(hb.v[b][0], hb.v[b][1], D);
+        D = mma32<F16>(hb.v[b][0], hb.v[b][0], D);
       }
 #else
       {
@@ -871,7 +929,7 @@ struct StageB {
         // i.e. a full L2 round trip for the tile that was JUST requested (measured: 0.88 -> see profiles/r1_conv_ablation.md).
         bf16x8 W[WREGS<NS>];
         const unsigned la = lds_w + (TILE % R) * NQ * 16;
-        OperandPipe<KIND, NS, 0, FULL>::run(la, W, hb, D);
+        OperandPipe<KIND, NS, 0, FULL, F16>::run(la, W, hb, D);
       }
 #endif
 #endif
@@ -888,7 +946,7 @@ struct StageB {
         __builtin_amdgcn_s_barrier();
       }
       __builtin_amdgcn_sched_barrier(0);
-      StageB<KIND, NS, TILE + 1, FULL>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local);
+      StageB<KIND, NS, TILE + 1, FULL, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local);
     } else {
       constexpr int PHL = n_tiles_phase<KIND>(1) > 0 ? 1 : 0;
       PROF_MARK(5);
@@ -904,7 +962,7 @@ struct StageB {
   }
 };
 
-template <int KIND, int NS, bool FULL = false>
+template <int KIND, int NS, bool FULL = false, bool F16 = false>
 __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArgs a) {
   using S = Spec<KIND>;
   using G = Geo<KIND>;
@@ -930,7 +988,7 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
     {
       float hid[32];
       gemm1_hidden<KIND>(a, e, lane, hid);
-      split_hidden<KIND, NS>(hid, hb);
+      split_hidden<KIND, NS, F16>(hid, hb);
     }
     PROF_MARK(0);
     load_tp_operands<KIND>(a, e, half, xr, sh, M);
@@ -949,7 +1007,7 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     PROF_MARK(2);
-    StageB<KIND, NS, 0, FULL>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local);
+    StageB<KIND, NS, 0, FULL, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local);
   }
   __syncthreads();
   conv_epilogue<KIND, WAVES_B * 64>(a, r, s_acc);
@@ -966,6 +1024,7 @@ template <int KIND> int launch(const DpConvArgs& a_in, hipStream_t st) {
   else if (a.precision == DP_PREC_BF16X3) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2>), grid, dim3(WAVES_B * 64), 0, st, a);
   else if (a.precision == DP_PREC_BF16X9) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 3, true>), grid, dim3(WAVES_B * 64), 0, st, a);
   else if (a.precision == DP_PREC_BF16) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 1>), grid, dim3(WAVES_B * 64), 0, st, a);
+  else if (a.precision == DP_PREC_F16X3) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2, false, true>), grid, dim3(WAVES_B * 64), 0, st, a);
   else return DP_E_BADARG;
   return (int)hipGetLastError();
 }
@@ -975,6 +1034,7 @@ template <int KIND> int w2p_floats(int prec) {
   if (prec == DP_PREC_BF16X6 || prec == DP_PREC_BF16X9) return Geo<KIND>::NT * TILE_QUADS<KIND, 3> * 4;
   if (prec == DP_PREC_BF16X3) return Geo<KIND>::NT * TILE_QUADS<KIND, 2> * 4;
   if (prec == DP_PREC_BF16) return Geo<KIND>::NT * TILE_QUADS<KIND, 1> * 4;
+  if (prec == DP_PREC_F16X3) return Geo<KIND>::NT * TILE_QUADS<KIND, 2> * 4 + 4;      // + one trailing quad: float[0] = the image's exponent w
   return DP_E_BADARG;
 }
 
@@ -1022,7 +1082,7 @@ int dp_conv_w2p_floats(int32_t kind, int32_t precision) {
 int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, const float* fc0_b, const float* fc3_w,
                          const float* fc3_b, float* w1p, float* w2p) {
   if (!fc0_w || !fc0_b || !fc3_w || !fc3_b || !w1p || !w2p) return DP_E_BADARG;
-  if (precision != DP_PREC_F32 && precision != DP_PREC_BF16X6 && precision != DP_PREC_BF16X3 && precision != DP_PREC_BF16X9 && precision != DP_PREC_BF16)
+  if (precision != DP_PREC_F32 && precision != DP_PREC_BF16X6 && precision != DP_PREC_BF16X3 && precision != DP_PREC_BF16X9 && precision != DP_PREC_BF16 && precision != DP_PREC_F16X3)
     return DP_E_BADARG;
   switch (kind) {
 #define DP_CASE(K)                                                                                            \
@@ -1031,6 +1091,7 @@ int dp_pack_conv_weights(int32_t kind, int32_t precision, const float* fc0_w, co
     if (precision == DP_PREC_F32) dp::pack_w2<K>(fc3_w, fc3_b, w2p);                                          \
     else if (precision == DP_PREC_BF16X6 || precision == DP_PREC_BF16X9) dp::pack_w2_bf16<K, 3>(fc3_w, fc3_b, (unsigned short*)w2p);         \
     else if (precision == DP_PREC_BF16) dp::pack_w2_bf16<K, 1>(fc3_w, fc3_b, (unsigned short*)w2p);           \
+    else if (precision == DP_PREC_F16X3) dp::pack_w2_f16<K>(fc3_w, fc3_b, (unsigned short*)w2p);              \
     else dp::pack_w2_bf16<K, 2>(fc3_w, fc3_b, (unsigned short*)w2p);                                          \
     return DP_OK;
     DP_CASE(0) DP_CASE(1) DP_CASE(2) DP_CASE(3) DP_CASE(4) DP_CASE(5)

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "dp_conv_node_f16_impl.h"
+#include "dp_f16.h"
 
 
 namespace dpn {
@@ -137,48 +138,6 @@ __global__ void edge_emb_bf16_kernel(const float* __restrict__ emb, int n_rows, 
 }
 
 // ---- DP_PREC_F16X3 (dp_conv_node_f16_impl.h): two-limb fp16 MFMA fragments, exact power-of-two scales ------------------------------------
-static inline unsigned short f16_rne(float x) {                     // fp32 -> fp16 bits, round to nearest even (overflow -> inf, subnormals kept)
-  unsigned int u;
-  memcpy(&u, &x, 4);
-  const unsigned int sign = (u >> 16) & 0x8000u;
-  u &= 0x7fffffffu;
-  if (u >= 0x7f800000u) return (unsigned short)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
-  if (u >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);    // >= 65520 rounds to inf
-  if (u < 0x38800000u) {                                            // below 2^-14: fp16 subnormal (or zero)
-    if (u < 0x33000000u) return (unsigned short)sign;               // < 2^-25 rounds to zero
-    const int e = (int)(u >> 23);                                   // biased exponent, 102..112
-    unsigned int m = (u & 0x7fffffu) | 0x800000u;                   // 24-bit significand
-    const int shift = 126 - e;                                      // bits to drop so that the result counts units of 2^-24
-    const unsigned int halfway = 1u << (shift - 1), rest = m & ((1u << shift) - 1u);
-    m >>= shift;
-    if (rest > halfway || (rest == halfway && (m & 1u))) ++m;
-    return (unsigned short)(sign | m);
-  }
-  unsigned int r = u - 0x38000000u;                                 // re-bias the exponent (127 -> 15)
-  const unsigned int rest = r & 0x1fffu;
-  r >>= 13;
-  if (rest > 0x1000u || (rest == 0x1000u && (r & 1u))) ++r;
-  return (unsigned short)(sign | r);
-}
-static inline float f16_to_f32(unsigned short h) {
-  const unsigned int sign = ((unsigned int)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
-  float f;
-  if (e == 0) {
-    f = (float)m * 5.9604644775390625e-8f;                          // m * 2^-24
-    unsigned int u;
-    memcpy(&u, &f, 4);
-    u |= sign;
-    memcpy(&f, &u, 4);
-    return f;
-  }
-  const unsigned int u = sign | (e == 31 ? 0x7f800000u : ((e + 112u) << 23)) | (m << 13);
-  memcpy(&f, &u, 4);
-  return f;
-}
-static inline void f16_split(float v, unsigned short& hi, unsigned short& lo) {
-  hi = f16_rne(v);
-  lo = f16_rne(v - f16_to_f32(hi));
-}
 // first layer: three B-operand images x two limbs per wave q, as pack_w1b, stored as 16 W1 (dpf::W1_SCALE; relu commutes with the scale, the kernel
 // divides the hidden vectors by it); the flag row is dpf::FLAG_W: [img][limb][q][lane][8]
 template <int KIND> void pack_w1h(const float* fc0_w, const float* fc0_b, unsigned short* w1h) {
@@ -216,12 +175,7 @@ template <int KIND> void pack_w2h(const float* fc3_w, const float* fc3_b, const 
     for (int u = 0; u < S::P[p].mul_in; ++u)
       for (int w = 0; w < S::P[p].mul_out; ++w)
         for (int k = 0; k <= HIDN; ++k) { const double v = __builtin_fabs(value(p, u, w, k)); if (v > mx) mx = v; }
-  int wexp = 0;
-  if (mx > 0.0 && mx < 1e30) {
-    wexp = 11 - (int)__builtin_ceil(__builtin_log2(mx));            // mx * 2^wexp in (1024, 2048]
-    if (wexp > 40) wexp = 40;
-    if (wexp < -40) wexp = -40;
-  }
+  const int wexp = f16_image_exponent(mx);
   const double sc = __builtin_ldexp(1.0, wexp);
   float* hdr = reinterpret_cast<float*>(w2h);
   for (int i = 0; i < dpf::HDR_QUADS * 4; ++i) hdr[i] = 0.f;

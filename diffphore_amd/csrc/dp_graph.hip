@@ -794,8 +794,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
   auto node_path_split = [&](int B_, int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B_, slices_, f16_ok)); };
-  // the convs that stay edge-side in an fp32 model (phore-phore, torsion bonds) take the bf16x6 form of their radial contraction when the
-  // blob carries it (DpConvW.w2x): same tolerances, 16x the matrix rate per product
+  // the convs that stay edge-side in an fp32 model (phore-phore, torsion bonds) take the two-limb fp16 form of their radial contraction when the
+  // blob carries it (DpConvW.w2x / bn_scale_x; until round 4: the 3-way bf16 split): same tolerances, 16x the matrix rate per product
   const bool edge_x6 = w->precision == DP_PREC_F32 && k->edge_bf16x6 != 0;
   int slices_x6 = 1;
   {
@@ -860,7 +860,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.edge_scat = k->ll_src; c.gather_tab = hl; c.attr1_tab = hl; c.attr2_tab = hl; c.edge_emb = k->ll_emb; c.edge_sh = k->ll_sh;
       c.w1p = w->lig_conv[l].w1p; c.w2p = w->lig_conv[l].w2p; c.bn_scale = w->lig_conv[l].bn_scale; c.bn_shift = w->lig_conv[l].bn_shift;
       c.out = hl2; c.accumulate = 0; c.resid = hl; c.resid_width = din;
-      if (!node_ll && edge_x6 && w->lig_conv[l].w2x) { c.precision = DP_PREC_BF16X6; c.w2p = w->lig_conv[l].w2x; c.slices = slices_x6; c.phase_split = 0; }
+      if (!node_ll && edge_x6 && w->lig_conv[l].w2x && w->lig_conv[l].bn_scale_x) { c.precision = DP_PREC_F16X3; c.w2p = w->lig_conv[l].w2x; c.bn_scale = w->lig_conv[l].bn_scale_x; c.slices = slices_x6; c.phase_split = 0; }
       if (node_ll) {
         c.algo = DP_ALGO_NODE; c.mode = DP_EDGES_LLPAIR; c.w1n = w->lig_conv[l].w1n; c.w2n = w->lig_conv[l].w2n; c.slices = slices_pl; c.phase_split = 0;
         c.precision = w->precision; c.edge_emb_bf = k->ll_emb_bf; c.emb_flag_row = b->ll_cap;
@@ -902,7 +902,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_scat = b->pp_src; c.gather_tab = hp; c.attr1_tab = hp; c.attr2_tab = hp; c.edge_emb = k->pp_emb; c.edge_sh = k->pp_sh;
         c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
-        if (edge_x6 && w->ph_conv[l].w2x) { c.precision = DP_PREC_BF16X6; c.w2p = w->ph_conv[l].w2x; c.slices = slices_x6; c.phase_split = 0; }
+        if (edge_x6 && w->ph_conv[l].w2x && w->ph_conv[l].bn_scale_x) { c.precision = DP_PREC_F16X3; c.w2p = w->ph_conv[l].w2x; c.bn_scale = w->ph_conv[l].bn_scale_x; c.slices = slices_x6; c.phase_split = 0; }
         if ((rc = timed(c, l, 3, sp_))) return fail(rc);
       }
       DpConvArgs phc[2];
@@ -958,8 +958,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.attr_swap = 1; c.edge_emb = k->t_emb; c.edge_sh = k->t_sh; c.sh_stride = 7;
     c.w1p = w->tor_conv.w1p; c.w2p = w->tor_conv.w2p; c.bn_scale = w->tor_conv.bn_scale; c.bn_shift = w->tor_conv.bn_shift;
     c.out = k->t_q; c.out_stride = 40;
-    if (edge_x6 && w->tor_conv.w2x) {
-      c.precision = DP_PREC_BF16X6; c.w2p = w->tor_conv.w2x;
+    if (edge_x6 && w->tor_conv.w2x && w->tor_conv.bn_scale_x) {
+      c.precision = DP_PREC_F16X3; c.w2p = w->tor_conv.w2x; c.bn_scale = w->tor_conv.bn_scale_x;
       c.slices = 1;
       while ((b->max_t + c.slices - 1) / c.slices > dp_conv_max_nodes(DP_PREC_BF16X6)) ++c.slices;
     }

@@ -145,7 +145,8 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
       }
       if (((f == 1 && l < 3) || f == 0) && precision == DP_PREC_F32) {     // phore-phore stays edge-side, ligand-ligand goes edge-side for large
                                                                             // ligands: their second layer for the bf16 pipe as well (DpConvW.w2x)
-        snprintf(nm, sizeof(nm), "%s.%d.w2x", FAMS[f], l); s.add(nm, dp_conv_w2p_floats(l, DP_PREC_BF16X6));
+        snprintf(nm, sizeof(nm), "%s.%d.w2x", FAMS[f], l); s.add(nm, dp_conv_w2p_floats(l, DP_PREC_F16X3));
+        snprintf(nm, sizeof(nm), "%s.%d.bnx", FAMS[f], l); s.add(nm, D_OUT_KIND[l]);      // bn_scale * 2^-w of that image (DpConvW.bn_scale_x)
       }
     }
   static const char* const heads[2] = {"final_conv", "tor_conv"};
@@ -155,7 +156,10 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
     snprintf(nm, sizeof(nm), "%s.w2p", heads[h]); s.add(nm, dp_conv_w2p_floats(kind, precision));
     snprintf(nm, sizeof(nm), "%s.bn_scale", heads[h]); s.add(nm, D_OUT_KIND[kind]);
     snprintf(nm, sizeof(nm), "%s.bn_shift", heads[h]); s.add(nm, D_OUT_KIND[kind]);
-    if (h == 1 && precision == DP_PREC_F32) { snprintf(nm, sizeof(nm), "%s.w2x", heads[h]); s.add(nm, dp_conv_w2p_floats(kind, DP_PREC_BF16X6)); }
+    if (h == 1 && precision == DP_PREC_F32) {
+      snprintf(nm, sizeof(nm), "%s.w2x", heads[h]); s.add(nm, dp_conv_w2p_floats(kind, DP_PREC_F16X3));
+      snprintf(nm, sizeof(nm), "%s.bnx", heads[h]); s.add(nm, D_OUT_KIND[kind]);
+    }
   }
   s.add("so3_table", 1000); s.add("torus_table", 5001);
   s.add("lig_gauss_mu", 20); s.add("ph_gauss_mu", 20); s.add("x_gauss_mu", 20); s.add("center_gauss_mu", 20);
@@ -244,9 +248,9 @@ int64_t dp_weights_blob_floats(int32_t precision) {
 
 int dp_weights_bind(const float* blob, int32_t precision, const DpModelScalars* sc, DpWeights* w) {
   if (!blob || !sc || !w) return DP_E_BADARG;
-  DpSegment segs[256];
-  const int n = dph::list_segments(precision, segs, 256, nullptr);
-  if (n < 0 || n > 256) return DP_E_BADARG;
+  DpSegment segs[384];
+  const int n = dph::list_segments(precision, segs, 384, nullptr);
+  if (n < 0 || n > 384) return DP_E_BADARG;
   memset(w, 0, sizeof(*w));
   auto find = [&](const char* name) -> const float* {
     for (int i = 0; i < n; ++i)
@@ -268,6 +272,7 @@ int dp_weights_bind(const float* blob, int32_t precision, const DpModelScalars* 
     snprintf(nm, sizeof(nm), "%s.w1n", name); c.w1n = find(nm);
     snprintf(nm, sizeof(nm), "%s.w2n", name); c.w2n = find(nm);
     snprintf(nm, sizeof(nm), "%s.w2x", name); c.w2x = find(nm);
+    snprintf(nm, sizeof(nm), "%s.bnx", name); c.bn_scale_x = find(nm);
     snprintf(nm, sizeof(nm), "%s.w1h", name); c.w1h = find(nm);
     snprintf(nm, sizeof(nm), "%s.w2h", name); c.w2h = find(nm);
   };

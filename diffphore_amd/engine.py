@@ -59,7 +59,7 @@ class DpMlp(C.Structure):
 
 
 class DpConvW(C.Structure):
-    _fields_ = [(n, VOIDP) for n in ("w1p", "w2p", "bn_scale", "bn_shift", "w1n", "w2n", "w2x", "w1h", "w2h")]
+    _fields_ = [(n, VOIDP) for n in ("w1p", "w2p", "bn_scale", "bn_shift", "w1n", "w2n", "w2x", "bn_scale_x", "w1h", "w2h")]
 
 
 class DpWeights(C.Structure):
@@ -212,7 +212,7 @@ class DeviceModel:
             for l in range(4):
                 node = name != "ph_conv" and prec == _lib.PREC_F32
                 node_bf = name != "ph_conv" and prec == _lib.PREC_BF16
-                # edge-side in an fp32 model (phore-phore always, ligand-ligand for large ligands): bf16x6 second layer as well
+                # edge-side in an fp32 model (phore-phore always, ligand-ligand for large ligands): two-limb fp16 second layer as well (w2x, bnx)
                 x6 = ((name == "ph_conv" and l < 3) or name == "lig_conv") and prec == _lib.PREC_F32
                 # node-side in an fp32 model: the fp32-grade two-limb fp16 fragments as well (DP_PREC_F16X3: what those convs run on by default)
                 for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6, node_bf16=node_bf, node_f16=node).items():
@@ -824,13 +824,13 @@ class Engine:
         x6 = os.environ.get("DIFFPHORE_EDGE_X6", "1")
         if x6 not in ("0", "1"):
             raise ValueError(f"DIFFPHORE_EDGE_X6 must be 0 or 1 (got {x6!r})")
-        self.ws.struct.edge_bf16x6 = int(x6)         # 1 (default): edge-side convs of an fp32 model as a bf16x6 split; 0: exact fp32 MFMA everywhere
+        self.ws.struct.edge_bf16x6 = int(x6)         # 1 (default): edge-side convs of an fp32 model as a two-limb fp16 split (until round 4: bf16x6); 0: exact fp32 MFMA
         f16 = os.environ.get("DIFFPHORE_NODE_F16", "1")
         if f16 not in ("0", "1"):
             raise ValueError(f"DIFFPHORE_NODE_F16 must be 0 or 1 (got {f16!r})")
         self.ws.struct.node_f16 = int(f16)           # 1 (default): node-side convs of an fp32 model as two fp16 limbs per operand (DP_PREC_F16X3); 0: fp32 MFMA
         self.node_side_convs = ("f16x3" if f16 == "1" else "f32") if model.precision == "f32" else model.precision
-        self.edge_side_convs = ("bf16x6" if x6 == "1" else "f32") if model.precision == "f32" else model.precision
+        self.edge_side_convs = ("f16x3" if x6 == "1" else "f32") if model.precision == "f32" else model.precision
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         ps = os.environ.get("DIFFPHORE_PATH_SPLIT", "auto")
         if ps not in ("auto", "1", "0"):

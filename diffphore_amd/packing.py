@@ -34,8 +34,8 @@ def bn_affine(sd: Dict[str, torch.Tensor], prefix: str, irreps, eps: float = 1e-
 def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: int = 0, node_side: bool = False, x6: bool = False,
               node_bf16: bool = False, node_f16: bool = False) -> Dict[str, torch.Tensor]:
     """fc.0 / fc.3 / batch_norm of one TensorProductConvLayer -> MFMA operand order (host tensors).  `node_side` adds the layout of
-    the node-side kernel (dp_conv_node_impl.h: layer convs over the dense cross edge sets, fp32); `x6` adds the second layer packed for
-    DP_PREC_BF16X6 (`w2x`: what the edge-side convs of an fp32 model run on, DpConvW.w2x); `node_bf16` adds the bf16 MFMA fragments of the
+    the node-side kernel (dp_conv_node_impl.h: layer convs over the dense cross edge sets, fp32); `x6` adds the second layer packed for the
+    edge-side kernel at DP_PREC_F16X3 (`w2x` + `bnx`: what the edge-side convs of an fp32 model run on, DpConvW.w2x / bn_scale_x); `node_bf16` adds the bf16 MFMA fragments of the
     DP_PREC_BF16 node-side kernel (dp_conv_node_bf16_impl.h) under the same names `w1n` / `w2n`; `node_f16` adds the two-limb fp16 fragments of
     the fp32-grade DP_PREC_F16X3 node-side kernel (dp_conv_node_f16_impl.h) as `w1h` / `w2h` (DpConvW.w1h / w2h)."""
     L = _lib.lib()
@@ -73,10 +73,15 @@ def pack_conv(sd: Dict[str, torch.Tensor], prefix: str, kind: int, precision: in
                                                    scale.data_ptr(), w1h.data_ptr(), w2h.data_ptr()), "dp_pack_conv_weights_node_f16")
         out.update(w1h=w1h, w2h=w2h)
     if x6:
+        # the second layer once more for the EDGE-side kernel at DP_PREC_F16X3 (two fp16 limbs of W2 * 2^w; w = float[0] of the image's last quad)
+        # and the BatchNorm scale that undoes the 2^w (the contraction, the segmented mean and the scale are linear in W2)
         w1_ = torch.empty(L.dp_conv_w1p_floats(kind), dtype=torch.float32)
-        w2x = torch.empty(L.dp_conv_w2p_floats(kind, _lib.PREC_BF16X6), dtype=torch.float32)
-        _lib.check(L.dp_pack_conv_weights(kind, _lib.PREC_BF16X6, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
-                                          w1_.data_ptr(), w2x.data_ptr()), "dp_pack_conv_weights (bf16x6)")
+        w2x = torch.empty(L.dp_conv_w2p_floats(kind, _lib.PREC_F16X3), dtype=torch.float32)
+        _lib.check(L.dp_pack_conv_weights(kind, _lib.PREC_F16X3, fc0_w.data_ptr(), fc0_b.data_ptr(), fc3_w.data_ptr(), fc3_b.data_ptr(),
+                                          w1_.data_ptr(), w2x.data_ptr()), "dp_pack_conv_weights (f16x3)")
         assert torch.equal(w1_, w1p)                       # the first layer's packing does not depend on the precision
+        wexp = float(w2x[-4])
+        assert wexp == int(wexp) and abs(wexp) <= 40, wexp
         out["w2x"] = w2x
+        out["bnx"] = (scale.double() * 2.0 ** -wexp).float().contiguous()
     return out

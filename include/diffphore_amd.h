@@ -64,11 +64,14 @@ enum DpPrecision {
                            relative each); geometry, spherical harmonics, edge-embedding MLPs, accumulation, BatchNorm shift and the
                            residual stream stay fp32.  Node-side kernel: dp_conv_node_bf16_impl.h (one v_mfma_f32_16x16x32_bf16 per node,
                            column tile and pass).  Edge-side kernel: the bf16x3 arithmetic (its weights are packed as for DP_PREC_BF16X3). */
-  DP_PREC_F16X3 = 6     /* node-side kernel only (dp_conv_node_f16_impl.h), fp32-GRADE: every operand of the three GEMMs as TWO fp16 limbs
+  DP_PREC_F16X3 = 6     /* fp32-GRADE on the 16-bit pipe.  Node-side kernel (dp_conv_node_f16_impl.h): every operand of the three GEMMs as TWO fp16 limbs
                            (hi = rne16(v), lo = rne16(v - hi): 22 significand bits; exact power-of-two scales map the operands into fp16's
                            range), cross products hi*hi + hi*lo + lo*hi (+ lo*lo in the second contraction) on v_mfma_f32_16x16x32_f16, fp32
                            accumulate.  Held to the same tolerances as DP_PREC_F32.  Precondition: |features|, |edge embedding| < 65504.
-                           Not a model precision: dp_forward uses it for the node-side convs of a DP_PREC_F32 model (DpWork.node_f16). */
+                           Edge-side kernel (dp_conv.hip, round 5): the radial contraction W2 hid with both operands as two fp16 limbs, 3 cross
+                           products on v_mfma_f32_32x32x16_f16 (weights from dp_pack_conv_weights(kind, DP_PREC_F16X3): W2 * 2^w, w in a trailing
+                           quad; the caller passes bn_scale * 2^-w).  Not a model precision: dp_forward uses it for the convs of a DP_PREC_F32
+                           model (DpWork.node_f16 for the node-side launches, DpWork.edge_bf16x6 for the convs that stay edge-side). */
 };
 
 /* formulation of the fused conv: per-edge radial GEMM, or node-side contraction (dense cross edge sets; DP_PREC_F32 or DP_PREC_BF16) */
@@ -288,10 +291,12 @@ typedef struct DpMlp { const float *w0, *b0, *w3, *b3; } DpMlp;   /* nn.Sequenti
 typedef struct DpConvW {
   const float *w1p, *w2p, *bn_scale, *bn_shift;
   const float *w1n, *w2n;     /* node-side layout or NULL */
-  const float* w2x;           /* the second layer packed for DP_PREC_BF16X6 beside an fp32 `w2p`, or NULL: the convs that stay on the edge-side
-                                 kernel in an fp32 model (phore-phore: low degree; torsion bonds) then run their radial contraction as a 3-way
-                                 bf16 split with 6 cross products on the bf16 pipe (16x the fp32 MFMA rate) - ~2^-24 relative per product, fp32
-                                 accumulate, held to the same tolerances as the fp32 kernel (DpWork.edge_bf16x6 = 0 turns it off) */
+  const float* w2x;           /* the second layer packed for the EDGE-side kernel at DP_PREC_F16X3 beside an fp32 `w2p`, or NULL: the convs that stay on
+                                 the edge-side kernel in an fp32 model (phore-phore: low degree; torsion bonds; ligand-ligand of large ligands) then
+                                 run their radial contraction on the 16-bit matrix pipe as a 2-way fp16 split with 3 cross products (22 significand
+                                 bits, fp32 accumulate; rounds 3-4: a 3-way bf16 split with 6 products, DP_PREC_BF16X6, still selectable as a model
+                                 precision) - held to the same tolerances as the fp32 kernel (DpWork.edge_bf16x6 = 0 turns it off) */
+  const float* bn_scale_x;    /* [D_out] bn_scale * 2^-w for `w2x` (its image stores W2 * 2^w; w = the float in the image's last quad) */
   const float *w1h, *w2h;     /* the node-side convs of an fp32 model once more as two-limb fp16 fragments (dp_pack_conv_weights_node_f16), or NULL:
                                  DP_PREC_F16X3, fp32-grade on the 16-bit matrix pipe (DpWork.node_f16 = 0 turns it off) */
 } DpConvW;
@@ -372,8 +377,9 @@ typedef struct DpWork {
   int32_t ll_node_max_atoms;        /* the ligand-ligand conv runs node-side (pair-dense) while the batch's largest ligand has at most this many
                                        atoms, edge-side (CSR) beyond; 0 = library default */
   int32_t edge_bf16x6;              /* 1 = the edge-side convs of an fp32 model (phore-phore, torsion bonds, ligand-ligand above the pair cap) use
-                                       DpConvW.w2x when present: 3-way bf16 split, 6 cross products, fp32-grade (the default dp_work_bind sets);
-                                       0 = exact fp32 MFMA everywhere */
+                                       DpConvW.w2x / bn_scale_x when present: fp32-grade operand split on the 16-bit pipe (the default dp_work_bind
+                                       sets; the field keeps its round-3 name: until round 4 the split was bf16x6, since round 5 it is the two-limb
+                                       fp16 form, DP_PREC_F16X3); 0 = exact fp32 MFMA */
   float* conv_part;                 /* [DP_CONV_PART_FLOATS] scratch of the conv-split launches of small batches (dp_tp_conv_node_fused_split) */
   float* z_noise;                   /* [6 B + n_tor] scratch of DP_NOISE_SEED: one step's z_tr | z_rot | z_tor */
   int32_t path_split;               /* node-side fp32 convs: 0 = library's choice (two workgroups per node group while B x groups <= 256: small batches), 1 = always,

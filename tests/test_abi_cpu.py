@@ -113,6 +113,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
         names = [sg.name.decode() for sg in segs]
         assert len(set(names)) == n and "p2l_conv.3.w2p" in names and ("p2l_conv.3.w2n" in names) == (prec in (_lib.PREC_F32, _lib.PREC_BF16))
         assert ("ph_conv.0.w2x" in names) == ("tor_conv.w2x" in names) == (prec == _lib.PREC_F32) and "ph_conv.3.w2x" not in names
+        assert ("ph_conv.0.bnx" in names) == ("tor_conv.bnx" in names) == ("lig_conv.2.bnx" in names) == (prec == _lib.PREC_F32)
         # the node-side families of an fp32 model carry the two-limb fp16 images too (DP_PREC_F16X3), phore-phore (edge-side) does not
         assert ("p2l_conv.3.w2h" in names) == ("lig_conv.0.w1h" in names) == (prec == _lib.PREC_F32) and "ph_conv.0.w2h" not in names
 

@@ -278,3 +278,37 @@ def test_conv_node_f16_lean_instantiation_is_bit_identical(kind, mode):
     want = ref.clone()
     want[:, :dims["d_in"]] += resid.double()
     assert (out_l.cpu().double() - want).abs().max().item() / ref.abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", ["p2l", "l2p"])
+def test_edge_side_f16x3_vs_oracle(kind, mode):
+    """DP_PREC_F16X3 on the EDGE-side kernel (dp_conv.hip, round 5: what the phore-phore / torsion / large-ligand convs of an fp32 model run
+    instead of the 3-way bf16 split): both operands of the radial contraction as two fp16 limbs, 3 cross products; weights `w2x` = W2 * 2^w and
+    the BatchNorm scale `bnx` = bn_scale * 2^-w from packing.pack_conv(x6=True).  Same tolerance as the exact-fp32 kernel."""
+    base, ref, resid, dims, n_out, _ = _cross_case(kind, mode, 2800 + kind, [7, 30, 13, 1, 40, 17], [32, 5, 79, 33, 17, 48])
+    sd = weights.init_state_dict(11)
+    fam = "phore_to_lig_conv_layers" if mode == "p2l" else "lig_to_phore_norm_conv_layers"
+    if kind == 3 and mode == "l2p":
+        fam = "lig_to_phore_conv_layers"
+    pk = packing.pack_conv(sd, f"encoder.{fam}.{kind}", kind, _lib.PREC_F32, x6=True)
+    wexp = float(pk["w2x"][-4])
+    assert torch.allclose(pk["bnx"].double() * 2.0 ** wexp, pk["bn_scale"].double(), rtol=1e-7)
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    args = dict(base, algo=_lib.ALGO_EDGE, precision=_lib.PREC_F16X3, slices=3, w2p=_dev(pk["w2x"]), bn_scale=_dev(pk["bnx"]), out=out)
+    _run(args, keep)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    err = (got - want).abs().max().item() / ref.abs().max().item()
+    print(f"kind {kind} {mode}: edge-side f16x3 vs fp64 oracle {err:.2e}")
+    assert err < TOL, err
+    # the 3-way bf16 split it replaces, on the same inputs
+    pk6 = packing.pack_conv(sd, f"encoder.{fam}.{kind}", kind, _lib.PREC_BF16X6)
+    out6 = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    _run(dict(base, algo=_lib.ALGO_EDGE, precision=_lib.PREC_BF16X6, slices=3, w2p=_dev(pk6["w2p"]), bn_scale=_dev(pk6["bn_scale"]), out=out6), keep)
+    err6 = (out6.cpu().double() - want).abs().max().item() / ref.abs().max().item()
+    print(f"    bf16x6 on the same inputs {err6:.2e}")
+    assert err6 < TOL

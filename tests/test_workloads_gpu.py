@@ -83,16 +83,16 @@ def test_config_workload_matches_oracle(cfg_id, precision, tol, monkeypatch):
 
 # bounds of the full 100-step configs[4] run below, per precision: (every pose after 20 steps, every pose after 100 steps), Angstrom RMSD from the
 # fp64 oracle with the same start poses and noise.  Measured on MI355X (printed by the test, profiles/r5_configs4_100step.txt), max over the 6 poses
-# after 20 / 100 steps:   f32 (library default: f16x3 node-side + bf16x6 edge-side convs) 9.3e-5 / 8.9e-5;  f32-f16x3 (f16x3 node-side convs, exact
+# after 20 / 100 steps:   f32 (library default: f16x3 node-side + split edge-side convs) 9.3e-5 / 8.9e-5;  f32-f16x3 (f16x3 node-side convs, exact
 # fp32 edge-side) and f32-exact (exact fp32 MFMA everywhere): see the profile;  bf16x3 9.5e-5 / 9.1e-5;  bf16 7.4e-4 / 1.6e-3.
 # (One pose of the six sits at 9e-5 from step 20 on in every arm that runs the phore-phore convs as a bf16 split, and at 8e-6 in the exact arm;
 # the other five stay below 5.4e-5 over all 100 steps.)
 FULL_RUN_BOUNDS = {"f32": (1.5e-4, 3e-4), "f32-f16x3": (1.5e-4, 3e-4), "f32-exact": (5e-5, 1e-4), "f32-small": (1.5e-4, 3e-4), "bf16x3": (1.5e-4, 3e-4),
                    "bf16": (2.5e-3, 5e-3)}
-# environment of the fp32 arms: DIFFPHORE_NODE_F16 (two-limb fp16 node-side kernel), DIFFPHORE_EDGE_X6 (bf16x6 edge-side convs), DIFFPHORE_PATH_SPLIT=0
+# environment of the fp32 arms: DIFFPHORE_NODE_F16 (two-limb fp16 node-side kernel), DIFFPHORE_EDGE_X6 (fp32-grade operand split of the edge-side convs), DIFFPHORE_PATH_SPLIT=0
 # (these 6 poses would otherwise take the small-batch path split, i.e. the exact-fp32 node-side kernels): "f32" = what a LARGE batch of an fp32
-# model runs by default (f16x3 node-side + bf16x6 edge-side), "f32-f16x3" = the f16x3 kernel alone beside exact-fp32 edge-side convs, "f32-exact" =
-# fp32 MFMA everywhere, "f32-small" = the library's own choice for this 6-pose batch (fp32 path-split node-side kernels + bf16x6 edge-side)
+# model runs by default (f16x3 node-side + split edge-side), "f32-f16x3" = the f16x3 kernel alone beside exact-fp32 edge-side convs, "f32-exact" =
+# fp32 MFMA everywhere, "f32-small" = the library's own choice for this 6-pose batch (fp32 path-split node-side kernels + split edge-side)
 FP32_ARMS = {"f32": {"DIFFPHORE_PATH_SPLIT": "0"}, "f32-f16x3": {"DIFFPHORE_PATH_SPLIT": "0", "DIFFPHORE_EDGE_X6": "0"},
              "f32-exact": {"DIFFPHORE_NODE_F16": "0", "DIFFPHORE_EDGE_X6": "0"}, "f32-small": {}}
 
@@ -241,4 +241,4 @@ def test_bench_self_launches_two_ranks(cfg_id, extra):
     assert len(rk["pose_steps_per_s"]) == 2 and len(rk["seconds"]) == 2 and sum(rk["poses"]) == d["config"]["poses_total"]
     assert rk["imbalance_max_over_mean"] >= 1.0 and rk["weight_broadcast_ms"] is not None and rk["weight_broadcast_ms"] > 0
     assert d["config"]["library"]["nabl"] == 0 and len(d["config"]["library"]["source_hash"]) == 16
-    assert d["config"]["edge_side_convs"] == ("bf16" if cfg_id == 5 else "bf16x6")
+    assert d["config"]["edge_side_convs"] == ("bf16" if cfg_id == 5 else "f16x3")
