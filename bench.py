@@ -562,7 +562,9 @@ def main():
         return {"achieved": fl / (tm * 1e-3) / 1e12, "frac": fl / (tm * 1e-3) / 1e12 / peak, "issued_frac": iss / (tm * 1e-3) / 1e12 / peak,
                 "node_launch_ms_per_step": tm, "launches": rows,
                 "note": "sum of node-form algorithmic flops / sum of launch times over every node-side launch of a step; launch times from an untimed "
-                        "extra pass that brackets each launch with HIP events (DpWork.prof_events), one step at a time"}
+                        "extra pass that brackets each launch with HIP events (DpWork.prof_events), one step at a time.  When dp_forward runs the two sides "
+                        "of a layer on two streams (the default with the f16x3 node-side kernels) the bracketed launches OVERLAP and stretch each other: "
+                        "node_launch_ms_per_step then exceeds ms_per_step and this ratio is a lower bound"}
 
     other = None
     if not a.no_other and a.config == 2 and a.precision is None and a.conv_algo is None and a.poses is None:
