@@ -17,8 +17,8 @@ carries ligand-ligand + phore->ligand + phore->ligand(normals) in one launch): a
 its convs) / mean launch duration measured with HIP events recorded inside dp_forward on the launch stream during the timed steps;
 `roofline.step_weighted` = the same ratio over ALL node-side launches of a step (a short extra pass that brackets every launch).
 `cpu_baseline` = this repo's CPU oracle (reference-style torch-CPU restatement, fp32) on a bounded sample of the same workload
-(rank 0, N=1 only).  `config.edge_side_convs` says what the convs that stay on the edge-side kernel in an fp32 model run (bf16x6 split
-by default, fp32-grade; `alt_runs` carries the exact-fp32-everywhere arm).
+(rank 0, N=1 only).  `config.edge_side_convs` says what the convs that stay on the edge-side kernel in an fp32 model run ("f16x3" = two fp16
+limbs per operand by default, fp32-grade; `value_exact_fp32` / `alt_runs[0]` carry the exact-fp32-everywhere arm).
 """
 import argparse
 import ctypes as C
