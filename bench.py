@@ -646,7 +646,7 @@ def main():
             ed = ("f16x3 = both operands of the radial contraction as two fp16 limbs, 3 cross products on v_mfma_f32_32x32x16_f16, fp32 accumulate"
                   if main["edge_side_convs"] == "f16x3" else (main["edge_side_convs"] + " split" if main["edge_side_convs"] != "f32" else "exact fp32 MFMA"))
             dtype = (f"f32-grade (fp32 model held to the fp32 parity tolerances; node-side convs: {nd}; edge-side convs = phore-phore, torsion bonds "
-                     f"[, ligand-ligand above 96 atoms]: {ed}; exact-fp32-MFMA-everywhere arm: value_exact_fp32)")
+                     f"[, ligand-ligand above 32 atoms]: {ed}; exact-fp32-MFMA-everywhere arm: value_exact_fp32)")
         rank_rate = [p_ * a.steps / t_ for p_, t_ in zip(rank_poses, main["rank_seconds"])]
         out = {
             "metric": "poses/sec (samples x steps) on the reverse-diffusion hot path",
@@ -665,7 +665,7 @@ def main():
                        "node_side_convs_note": "what the node-side launches (ligand-ligand + cross convs: 21 per forward) run: 'f16x3' = the fp32-grade two-limb "
                                                "fp16 kernel (dp_conv_node_f16_impl.h; library default DpWork.node_f16 = 1, same parity tolerances as fp32: "
                                                "tests/test_conv_f16_gpu.py 2-4e-7 of max vs the fp64 oracle), 'f32' = v_mfma_f32_16x16x4_f32 (DIFFPHORE_NODE_F16=0)",
-                       "edge_side_convs_note": "what the convs that stay on the edge-side kernel (phore-phore, torsion bonds; ligand-ligand above 96 atoms, 32 with the fp32 node-side kernel) run: "
+                       "edge_side_convs_note": "what the convs that stay on the edge-side kernel (phore-phore, torsion bonds; ligand-ligand above 32 atoms) run: "
                                                "'f16x3' = 2-way fp16 operand split, 3 cross products, fp32 accumulate (fp32-grade: same parity tolerances; the library default, "
                                                "DpWork.edge_bf16x6 = 1 - the 3-way bf16 split 'bf16x6' until round 4), 'f32' = exact fp32 MFMA (alt_runs[0] times that arm)",
                        "library": dict(_build_info()),

@@ -12,16 +12,14 @@
 
 #ifndef DP_NODE_LL_MAX_ATOMS
 // The ligand-ligand conv runs node-side (pair-dense: N x N slots) while every ligand of the batch fits ONE 32-slot pass; beyond, the
-// pair slots are < 50 % full (radius graph capped at 32 neighbours) and the edge-side CSR kernel in its bf16x6 form is faster: 256 poses
-// x 80 atoms 8.93 vs 9.53 ms/step, the 15-45-atom virtual-screen batch 18.80 vs 19.14, 512 x 30 atoms 5.74 vs 5.50 (node-side stays).
-// DpWork.ll_node_max_atoms overrides it.
+// pair slots are < 50 % full (radius graph capped at 32 neighbours) and the edge-side CSR kernel in its fp32-grade 16-bit form is faster.
+// Round 3 (fp32 node-side kernel vs edge-side bf16x6): 256 poses x 80 atoms 8.93 vs 9.53 ms/step, the 15-45-atom virtual-screen batch
+// 18.80 vs 19.14, 512 x 30 atoms 5.74 vs 5.50 (node-side stays).  Round 5, both forms on two fp16 limbs (node-side 0.48 ns per pair SLOT,
+// edge-side 0.78 ns per EDGE at layer 2: the node form needs > 60 % of its slots filled): 256 x 80 atoms 48.9k (edge-side) vs 41.6k
+// pose-steps/s (three pair passes), 15-45 atoms 59.9k vs 58.2k, 512 x 30 atoms 140.3k vs 146.8k (node-side stays); against the slower
+// bf16x6 edge-side form the three-pass node form had still won (40.3k vs 41.6k), which is why the cap briefly stood at 96.
+// DpWork.ll_node_max_atoms overrides it.  tools/gpu_ll_policy.sh
 #define DP_NODE_LL_MAX_ATOMS 32
-#endif
-#ifndef DP_NODE_LL_MAX_ATOMS_F16
-// ... with the fp32 node-side kernel.  The two-limb fp16 kernel (DP_PREC_F16X3, ~1.5x shorter per pass) keeps the ligand-ligand conv
-// node-side up to three 32-slot passes: 256 x 80 atoms 40.3k -> 41.6k pose-steps/s, the 15-45-atom virtual-screen batch 53.3k -> 55.6k
-// against the edge-side bf16x6 form (round 5, tools/gpu_ab_env.sh)
-#define DP_NODE_LL_MAX_ATOMS_F16 96
 #endif
 
 namespace dp {
@@ -697,11 +695,8 @@ static bool plan_node_side(const DpBatch* b, const DpWeights* w, const DpWork* k
   return dp_resolve_conv_algo(k->conv_algo, w->precision, b->B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
 }
 static bool plan_node_ll(const DpBatch* b, const DpWeights* w, const DpWork* k) {
-  // (the cap depends on which node-side kernel the ligand-side launch would run: the f16x3 one unless the launch takes the small-batch path split)
-  const bool f16 = w->precision == DP_PREC_F32 && k->node_f16 != 0 && w->lig_conv[0].w2h != nullptr && k->x_emb_bf != nullptr && k->ll_emb_bf != nullptr &&
-                   !(k->path_split == 1 || (k->path_split != 2 && node_path_split_auto(b->B, (b->max_nl + 15) / 16, true)));
   return plan_node_side(b, w, k) && w->lig_conv[0].w2n != nullptr && b->llp_ptr != nullptr && k->ll_pair_rad != nullptr &&
-         k->ll_pair_bond != nullptr && b->max_nl <= (k->ll_node_max_atoms > 0 ? k->ll_node_max_atoms : (f16 ? DP_NODE_LL_MAX_ATOMS_F16 : DP_NODE_LL_MAX_ATOMS));
+         k->ll_pair_bond != nullptr && b->max_nl <= (k->ll_node_max_atoms > 0 ? k->ll_node_max_atoms : DP_NODE_LL_MAX_ATOMS);
 }
 
 int dp_forward_launch_of(const DpBatch* b, const DpWeights* w, const DpWork* k, int32_t layer, int32_t conv, int32_t* first, int32_t* count,

@@ -224,6 +224,49 @@ def test_node_side_above_the_ligand_ligand_cap():
         os.environ.pop("DIFFPHORE_CONV_ALGO", None)
 
 
+def test_multi_pass_pair_dense_ligand_conv_equals_the_edge_side_one(monkeypatch):
+    """Ligands of 40-60 atoms: by default (one pair pass only, DP_NODE_LL_MAX_ATOMS = 32) their ligand-ligand convs run on the edge-side
+    f16x3 kernel; DIFFPHORE_LL_NODE_MAX_ATOMS=64 puts them into the fused ligand-side launch as two pair-dense passes of the f16x3
+    node-side kernel (what round 5 shipped for a while).  Both forms against the fp64 oracle, pose by pose (a pose may deviate only on an
+    oracle-recorded near-tie decision, as in the test above)."""
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import sampler as osampler
+    gs = synthetic.synthetic_pairs(821, 12, 40, 8, 24) + synthetic.synthetic_pairs(822, 12, 60, 10, 40)
+    sd, om = _model()
+    batch = Batch.from_data_list(gs)
+    osampler.set_time_phore(batch, 0.45, 0.45, 0.45, batch.num_graphs)
+    om.track_margins = True
+    try:
+        tr_o, rot_o, tor_o = om(batch)
+    finally:
+        om.track_margins = False
+    margin = np.min(np.stack([v.numpy() for v in om.margins.values()]), 0)
+    tor_pose = torch.repeat_interleave(torch.arange(len(gs)), torch.tensor([int(g["ligand"].edge_mask.sum()) for g in gs]))
+
+    def per_pose(tr, rot, tor):
+        e = np.zeros(len(gs))
+        for got, want, idx in ((tr, tr_o, torch.arange(len(gs))), (rot, rot_o, torch.arange(len(gs))), (tor, tor_o, tor_pose)):
+            got, want = got.double().cpu(), want.double().cpu()
+            d = (got - want).abs().reshape(got.shape[0], -1).max(1).values / want.abs().max()
+            for p in range(len(gs)):
+                e[p] = max(e[p], float(d[idx == p].max()))
+        return e
+
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", "node")
+    monkeypatch.setenv("DIFFPHORE_PATH_SPLIT", "0")           # 24 poses: keep the f16x3 kernels (the small-batch path split runs the fp32 ones)
+    for cap in ("32", "64"):
+        monkeypatch.setenv("DIFFPHORE_LL_NODE_MAX_ATOMS", cap)
+        m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+        tr, rot, tor = m(batch)
+        torch.cuda.synchronize()
+        assert int(m._engine.ws.t["status"].abs().sum()) == 0
+        e = per_pose(tr, rot, tor)
+        bad = np.nonzero(~(e < 1e-5))[0]
+        print(f"ligand-ligand cap {cap}: per-pose score error vs fp64 oracle", " ".join(f"{x:.1e}" for x in e), "| beyond 1e-5:", bad.tolist(),
+              [float(margin[i]) for i in bad])
+        assert np.isfinite(e).all() and bad.size <= max(1, len(e) // 8) and all(margin[i] < MARGIN_FP32 for i in bad), (cap, e, margin)
+
+
 def test_repeated_ordered_bond_falls_back_to_the_edge_side_lig_conv():
     """a ligand multigraph (same ordered bond listed twice) used to raise ValueError on the default path.  Now the batch is
     packed without pair tables, the ligand-ligand convs run on the edge-side CSR kernel (cross convs stay node-side), no status bit is
