@@ -546,7 +546,10 @@ __device__ __forceinline__ void conv_bf16(const DpConvArgs& a, const Grp& grp, i
 }
 
 template <int KIND, bool HAS_LL, int XMODE>
-__global__ __launch_bounds__(256, 2) void tp_conv_node_bf16_kernel(FusedArgs fa) {
+#ifndef DP_WG_PER_CU
+#define DP_WG_PER_CU 2            // 1 = timing experiment: one wave per SIMD with the whole 512-register file (r5_experiments.md section 7)
+#endif
+__global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(FusedArgs fa) {
   __shared__ __attribute__((aligned(128))) float s_T[4 * TIMG_F + TDUM_B / 4];   // wave-private T images (bf16) + the dummy column; reused for the reduction
   __shared__ __attribute__((aligned(16))) float s_S[NB * SCOMP * 32];         // per-edge sh factors of the current pass (fp32)
   __shared__ float s_inv[NB];

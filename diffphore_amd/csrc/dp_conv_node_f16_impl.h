@@ -677,7 +677,10 @@ __device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, in
 __device__ __forceinline__ float w2_exponent(const DpConvArgs& a) { return *reinterpret_cast<const float*>(a.w2n); }
 
 template <int KIND, bool HAS_LL, int XMODE, bool HALFOK>
-__global__ __launch_bounds__(256, 2) void tp_conv_node_f16_kernel(FusedArgs fa) {
+#ifndef DP_WG_PER_CU
+#define DP_WG_PER_CU 2            // 1 = timing experiment: one wave per SIMD with the whole 512-register file (r5_experiments.md section 7)
+#endif
+__global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(FusedArgs fa) {
   __shared__ __attribute__((aligned(128))) float s_T[4 * TIMG_F + TDUM_B / 4];   // wave-private T images (fp16, hi | lo node slots) + the dummy column; reused for the reduction
   __shared__ __attribute__((aligned(16))) float s_S[NBH * SCOMP * 32];         // per-edge sh factors of the current pass (fp32)
   __shared__ __attribute__((aligned(16))) float s_X[32 * XROW];               // the pass's gathered rows, one half of the input columns at a time
