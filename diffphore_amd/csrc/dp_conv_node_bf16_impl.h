@@ -560,7 +560,13 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
   using S = Spec<KIND>;
   static_assert(4 * NB * S::D_OUT <= 4 * TIMG_F, "reduction scratch fits in the T images");
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
-  const Grp grp = grp_of(fa.conv[0], (int)blockIdx.x);
+  // conv split (small batches: FusedArgs.conv_split, as in the fp32 kernel): blockIdx = conv * groups + group, this workgroup runs ONE conv of the
+  // launch and leaves the sum of its four k-partials in part[conv][node] - shifts, residual and the sum over convs are dp_conv_node_combine's
+  const int n_conv_all = (HAS_LL ? 1 : 0) + fa.n_x;
+  const int groups = fa.conv[0].B * fa.conv[0].slices;
+  const int bid = fa.conv_split ? (int)blockIdx.x % groups : (int)blockIdx.x;
+  const int cx_only = fa.conv_split ? (int)blockIdx.x / groups : -1;
+  const Grp grp = grp_of(fa.conv[0], bid);
   if (grp.n_loc <= 0) return;
   f32x4 acc[n_acc4<KIND>()];
 #pragma unroll
@@ -568,13 +574,19 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
   NProfT prof_prev{};
   (void)prof_prev;
   NPROF(-1);
-  if constexpr (HAS_LL) conv_bf16<KIND, LL>(fa.conv[0], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
+  if constexpr (HAS_LL) {
+    if (cx_only <= 0) conv_bf16<KIND, LL>(fa.conv[0], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
+  }
+  {
+    const int c_lo = cx_only < 0 ? (HAS_LL ? 1 : 0) : (cx_only < (HAS_LL ? 1 : 0) ? n_conv_all : cx_only);
+    const int c_hi = cx_only < 0 ? n_conv_all : (c_lo < n_conv_all ? c_lo + 1 : n_conv_all);
 #pragma unroll 1
-  for (int cx = 0; cx < fa.n_x; ++cx) conv_bf16<KIND, XMODE>(fa.conv[(HAS_LL ? 1 : 0) + cx], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
+    for (int cx = c_lo; cx < c_hi; ++cx) conv_bf16<KIND, XMODE>(fa.conv[cx], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
+  }
   // ---- sum the four k-partials, BatchNorm shift, residual stream (mean and BatchNorm scale are inside the operands) -----------------
   {
     const DpConvArgs& a = fa.conv[0];
-    const int n_conv = (HAS_LL ? 1 : 0) + fa.n_x;
+    const int n_conv = cx_only < 0 ? n_conv_all : 0;       // (conv split: no shifts, no residual here)
     constexpr int EP_ROUNDS = (NB * S::D_OUT + 255) / 256;
     float er[EP_ROUNDS], eb[EP_ROUNDS];
 #pragma unroll
@@ -588,7 +600,7 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
       eb[it] = sh;
       const float* src = a.accumulate ? a.out + (size_t)node * a.out_stride + (live ? ch : 0)
                                       : (a.resid != nullptr && live && ch < a.resid_width ? a.resid + (size_t)node * a.resid_stride + ch : nullptr);
-      er[it] = (live && src != nullptr) ? *src : 0.f;
+      er[it] = (live && src != nullptr && cx_only < 0) ? *src : 0.f;
     }
     __syncthreads();
     AccStore<KIND, 0>::run(acc, s_T + q * (NB * S::D_OUT), lane);
@@ -599,7 +611,8 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
       if (i >= grp.n_loc * S::D_OUT) continue;
       const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
       const float part = ((s_T[i] + s_T[NB * S::D_OUT + i]) + s_T[2 * NB * S::D_OUT + i]) + s_T[3 * NB * S::D_OUT + i];
-      a.out[(size_t)(grp.n_lo + n) * a.out_stride + ch] = er[it] + (part + eb[it]);
+      if (cx_only < 0) a.out[(size_t)(grp.n_lo + n) * a.out_stride + ch] = er[it] + (part + eb[it]);
+      else fa.part[(size_t)cx_only * fa.part_stride + (size_t)(grp.n_lo - fa.node0 + n) * a.out_stride + ch] = part;
     }
   }
   NPROF(4);
@@ -611,7 +624,7 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
 
 template <int KIND> int launch_bf16(const FusedArgs& fa, int xmode, hipStream_t st) {
   const DpConvArgs& a = fa.conv[0];
-  const dim3 grid((unsigned)(a.B * a.slices)), block(256);
+  const dim3 grid((unsigned)(a.B * a.slices * (fa.conv_split ? fa.n_ll + fa.n_x : 1))), block(256);
   if (fa.n_ll) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, true, DP_EDGES_P2L>), grid, block, 0, st, fa);
   else if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_P2L>), grid, block, 0, st, fa);
   else hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_L2P>), grid, block, 0, st, fa);

@@ -264,3 +264,21 @@ def test_conv_node_bf16_fused_equals_separate_launches(kind, mode):
     assert torch.isfinite(b_).all()
     err = (a - b_).abs().max().item() / a.abs().max().item()
     assert err < 1e-5, err
+    # conv split (small batches): every conv on its own workgroups + the combine launch - the same MFMA operands per conv, the convs' outputs
+    # added in fp32 by dp_conv_node_combine instead of inside the accumulators; deterministic (bit-identical reruns)
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    part = torch.zeros(2 * n_out * dims["d_out"], device="cuda")
+    outs = []
+    for rep in range(2):
+        out_c = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+        for i in range(2):
+            arr[i].out, arr[i].path_split = out_c.data_ptr(), 1
+        _lib.check(L.dp_tp_conv_node_fused_split(arr, 2, n_out, part.data_ptr(), part.numel(), st), "dp_tp_conv_node_fused_split (bf16)")
+        torch.cuda.synchronize()
+        outs.append(out_c.cpu())
+    assert torch.equal(outs[0], outs[1])
+    c_ = outs[0].double()
+    assert torch.isfinite(c_).all()
+    err_s = (c_ - b_).abs().max().item() / b_.abs().max().item()
+    print(f"kind {kind} {mode}: bf16 conv split vs fused launch {err_s:.1e}")
+    assert err_s < 1e-5, err_s

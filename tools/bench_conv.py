@@ -33,13 +33,14 @@ def main():
         _lib.LIB_PATH = a.lib
     dims = _lib.conv_dims(a.kind)
     sd = weights.init_state_dict(1)
-    f16 = a.prec == "f16x3"        # the fp32-grade two-limb fp16 node-side kernel (DP_PREC_F16X3): weights of an fp32 model
-    if f16 and a.algo != "node":
-        raise SystemExit("--prec f16x3 is a node-side kernel: add --algo node")
-    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PREC_F32 if f16 else _lib.PRECISIONS[a.prec],
-                           node_side=a.algo == "node" and a.prec == "f32", node_bf16=a.algo == "node" and a.prec == "bf16", node_f16=f16)
+    f16 = a.prec == "f16x3" and a.algo == "node"    # the fp32-grade two-limb fp16 node-side kernel (DP_PREC_F16X3): weights of an fp32 model
+    f16e = a.prec == "f16x3" and a.algo == "edge"   # the same arithmetic on the edge-side kernel (what an fp32 model's phore-phore / torsion convs run)
+    pk = packing.pack_conv(sd, f"encoder.phore_to_lig_conv_layers.{a.kind}", a.kind, _lib.PREC_F32 if a.prec == "f16x3" else _lib.PRECISIONS[a.prec],
+                           node_side=a.algo == "node" and a.prec == "f32", node_bf16=a.algo == "node" and a.prec == "bf16", node_f16=f16, x6=f16e)
     if f16:
         pk["w1n"], pk["w2n"] = pk["w1h"], pk["w2h"]
+    if f16e:
+        pk["w2p"], pk["bn_scale"] = pk["w2x"], pk["bnx"]
     B, NL, NP = a.B, a.nl, a.np
     dev = "cuda"
     lig_ptr = torch.arange(B + 1, dtype=torch.int32) * NL
@@ -57,7 +58,7 @@ def main():
     args = _lib.DpConvArgs()
     args.kind, args.B, args.slices = a.kind, B, a.slices
     args.phase_split = a.phase_split
-    args.precision = _lib.PREC_F16X3 if f16 else _lib.PRECISIONS[a.prec]
+    args.precision = _lib.PREC_F16X3 if a.prec == "f16x3" else _lib.PRECISIONS[a.prec]
     args.max_scatter = NL if a.mode == "p2l" else NP
     args.mode = _lib.EDGES_P2L if a.mode == "p2l" else _lib.EDGES_L2P
     args.scat_ptr = keep["lig_ptr"].data_ptr() if a.mode == "p2l" else keep["ph_ptr"].data_ptr()
