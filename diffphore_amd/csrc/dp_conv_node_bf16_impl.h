@@ -151,7 +151,7 @@ __device__ __forceinline__ void load_x2(const XSrc& xs, int lane_l, int st, f32x
 
 template <int KIND, int MODE, bool HALF, int P>
 struct StageB {
-  static __device__ __forceinline__ void run(const DpConvArgs& a, const XSrc& xs, int q, int lane, const u32x4 (&hid)[NB],
+  static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t wrs, const XSrc& xs, int q, int lane, const u32x4 (&hid)[NB],
                                              unsigned tl_base, unsigned dummy_base, const float* sS, f32x4 (&acc)[n_acc4<KIND>()],
                                              f32x2 (&xr)[2][3][4], NProfT& prof_prev) {
     using S = Spec<KIND>;
@@ -183,16 +183,18 @@ struct StageB {
           twr[tl] = (colv ? tl_base + (unsigned)((tl * TCOLS + c) * COLB) : dummy_base + (unsigned)(c * 8)) + (unsigned)(g * 128);
         // the supertile's W2 fragments (GEMM-B's A operands, 5 K chunks x MT) are requested NOW: a chunk is only 3-6 MFMAs of 16 cycles long, an L2
         // round trip under load several hundred cycles - requested inside GEMM-B they would stall every chunk; GEMM-A hides them
-        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w2n) + w2b_path_off<KIND>(P) + (size_t)(st * SUPER_CH * MT) * 256 + q * 64 + lane_l;
+        // (through a buffer resource: one VGPR offset per lane, the fragment's offset is wave-uniform - no 64-bit address arithmetic per load)
+        const unsigned wvoff = (unsigned)(q * 64 + lane_l) * 16u;
+        const unsigned wsoff = uni((unsigned)(w2b_path_off<KIND>(P) + st * (SUPER_CH * MT * 256)) * 16u);
         u32x4 wall[SUPER_CH][MT];
 #pragma unroll
         for (int ch = 0; ch < SUPER_CH; ++ch)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
 #if DP_BABL == 8
-            wall[ch][mt] = u32x4{(unsigned)(size_t)wsrc, (unsigned)ch, (unsigned)mt, 5u};
+            wall[ch][mt] = u32x4{wvoff, wsoff, (unsigned)ch, (unsigned)mt};
 #else
-            wall[ch][mt] = wsrc[(ch * MT + mt) * 256];
+            wall[ch][mt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff + (unsigned)((ch * MT + mt) * 256 * 16), 0);
 #endif
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -347,14 +349,14 @@ struct StageB {
         }
         NPROF(3);
       }
-      StageB<KIND, MODE, HALF, P + 1>::run(a, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr, prof_prev);
+      StageB<KIND, MODE, HALF, P + 1>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr, prof_prev);
     }
   }
 };
 
 // one pass (32 edge slots per node; HALF: 16) of one conv: stage the SH factors, GEMM1 -> hid (bf16 A fragments), then the path stages
 template <int KIND, int MODE, bool HALF>
-__device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t ers, const Grp& grp, const Wg& r, int et, int tid,
+__device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t ers, __amdgpu_buffer_rsrc_t wrs, const Grp& grp, const Wg& r, int et, int tid,
                                           float* s_T, float* s_S, const float* s_inv, f32x4 (&acc)[n_acc4<KIND>()], NProfT& prof_prev) {
   const int lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
   constexpr int NT2 = HALF ? 1 : 2;
@@ -517,11 +519,11 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_r
   const unsigned tl_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(q * TIMG_B);
   const unsigned dummy_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(4 * TIMG_B);
   NPROF(1);
-  StageB<KIND, MODE, HALF, 0>::run(a, xs, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0, prof_prev);
+  StageB<KIND, MODE, HALF, 0>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0, prof_prev);
 }
 
 // every pass of one conv of the (possibly fused) launch
-template <int KIND, int MODE>
+template <int KIND, int MODE, bool HALFOK>
 __device__ __forceinline__ void conv_bf16(const DpConvArgs& a, const Grp& grp, int tid, float* s_T, float* s_S, float* s_inv,
                                           f32x4 (&acc)[n_acc4<KIND>()], NProfT& prof_prev) {
   const Wg r = wg_of<MODE>(a, grp.pose);
@@ -538,14 +540,19 @@ __device__ __forceinline__ void conv_bf16(const DpConvArgs& a, const Grp& grp, i
   const int g_row0 = MODE == DP_EDGES_P2L ? r.p0 : r.l0;
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.gather_tab + (size_t)g_row0 * a.gather_stride, (unsigned)r.En * (unsigned)a.gather_stride * 4u);
   const __amdgpu_buffer_rsrc_t ers = make_rsrc(a.edge_emb_bf, (unsigned)(a.emb_flag_row + 1) * (unsigned)(EMB_ROW * 2));
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.w2n, (unsigned)w2b_quads<KIND>() * 16u);
 #pragma unroll 1
   for (int et = 0; et < n_et; ++et) {
-    if (r.En - 32 * et <= 16) pass_bf16<KIND, MODE, true>(a, xrs, ers, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev);
-    else pass_bf16<KIND, MODE, false>(a, xrs, ers, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev);
+    // HALFOK = false: the lean instantiation for launches in which no pose ends on a pass of <= 16 slots (DpConvArgs.no_tail on every conv, as
+    // for the other node-side kernels): without the half-pass body the kernel spills less
+    if constexpr (HALFOK) {
+      if (r.En - 32 * et <= 16) { pass_bf16<KIND, MODE, true>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev); continue; }
+    }
+    pass_bf16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev);
   }
 }
 
-template <int KIND, bool HAS_LL, int XMODE>
+template <int KIND, bool HAS_LL, int XMODE, bool HALFOK>
 #ifndef DP_WG_PER_CU
 #define DP_WG_PER_CU 2            // 1 = timing experiment: one wave per SIMD with the whole 512-register file (r5_experiments.md section 7)
 #endif
@@ -575,13 +582,13 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
   (void)prof_prev;
   NPROF(-1);
   if constexpr (HAS_LL) {
-    if (cx_only <= 0) conv_bf16<KIND, LL>(fa.conv[0], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
+    if (cx_only <= 0) conv_bf16<KIND, LL, HALFOK>(fa.conv[0], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
   }
   {
     const int c_lo = cx_only < 0 ? (HAS_LL ? 1 : 0) : (cx_only < (HAS_LL ? 1 : 0) ? n_conv_all : cx_only);
     const int c_hi = cx_only < 0 ? n_conv_all : (c_lo < n_conv_all ? c_lo + 1 : n_conv_all);
 #pragma unroll 1
-    for (int cx = c_lo; cx < c_hi; ++cx) conv_bf16<KIND, XMODE>(fa.conv[cx], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
+    for (int cx = c_lo; cx < c_hi; ++cx) conv_bf16<KIND, XMODE, HALFOK>(fa.conv[cx], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
   }
   // ---- sum the four k-partials, BatchNorm shift, residual stream (mean and BatchNorm scale are inside the operands) -----------------
   {
@@ -622,13 +629,16 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
 #endif
 }
 
-template <int KIND> int launch_bf16(const FusedArgs& fa, int xmode, hipStream_t st) {
+template <int KIND, bool HALFOK> int launch_bf16_h(const FusedArgs& fa, int xmode, hipStream_t st) {
   const DpConvArgs& a = fa.conv[0];
   const dim3 grid((unsigned)(a.B * a.slices * (fa.conv_split ? fa.n_ll + fa.n_x : 1))), block(256);
-  if (fa.n_ll) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, true, DP_EDGES_P2L>), grid, block, 0, st, fa);
-  else if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_P2L>), grid, block, 0, st, fa);
-  else hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_L2P>), grid, block, 0, st, fa);
+  if (fa.n_ll) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, true, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
+  else if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
+  else hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_L2P, HALFOK>), grid, block, 0, st, fa);
   return (int)hipGetLastError();
+}
+template <int KIND> int launch_bf16(const FusedArgs& fa, int xmode, hipStream_t st) {
+  return fa.lean ? launch_bf16_h<KIND, false>(fa, xmode, st) : launch_bf16_h<KIND, true>(fa, xmode, st);
 }
 
 }  // namespace dpb
