@@ -7,7 +7,7 @@ export PYTHONPATH=$PWD TMPDIR=/tmp
 mkdir -p gpurun_out
 ( python -m pytest tests -m gpu -q 2>&1 | tail -5 ) > gpurun_out/r5_gpu_suite.txt
 bash tools/profile_round.sh r5 > gpurun_out/r5_profile.log 2>&1
-bash tools/profile_config.sh r5_cfg5_bf16 5 > gpurun_out/r5_cfg5.log 2>&1
+bash tools/profile_round.sh r5_cfg5_bf16 --config 5 > gpurun_out/r5_cfg5.log 2>&1
 python tools/merge_traffic_record.py gpurun_out/r5_traffic_record.json $(ls gpurun_out/r5_cfg5_bf16_traffic_record.json 2>/dev/null)
 cp profiles/conv_hbm_traffic.json gpurun_out/conv_hbm_traffic.json
 python bench.py > gpurun_out/r5_bench_full.json 2> gpurun_out/r5_bench_full.err
