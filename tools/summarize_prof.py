@@ -24,10 +24,13 @@ for k in range(4):
             SLOTS[f"{kn}<{k}, true, 1, {h}>"] = [LIG3]
             SLOTS[f"{kn}<{k}, false, 1, {h}>"] = [LIG2]
             SLOTS[f"{kn}<{k}, false, 2, {h}>"] = [PH2]
-    for kn in ("tp_conv_node_bf16_kernel",):                  # precision="bf16": <KIND, HAS_LL, XMODE>
-        SLOTS[f"{kn}<{k}, true, 1>"] = [LIG3]
-        SLOTS[f"{kn}<{k}, false, 1>"] = [LIG2]
-        SLOTS[f"{kn}<{k}, false, 2>"] = [PH2]
+    for h in ("true", "false"):                               # precision="bf16": <KIND, HAS_LL, XMODE, HALFOK> (round 4: without HALFOK)
+        SLOTS[f"tp_conv_node_bf16_kernel<{k}, true, 1, {h}>"] = [LIG3]
+        SLOTS[f"tp_conv_node_bf16_kernel<{k}, false, 1, {h}>"] = [LIG2]
+        SLOTS[f"tp_conv_node_bf16_kernel<{k}, false, 2, {h}>"] = [PH2]
+    SLOTS[f"tp_conv_node_bf16_kernel<{k}, true, 1>"] = [LIG3]
+    SLOTS[f"tp_conv_node_bf16_kernel<{k}, false, 1>"] = [LIG2]
+    SLOTS[f"tp_conv_node_bf16_kernel<{k}, false, 2>"] = [PH2]
     for h in ("true", "false"):                               # the f16x3 node-side convs of an fp32 model: <KIND, HAS_LL, XMODE, HALFOK>
         SLOTS[f"tp_conv_node_f16_kernel<{k}, true, 1, {h}>"] = [LIG3]
         SLOTS[f"tp_conv_node_f16_kernel<{k}, false, 1, {h}>"] = [LIG2]
@@ -141,7 +144,7 @@ def main():
                     fa, wa = sum(f) / len(f), sum(w) / len(w)
                     res.append(f"{k},{sname},{len(f)},{fa:.1f},{wa:.1f},{2 * fa / 1024:.2f},{wa / 1024:.2f}")
                     if (k.startswith("tp_conv_node_kernel<3, true, 1, ")) or (k == "tp_conv_kernel<3>" and sname == "phore->lig") or \
-                            k == "tp_conv_node_bf16_kernel<3, true, 1>" or k.startswith("tp_conv_node_f16_kernel<3, true, 1, "):      # bench.py PROF_LAYER = 3
+                            k.startswith("tp_conv_node_bf16_kernel<3, true, 1") or k.startswith("tp_conv_node_f16_kernel<3, true, 1, "):      # bench.py PROF_LAYER = 3
                         rec = int((2 * fa + wa) * 1024)
         open(f"{a.prefix}_conv_hbm_traffic.csv", "w").write("\n".join(res) + "\n")
         if rec is not None and bench is not None:
