@@ -138,6 +138,28 @@ def test_conv_node_f16_neighbour_nan_does_not_leak():
     assert not torch.isfinite(got[lig_ptr[1]:lig_ptr[2]]).all()
 
 
+def test_conv_node_f16_out_of_range_features_fail_loudly_and_locally():
+    """the kernel's precondition: |gathered features| < 65504 (fp16's range; BatchNorm keeps real features at O(1-10)).  A value beyond it becomes
+    inf in the hi limb and NaN in the products: the pose that holds it comes out non-finite - never a silently wrong finite number - and the
+    poses packed around it are untouched (the status / screen() failure path then reports that pose)"""
+    base, ref, resid, dims, n_out, _ = _cross_case(1, "p2l", 79, [12, 20, 9], [20, 17, 40])
+    gt = base["gather_tab"].clone()
+    ph_ptr = base["ph_ptr"].cpu().numpy()
+    gt[ph_ptr[1] + 3, 25] = 1.0e5                                 # one vector component of one pharmacophore node of pose 1
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    keep = []
+    _run(dict(base, out=out, gather_tab=gt), keep)
+    got = out.cpu().double()
+    lig_ptr = base["lig_ptr"].cpu().numpy()
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    good = np.r_[0:lig_ptr[1], lig_ptr[2]:lig_ptr[3]]
+    assert torch.isfinite(got[good]).all()
+    assert (got[good] - want[good]).abs().max().item() / ref.abs().max().item() < TOL
+    bad = got[lig_ptr[1]:lig_ptr[2]]
+    assert not torch.isfinite(bad).all(dim=1).any(), "every atom of the pose gathers the out-of-range node (dense cross edges): all of its rows are flagged"
+
+
 def _ll_case(kind, seed, NL):
     g = torch.Generator().manual_seed(seed)
     sd = weights.init_state_dict(11)
