@@ -140,51 +140,79 @@ __global__ void static_pp_kernel(DpBatch b, DpWeights w, DpWork k) {
   store_row<NS>(k.pp_pre + (size_t)e * NS, pre);
 }
 
-// bf16 image of an embedded edge row for the DP_PREC_BF16 node-side conv (DpConvArgs.edge_emb_bf): 32 bf16 = features 0..19 | zeros; RNE
-__device__ __forceinline__ void store_row_bf16(uint16_t* __restrict__ dst, const float* v) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-#pragma unroll
-  for (int i = 0; i < 10; ++i) d[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, bf2));
-#pragma unroll
-  for (int i = 10; i < 16; ++i) d[i] = 0u;
-}
 // the flag row ("this edge does not exist": feature 20 = 1.0) behind the table's last row
 __device__ __forceinline__ void store_flag_row_bf16(uint16_t* __restrict__ tab, int n_rows, int tid) {
   if (tid < 32) tab[(size_t)n_rows * 32 + tid] = tid == 20 ? (uint16_t)0x3F80 : (uint16_t)0;
 }
-// two-limb fp16 image of an embedded edge row for the DP_PREC_F16X3 node-side conv: 64 fp16 = hi limbs (features 0..19 | zeros to 32) | lo limbs
-// (hi = rne16(v), lo = rne16(v - hi); the same split as dp_conv_node_f16_impl.h: split2)
-__device__ __forceinline__ void store_row_f16x2(uint16_t* __restrict__ dst, const float* v) {
+__device__ __forceinline__ void store_flag_row_f16x2(uint16_t* __restrict__ tab, int n_rows, int tid) {
+  if (tid < 64) tab[(size_t)n_rows * 64 + tid] = tid == 20 ? (uint16_t)0x3C00 : (uint16_t)0;
+}
+// The edge kernels hold ONE ROW PER THREAD in registers, rows of consecutive threads consecutive in memory.  A thread that stores its own 36- / 80- /
+// 128-byte row makes every store instruction of a wave touch 64 different cache lines (the 128-byte two-limb image had doubled both edge
+// kernels, 50 -> 102 us; staged: cross_edges_kernel 77 us, lig_edges_kernel 92 us - that one is bound by its dependent gathers).  rows_store stages the workgroup's rows in LDS ([256][ROW | 1] dwords: an odd stride, conflict-free) and writes them back
+// as dwords in memory order - 256 contiguous bytes per wave and instruction.  n_rows = live rows of the workgroup (a prefix of its threads),
+// dst = the row of thread 0.  Every thread of the workgroup must call it (two workgroup barriers).
+constexpr int ROWBUF_DWORDS = 256 * 33;
+template <int ROW>
+__device__ __forceinline__ void rows_store(uint32_t* __restrict__ sbuf, int tid, const uint32_t (&v)[ROW], int n_rows, uint32_t* __restrict__ dst) {
+  constexpr int RP = ROW | 1;
+  static_assert(256 * RP <= ROWBUF_DWORDS, "row buffer");
+#pragma unroll
+  for (int i = 0; i < ROW; ++i) sbuf[tid * RP + i] = v[i];
+  __syncthreads();
+  const int total = n_rows * ROW;
+#pragma unroll
+  for (int it = 0; it < ROW; ++it) {
+    const int j = it * 256 + tid;
+    if (j < total) {
+      const int r = j / ROW, c = j - r * ROW;
+      dst[j] = sbuf[r * RP + c];
+    }
+  }
+  __syncthreads();
+}
+template <int N>
+__device__ __forceinline__ void rows_store_f32(uint32_t* __restrict__ sbuf, int tid, const float (&v)[N], int n_rows, float* __restrict__ dst) {
+  uint32_t u[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) u[i] = __builtin_bit_cast(uint32_t, v[i]);
+  rows_store<N>(sbuf, tid, u, n_rows, reinterpret_cast<uint32_t*>(dst));
+}
+// the 16-bit image of an embedded edge row as dwords: two fp16 limbs (32 dwords = 128 bytes: hi limbs of features 0..19 | zeros to 32 | lo limbs |
+// zeros; hi = rne16(v), lo = rne16(v - hi): the same split as dp_conv_node_f16_impl.h split2) or bf16 (16 dwords = 64 bytes)
+__device__ __forceinline__ void row_image_f16x2(const float* v, uint32_t (&u)[32]) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-  uint32_t hi[12], lo[12];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) u[i] = 0u;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
     const h2 h = __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, h2);
     const h2 l = __builtin_convertvector((f2){v[2 * i] - (float)h[0], v[2 * i + 1] - (float)h[1]}, h2);
-    hi[i] = __builtin_bit_cast(uint32_t, h);
-    lo[i] = __builtin_bit_cast(uint32_t, l);
+    u[i] = __builtin_bit_cast(uint32_t, h);
+    u[16 + i] = __builtin_bit_cast(uint32_t, l);
   }
-  hi[10] = hi[11] = lo[10] = lo[11] = 0u;
-  u4* d = reinterpret_cast<u4*>(dst);                    // 128-byte rows of a 256-byte aligned table: eight 16-byte stores
+}
+__device__ __forceinline__ void row_image_bf16(const float* v, uint32_t (&u)[16]) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    d[i] = u4{hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
-    d[4 + i] = u4{lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]};
+  for (int i = 0; i < 10; ++i) u[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){v[2 * i], v[2 * i + 1]}, bf2));
+#pragma unroll
+  for (int i = 10; i < 16; ++i) u[i] = 0u;
+}
+// the workgroup's rows of the 16-bit image (DpWork.node_f16, as dp_forward sets it in the kernels' copy of the workspace: which image the
+// node-side convs of this forward read); row0 = the row of thread 0
+__device__ __forceinline__ void rows_store_16(uint32_t* __restrict__ sbuf, int tid, const float* v, int n_rows, uint16_t* __restrict__ tab, size_t row0, int f16) {
+  if (f16) {
+    uint32_t u[32];
+    row_image_f16x2(v, u);
+    rows_store<32>(sbuf, tid, u, n_rows, reinterpret_cast<uint32_t*>(tab + row0 * 64));
+  } else {
+    uint32_t u[16];
+    row_image_bf16(v, u);
+    rows_store<16>(sbuf, tid, u, n_rows, reinterpret_cast<uint32_t*>(tab + row0 * 32));
   }
-  d[3] = u4{0u, 0u, 0u, 0u};
-  d[7] = u4{0u, 0u, 0u, 0u};
-}
-__device__ __forceinline__ void store_flag_row_f16x2(uint16_t* __restrict__ tab, int n_rows, int tid) {
-  if (tid < 64) tab[(size_t)n_rows * 64 + tid] = tid == 20 ? (uint16_t)0x3C00 : (uint16_t)0;
-}
-// DpWork.node_f16 (as dp_forward sets it in the kernels' copy of the workspace): which 16-bit image the node-side convs of this forward read
-__device__ __forceinline__ void store_row_16(uint16_t* __restrict__ tab, size_t row, const float* v, int f16) {
-  if (f16) store_row_f16x2(tab + row * 64, v);
-  else store_row_bf16(tab + row * 32, v);
 }
 __device__ __forceinline__ void store_flag_row_16(uint16_t* __restrict__ tab, int n_rows, int tid, int f16) {
   if (f16) store_flag_row_f16x2(tab, n_rows, tid);
@@ -284,6 +312,7 @@ __global__ __launch_bounds__(256) void lig_graph_kernel(DpBatch b, DpWork k) {
 // on the pose's one workgroup.)
 __global__ __launch_bounds__(256) void lig_edges_kernel(DpBatch b, DpWeights w, DpWork k, int slices) {
   __shared__ float s_c0[NS];
+  __shared__ uint32_t s_rows[ROWBUF_DWORDS];
   const int p = blockIdx.x / slices, slice = blockIdx.x % slices, tid = threadIdx.x;
   const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
   if (N <= 0) return;
@@ -299,26 +328,32 @@ __global__ __launch_bounds__(256) void lig_edges_kernel(DpBatch b, DpWeights w, 
     s_c0[tid] = a;
   }
   __syncthreads();
-  for (int e = slice * 256 + tid; e < E; e += slices * 256) {
-    const int o = base + e;
+  // (every thread runs every round - the row stores are workgroup-wide - a thread past the pose's last edge recomputes that edge and stores nothing)
+  for (int e0 = slice * 256; e0 < E; e0 += slices * 256) {
+    const bool live = e0 + tid < E;
+    const int n_rows = E - e0 < 256 ? E - e0 : 256;
+    const int o = base + (live ? e0 + tid : E - 1);
+    const size_t o0 = (size_t)(base + e0);
     const int packed = k.ll_src[o];
     const int bt = (packed >> 28) & 7, src = packed & 0x0fffffff, dst = k.ll_nbr[o];
-    k.ll_src[o] = src;
-    if (pairs) (bt < 4 ? k.ll_pair_bond : k.ll_pair_rad)[pr0 + (src - l0) * N + (dst - l0)] = o;    // pair tables of the node-side lig-lig conv
+    if (live) {
+      k.ll_src[o] = src;
+      if (pairs) (bt < 4 ? k.ll_pair_bond : k.ll_pair_rad)[pr0 + (src - l0) * N + (dst - l0)] = o;    // pair tables of the node-side lig-lig conv
+    }
     const float vx = b.pos[(size_t)dst * 3] - b.pos[(size_t)src * 3];
     const float vy = b.pos[(size_t)dst * 3 + 1] - b.pos[(size_t)src * 3 + 1];
     const float vz = b.pos[(size_t)dst * 3 + 2] - b.pos[(size_t)src * 3 + 2];
     float sh[9];
     sh9(vx, vy, vz, sh);
-    store_row<9>(k.ll_sh + (size_t)o * 9, sh);
+    rows_store_f32<9>(s_rows, tid, sh, n_rows, k.ll_sh + o0 * 9);
     float g[NS], h[NS], out[NS];
     gauss20(sqrtf(vx * vx + vy * vy + vz * vz), w.lig_gauss_mu, w.lig_gauss_coeff, g);
 #pragma unroll
     for (int c = 0; c < NS; ++c) h[c] = s_c0[c] + (bt < 4 ? w.lig_edge.w0[c * 44 + bt] : 0.f);
     matvec_acc<NS, NS>(w.lig_edge.w0, 44, 24, g, h);
     mlp_tail20(w.lig_edge, h, out);
-    store_row<NS>(k.ll_emb + (size_t)o * NS, out);
-    if (k.ll_emb_bf) store_row_16(k.ll_emb_bf, (size_t)o, out, k.node_f16);
+    rows_store_f32<NS>(s_rows, tid, out, n_rows, k.ll_emb + o0 * NS);
+    if (k.ll_emb_bf) rows_store_16(s_rows, tid, out, n_rows, k.ll_emb_bf, o0, k.node_f16);
   }
 }
 
@@ -390,6 +425,7 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
   __shared__ float s_cs[NS];
   __shared__ float s_ew[256];                   // exp(total_weight) of the workgroup's edges, in edge order
   __shared__ float s_den[256];
+  __shared__ uint32_t s_rows[ROWBUF_DWORDS];
   const int p = blockIdx.x / slices, slice = blockIdx.x % slices, tid = threadIdx.x;
   const int l0g = b.lig_ptr[p], NLp = b.lig_ptr[p + 1] - l0g, p0 = b.ph_ptr[p], NP = b.ph_ptr[p + 1] - p0;
   if (k.x_emb_bf && blockIdx.x == 0) store_flag_row_16(k.x_emb_bf, b.n_x, tid, k.node_f16);
@@ -446,7 +482,8 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
     s_den[tid] = s;
   }
   __syncthreads();
-  if (!live) return;
+  // (no early exit: the row stores below are workgroup-wide - a thread without an edge recomputes edge 0 and stores nothing)
+  const size_t r0 = (size_t)x0;
   // edge embedding: Linear(73,20) on [sigma emb | gauss | P], ReLU, Linear(20,20)
   {
     float h[NS], out[NS];
@@ -455,8 +492,8 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
     for (int c = 0; c < NS; ++c) h[c] = pre[c] + s_cs[c];
     matvec_acc<NS, NS>(w.x_edge.w0, 73, 20, g, h);
     mlp_tail20(w.x_edge, h, out);
-    store_row<NS>(k.x_emb + (size_t)(x0 + e) * NS, out);
-    if (k.x_emb_bf) store_row_16(k.x_emb_bf, (size_t)(x0 + e), out, k.node_f16);
+    rows_store_f32<NS>(s_rows, tid, out, E, k.x_emb + r0 * NS);
+    if (k.x_emb_bf) rows_store_16(s_rows, tid, out, E, k.x_emb_bf, r0, k.node_f16);
   }
   // sign rule (:813-816) and softmax weight (:839,:845-848)
   {
@@ -469,7 +506,7 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
     vx = vx * dir * aw; vy = vy * dir * aw; vz = vz * dir * aw;
     float sh[9];
     sh9(vx, vy, vz, sh);
-    store_row<9>(k.x_sh + (size_t)(x0 + e) * 9, sh);
+    rows_store_f32<9>(s_rows, tid, sh, E, k.x_sh + r0 * 9);
   }
   // normal-vector rule (:874-889); only the phore's own type can agree (phoretype is one-hot)
   {
@@ -490,7 +527,7 @@ __global__ __launch_bounds__(256) void cross_edges_kernel(DpBatch b, DpWeights w
     const float dl = fabsf(d2) < fabsf(d1) ? d2 : d1;
     float sh[9];
     sh9(rx * dl, ry * dl, rz * dl, sh);
-    store_row<9>(k.x_nsh + (size_t)(x0 + e) * 9, sh);
+    rows_store_f32<9>(s_rows, tid, sh, E, k.x_nsh + r0 * 9);
   }
 }
 
