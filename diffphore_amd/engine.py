@@ -364,7 +364,7 @@ class _GraphView:
     complex's own tensors wherever they already are) + the C struct pointing at them.  Cached on the graph object and shared by its samples
     (`HeteroData.sample_copy` copies the attribute); `key` = identity + in-place version of every source object, re-checked once per device
     batch, so a replaced or in-place edited static tensor rebuilds the view."""
-    __slots__ = ("struct", "addr", "keep", "key", "n", "src")
+    __slots__ = ("struct", "addr", "keep", "key", "n", "src", "_tver", "_other")
 
     # The view holds a ctypes struct of raw pointers: it is a cache, never state.  A pickled / deep-copied graph simply carries no view (None)
     # and rebuilds it at its next packing - torch.save, multiprocessing hand-off and copy.deepcopy of a packed graph keep working.
@@ -387,23 +387,43 @@ class _GraphView:
                 P.phoretype, PP.edge_index)
 
     @staticmethod
+    def _ver(v):
+        if hasattr(v, "_version"):
+            return v._version
+        if isinstance(v, np.ndarray):
+            return hash(v.tobytes())
+        if isinstance(v, (list, tuple)):
+            return hash(tuple(_GraphView._ver(x) for x in v))
+        return 0
+
+    @staticmethod
     def key_of(src):
         # identity of every source object + the in-place version counter of the tensors among them; sources without a version counter (the
         # reference keeps mask_rotate as an ndarray or a list of them) are hashed by content, as score_model._cheap_key does
-        def ver(v):
-            if hasattr(v, "_version"):
-                return v._version
-            if isinstance(v, np.ndarray):
-                return hash(v.tobytes())
-            if isinstance(v, (list, tuple)):
-                return hash(tuple(ver(x) for x in v))
-            return 0
+        ver = _GraphView._ver
         return tuple([id(v) for v in src]) + tuple([ver(v) for v in src])
+
+    def valid_for(self, src):
+        """key_of(src) == self.key without building the key (the re-check that runs once per complex and device batch: 13 sources x 512
+        complexes; `self.src` keeps the cached objects alive, so identity is what the ids in the key compare)"""
+        s0 = self.src
+        for i, v0 in self._tver:                       # tensors: same object, same in-place version
+            v = src[i]
+            if v is not s0[i] or v._version != v0:
+                return False
+        for i, h0 in self._other:                      # sources without a version counter: same object, same content
+            v = src[i]
+            if v is not s0[i] or self._ver(v) != h0:
+                return False
+        return True
 
     def __init__(self, g):
         src = self.sources(g)
         self.key = self.key_of(src)
         self.src = src                                  # keeps the source objects alive: their ids (part of the key) cannot be recycled
+        vers = self.key[len(src):]
+        self._tver = tuple((i, vers[i]) for i, v in enumerate(src) if hasattr(v, "_version"))
+        self._other = tuple((i, vers[i]) for i, v in enumerate(src) if not hasattr(v, "_version"))
         x, ei, ea, em, mr, fp, na1, na2, px, ppos, pnorm, ptype, pei = src
 
         def T(v, dt, shape=None):
@@ -444,9 +464,16 @@ class _GraphView:
         """the (cached) view of `g`'s complex; `checked`: views already validated for this device batch, `by_key`: the batch's views by
         source key (samples of one complex that were copied before any of them was packed find each other here)"""
         gv = getattr(g, "_dp_view", None)
-        if gv is not None and id(gv) in checked:
-            return gv
-        key = cls.key_of(cls.sources(g))
+        src = None
+        if gv is not None:
+            if id(gv) in checked:
+                return gv
+            src = cls.sources(g)
+            if gv.valid_for(src):
+                by_key[gv.key] = gv
+                checked.add(id(gv))
+                return gv
+        key = cls.key_of(src if src is not None else cls.sources(g))
         if gv is None or gv.key != key:
             gv = by_key.get(key)
             if gv is None:
