@@ -25,6 +25,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in the header but not exported"
 
 
+def test_committed_traffic_records_match_the_kernel_sources():
+    """bench.py quotes `roofline.traffic` only from a PMC record taken on the SAME kernel sources (profiles/conv_hbm_traffic.json, keyed by
+    build.source_hash()): a kernel edit - even a comment - without a new tools/gpu_round5_final3.sh run would make the driver's bench line say
+    traffic: null.  Records for the headline workload (config 2, f32) and the bf16 workload (config 5)."""
+    import json
+    import os
+    from diffphore_amd.csrc import build
+    recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "conv_hbm_traffic.json")))
+    h = build.source_hash()
+    mine = {(r["config"], r["precision"]) for r in recs if r["source_hash"] == h}
+    assert (2, "f32") in mine and (5, "bf16") in mine, f"no PMC traffic record for kernel sources {h}: re-run tools/gpu_round5_final3.sh and commit profiles/"
+
+
 def test_build_identity_and_ablation_builds_are_refused(monkeypatch):
     """dp_build_info: the product build carries no ablation / profiling switch and the hash of the sources it was compiled from (the hash
     bench.py keys PMC profiles with); `_lib.lib()` refuses a library that reports an ablation switch unless DIFFPHORE_ALLOW_ABLATION=1."""
