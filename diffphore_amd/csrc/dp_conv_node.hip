@@ -402,10 +402,8 @@ static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, flo
   for (int i = 0; i < n; ++i)
     if (!convs[i].no_tail) fa.lean = 0;
   if (!convs[0].out) return DP_E_BADARG;
-  const bool bf = convs[0].precision == DP_PREC_BF16;
-  if (bf || convs[0].precision == DP_PREC_F16X3) {        // one instantiation, no path split; the bf16 kernel knows the conv split (below)
+  if (convs[0].precision == DP_PREC_BF16 || convs[0].precision == DP_PREC_F16X3) {        // the 16-bit kernels: no path split; conv split below
     for (int i = 0; i < n; ++i) fa.conv[i].path_split = 0;
-    if (!bf || part == nullptr) return dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
   }
   if (part == nullptr) return dpn::launch_kind(convs[0].kind, fa, xmode, (hipStream_t)stream);
   fa.conv_split = 1;

@@ -688,7 +688,12 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(Fus
   using S = Spec<KIND>;
   static_assert(4 * NB * S::D_OUT <= 4 * TIMG_F, "reduction scratch fits in the T images");
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
-  const Grp grp = grp_of8(fa.conv[0], (int)blockIdx.x);
+  // conv split (small batches: FusedArgs.conv_split, as in the other node-side kernels): blockIdx = conv * groups + group, this workgroup runs ONE
+  // conv of the launch and leaves its un-scaled sum in part[conv][node]; shifts, residual and the sum over convs are dp_conv_node_combine's
+  const int groups = fa.conv[0].B * fa.conv[0].slices * 2;
+  const int bid = fa.conv_split ? (int)blockIdx.x % groups : (int)blockIdx.x;
+  const int cx_only = fa.conv_split ? (int)blockIdx.x / groups : -1;
+  const Grp grp = grp_of8(fa.conv[0], bid);
   if (grp.n_loc <= 0) return;
   f32x4 acc[n_acc4<KIND>()];
 #pragma unroll
@@ -698,11 +703,18 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(Fus
   float w_min = w2_exponent(fa.conv[0]);
   for (int k = 1; k < n_conv; ++k) w_min = fminf(w_min, w2_exponent(fa.conv[k]));
   const float s_exp = w_min + (float)A0;
-  if constexpr (HAS_LL) conv_f16<KIND, LL, HALFOK>(fa.conv[0], grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(fa.conv[0]))), s_T, s_S, s_X, s_inv, acc);
+  if constexpr (HAS_LL) {
+    if (cx_only <= 0) conv_f16<KIND, LL, HALFOK>(fa.conv[0], grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(fa.conv[0]))), s_T, s_S, s_X, s_inv, acc);
+  }
+  {
+    constexpr int X0 = HAS_LL ? 1 : 0;
+    const int c_lo = cx_only < 0 ? X0 : (cx_only < X0 ? n_conv : cx_only);
+    const int c_hi = cx_only < 0 ? n_conv : (c_lo < n_conv ? c_lo + 1 : n_conv);
 #pragma unroll 1
-  for (int cx = 0; cx < fa.n_x; ++cx) {
-    const DpConvArgs& a = fa.conv[(HAS_LL ? 1 : 0) + cx];
-    conv_f16<KIND, XMODE, HALFOK>(a, grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(a))), s_T, s_S, s_X, s_inv, acc);
+    for (int cx = c_lo; cx < c_hi; ++cx) {
+      const DpConvArgs& a = fa.conv[cx];
+      conv_f16<KIND, XMODE, HALFOK>(a, grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(a))), s_T, s_S, s_X, s_inv, acc);
+    }
   }
   // ---- sum the four k-partials and the two limb halves of the node slots, un-scale, BatchNorm shift, residual stream ----------------------
   {
@@ -717,11 +729,11 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(Fus
       const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
       const int node = grp.n_lo + (live ? n : 0);
       float sh = 0.f;
-      for (int k = 0; k < n_conv; ++k) sh += fa.conv[k].bn_shift[live ? ch : 0];
+      for (int k = 0; k < (cx_only < 0 ? n_conv : 0); ++k) sh += fa.conv[k].bn_shift[live ? ch : 0];
       eb[it] = sh;
       const float* src = a.accumulate ? a.out + (size_t)node * a.out_stride + (live ? ch : 0)
                                       : (a.resid != nullptr && live && ch < a.resid_width ? a.resid + (size_t)node * a.resid_stride + ch : nullptr);
-      er[it] = (live && src != nullptr) ? *src : 0.f;
+      er[it] = (live && src != nullptr && cx_only < 0) ? *src : 0.f;
     }
     __syncthreads();
     AccStore<KIND, 0>::run(acc, s_T + q * (NB * S::D_OUT), lane);
@@ -734,14 +746,15 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(Fus
       constexpr int WS = NB * S::D_OUT, LO = NBH * S::D_OUT;        // wave stride; offset of the lo-limb node slots
       const float lo = ((s_T[LO + i] + s_T[WS + LO + i]) + s_T[2 * WS + LO + i]) + s_T[3 * WS + LO + i];
       const float hi = ((s_T[i] + s_T[WS + i]) + s_T[2 * WS + i]) + s_T[3 * WS + i];
-      a.out[(size_t)(grp.n_lo + n) * a.out_stride + ch] = er[it] + ((hi + lo) * oscale + eb[it]);
+      if (cx_only < 0) a.out[(size_t)(grp.n_lo + n) * a.out_stride + ch] = er[it] + ((hi + lo) * oscale + eb[it]);
+      else fa.part[(size_t)cx_only * fa.part_stride + (size_t)(grp.n_lo - fa.node0 + n) * a.out_stride + ch] = (hi + lo) * oscale;
     }
   }
 }
 
 template <int KIND, bool HALFOK> int launch_f16_h(const FusedArgs& fa, int xmode, hipStream_t st) {
   const DpConvArgs& a = fa.conv[0];
-  const dim3 grid((unsigned)(a.B * a.slices * 2)), block(256);
+  const dim3 grid((unsigned)(a.B * a.slices * 2 * (fa.conv_split ? fa.n_ll + fa.n_x : 1))), block(256);
   if (fa.n_ll) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, true, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
   else if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
   else hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_L2P, HALFOK>), grid, block, 0, st, fa);

@@ -722,11 +722,20 @@ int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream) {
   return (int)hipGetLastError();
 }
 
-// Path split (two workgroups per 16-node group + one workgroup per conv, fp32 kernels only) for launches that cannot fill the chip.  With the
-// two-limb fp16 kernel available (8-node groups = twice the workgroups, ~1.5x shorter) the split only pays for the smallest batches
-// (profiles/r5_batch_sweep.csv, 30-atom ligands: 40 poses 0.96 -> 0.75 ms per step, 128 poses 1.84 -> 1.20 with the unsplit f16x3 launches; 8-20 poses
-// 0.68-0.71 either way)
+// Small batches: launches that cannot fill the chip (256 CUs x 2 workgroup slots).
+//  * fp32 / bf16 node-side kernels (16-node groups): path split (fp32 only: two workgroups per group, half of the paths each) + conv split (one
+//    workgroup per conv of the fused launch, dp_conv_node_combine adds them up) while B x groups <= 256;
+//  * the two-limb fp16 kernel (8-node groups: twice the workgroups to begin with, ~1.5x shorter passes): conv split while the FUSED launch would
+//    have at most DP_F16_CSPLIT_MAX_WG workgroups; with it the fp32 split kernels are no longer the default of an fp32 model at any batch size.
+//    ms per step, 30-atom ligands / 32 phore nodes, best driver (profiles/r5_batch_sweep.csv; before = fp32 split kernels up to 24 poses, unsplit
+//    f16x3 launches beyond): 1 pose 0.570 -> 0.468, 8: 0.622 -> 0.490, 20: 0.698 -> 0.527, 40: 0.697 -> 0.651, 64: 0.838 -> 0.793, 96: 1.036 -> 0.991,
+//    128 (512 workgroups per fused launch): 1.11 either way.  The two sides of a layer run side by side: the gain is large while BOTH split
+//    launches fit the chip at once (<= 25 poses of this shape) and small beyond.
 static int node_path_split_auto(int B, int slices, bool f16_avail) { return (long long)B * slices <= (f16_avail ? 48 : 256) ? 1 : 0; }
+#ifndef DP_F16_CSPLIT_MAX_WG
+#define DP_F16_CSPLIT_MAX_WG 384
+#endif
+static int node_f16_conv_split_auto(int B, int slices16) { return (long long)B * slices16 * 2 <= DP_F16_CSPLIT_MAX_WG ? 1 : 0; }
 // which formulation the convs of a forward take (shared by dp_forward and dp_forward_launch_of)
 static bool plan_node_side(const DpBatch* b, const DpWeights* w, const DpWork* k) {
   return dp_resolve_conv_algo(k->conv_algo, w->precision, b->B) == DP_ALGO_NODE && w->p2l_conv[0].w2n != nullptr;
@@ -788,7 +797,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   // those images; the kernel has no path-split / conv-split form, so launches that take the path split (small batches) stay on the fp32 kernel
   const int nb_ = dp_conv_node_max_nodes();
   const bool f16_ok = node_side && w->precision == DP_PREC_F32 && k->node_f16 != 0 && w->p2l_conv[0].w2h != nullptr && k->x_emb_bf != nullptr;
-  auto split_of = [&](int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B, slices_, f16_ok)); };
+  auto split_of = [&](int slices_) {
+    return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(B, slices_, f16_ok)));
+  };
   const bool f16_lig = f16_ok && !split_of((b->max_nl + nb_ - 1) / nb_) && (!node_ll || (w->lig_conv[0].w2h != nullptr && k->ll_emb_bf != nullptr));
   const bool f16_ph = f16_ok && !split_of((b->max_np + nb_ - 1) / nb_);
   // the 16-bit images of the edge embeddings are written only for the convs that read them (DP_PREC_BF16 or DP_PREC_F16X3, node-side)
@@ -825,7 +836,11 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while (B * slices < 512 && slices < 8) ++slices;
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
-  auto node_path_split = [&](int B_, int slices_) { return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : node_path_split_auto(B_, slices_, f16_ok)); };
+  auto node_path_split = [&](int B_, int slices_) {
+    return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(B_, slices_, f16_ok)));
+  };
+  // f16x3 launches: DpConvArgs.path_split only asks for the conv split (the kernel has no path split)
+  auto f16_csplit = [&](int slices_) { return k->path_split == 0 ? node_f16_conv_split_auto(B, slices_) : 0; };
   // the convs that stay edge-side in an fp32 model (phore-phore, torsion bonds) take the two-limb fp16 form of their radial contraction when the
   // blob carries it (DpConvW.w2x / bn_scale_x; until round 4: the 3-way bf16 split): same tolerances, 16x the matrix rate per product
   const bool edge_x6 = w->precision == DP_PREC_F32 && k->edge_bf16x6 != 0;
@@ -899,7 +914,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.no_tail = b->no_tail_nl;
         c.path_split = node_path_split(B, slices_pl);
         c.pair_a = k->ll_pair_rad; c.pair_b = k->ll_pair_bond; c.pair_ptr = b->llp_ptr;
-        if (f16_lig) { c.precision = DP_PREC_F16X3; c.w1n = w->lig_conv[l].w1h; c.w2n = w->lig_conv[l].w2h; }
+        if (f16_lig) { c.precision = DP_PREC_F16X3; c.w1n = w->lig_conv[l].w1h; c.w2n = w->lig_conv[l].w2h; c.path_split = f16_csplit(slices_pl); }
       }
     }
     for (int nv = 0; nv < 2; ++nv) {
@@ -912,7 +927,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.out = hl2; c.accumulate = 1;
       if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); c.no_tail = b->no_tail_np;
                        c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x;
-                       if (f16_lig) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; } }
+                       if (f16_lig) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; c.path_split = f16_csplit(slices_pl); } }
     }
     if (node_side && fuse && node_ll && k->conv_fuse != 2) {
       // one launch: the three convs scatter onto the same atoms and their outputs add up (:703-706)
@@ -948,7 +963,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.out = hp2; c.accumulate = 1;
         if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); c.no_tail = b->no_tail_nl;
                          c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x;
-                         if (f16_ph) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; } }
+                         if (f16_ph) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; c.path_split = f16_csplit(slices_lp); } }
       }
       if (node_side && fuse) {
         if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);

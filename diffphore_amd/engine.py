@@ -903,14 +903,15 @@ class Engine:
                 pass
 
     def path_split_on(self) -> bool:
-        """whether the ligand-side node-side launches of this batch take the path split (dp_graph.hip: node_path_split_auto - two workgroups per
-        node group while B x groups <= 256, <= 48 when the f16x3 kernel is available); such launches run the exact-fp32 kernel even with
-        DpWork.node_f16 = 1"""
+        """whether the ligand-side node-side launches of this batch take the fp32 kernels' path split (dp_graph.hip: two workgroups per node group
+        while B x groups <= 256; such launches run the exact-fp32 kernel even with DpWork.node_f16 = 1).  With the f16x3 kernel available the
+        library never chooses it by itself (that kernel has its own small-batch form, the conv split): only DIFFPHORE_PATH_SPLIT=1 does."""
         ps = int(self.ws.struct.path_split)
         if ps:
             return ps == 1
-        f16 = self.node_side_convs == "f16x3"
-        return self._ps_B * ((self._ps_nl + 15) // 16) <= (48 if f16 else 256)
+        if self.node_side_convs == "f16x3":
+            return False
+        return self._ps_B * ((self._ps_nl + 15) // 16) <= 256
 
     def launch_of(self, layer: int, conv: int):
         """(first, count, node_side) of the dp_forward launch that carries conv `conv` of interaction layer `layer` (conv numbering of

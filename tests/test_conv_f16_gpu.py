@@ -284,6 +284,23 @@ def test_conv_node_f16_fused_ligand_side(kind):
     err = (got - want).abs().max().item() / scale
     print(f"kind {kind} fused ligand side: f16x3 vs fp64 oracle {err:.2e}")
     assert err < TOL, err
+    # conv split (the small-batch form: one conv per workgroup, dp_conv_node_combine adds them up): the same limb products per conv, the three
+    # un-scaled sums added in fp32 outside the accumulators; bit-identical reruns; the convs keep their different exponents
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    part = torch.zeros(3 * N * dims["d_out"], device="cuda")
+    outs = []
+    for rep in range(2):
+        out_s = torch.full((N, dims["d_out"]), float("nan")).cuda()
+        for i in range(3):
+            arr[i].out, arr[i].path_split = out_s.data_ptr(), 1
+        _lib.check(L.dp_tp_conv_node_fused_split(arr, 3, N, part.data_ptr(), part.numel(), st), "dp_tp_conv_node_fused_split (f16x3)")
+        torch.cuda.synchronize()
+        outs.append(out_s.cpu())
+    assert torch.equal(outs[0], outs[1])
+    err_s = (outs[0].double() - want).abs().max().item() / scale
+    err_f = (outs[0].double() - got).abs().max().item() / scale
+    print(f"kind {kind} ligand side, conv split: vs fp64 oracle {err_s:.2e}, vs the fused launch {err_f:.2e}")
+    assert err_s < TOL and err_f < 1e-6, (err_s, err_f)
 
 
 @pytest.mark.parametrize("kind,mode", [(1, "p2l"), (3, "p2l"), (2, "l2p")])

@@ -85,19 +85,21 @@ def test_config_workload_matches_oracle(cfg_id, precision, tol, monkeypatch):
 # fp64 oracle with the same start poses and noise.  Measured on MI355X (printed by the test, profiles/r5_configs4_100step.txt), max over the 6 poses
 # after 20 / 100 steps:   f32 (library default: f16x3 node-side + split edge-side convs) 9.3e-5 / 8.9e-5;  f32-f16x3 (f16x3 node-side convs, exact
 # fp32 edge-side) and f32-exact (exact fp32 MFMA everywhere): see the profile;  bf16x3 9.5e-5 / 9.1e-5;  bf16 7.4e-4 / 1.6e-3.
-# (One pose of the six sits at 9e-5 from step 20 on in every arm that runs the phore-phore convs as a bf16 split, and at 8e-6 in the exact arm;
-# the other five stay below 5.4e-5 over all 100 steps.)
-FULL_RUN_BOUNDS = {"f32": (1.5e-4, 3e-4), "f32-f16x3": (1.5e-4, 3e-4), "f32-exact": (5e-5, 1e-4), "f32-small": (1.5e-4, 3e-4), "bf16x3": (1.5e-4, 3e-4),
-                   "bf16": (2.5e-3, 5e-3)}
-# environment of the fp32 arms: DIFFPHORE_NODE_F16 (two-limb fp16 node-side kernel), DIFFPHORE_EDGE_X6 (fp32-grade operand split of the edge-side convs), DIFFPHORE_PATH_SPLIT=0
-# (these 6 poses would otherwise take the small-batch path split, i.e. the exact-fp32 node-side kernels): "f32" = what a LARGE batch of an fp32
-# model runs by default (f16x3 node-side + split edge-side), "f32-f16x3" = the f16x3 kernel alone beside exact-fp32 edge-side convs, "f32-exact" =
-# fp32 MFMA everywhere, "f32-small" = the library's own choice for this 6-pose batch (fp32 path-split node-side kernels + split edge-side)
+# (One pose of the six sits on a discrete decision that some perturbations flip within the first 20 steps - it then stays at 9e-5 for the other 80 -
+# and others do not: both f16x3 arms and the exact arm end at 4-5e-5, the other five poses stay below 5.4e-5 in every arm.)
+FULL_RUN_BOUNDS = {"f32": (1.5e-4, 3e-4), "f32-f16x3": (1.5e-4, 3e-4), "f32-exact": (5e-5, 1e-4), "f32-small": (1.5e-4, 3e-4), "f32-pathsplit": (1.5e-4, 3e-4),
+                   "bf16x3": (1.5e-4, 3e-4), "bf16": (2.5e-3, 5e-3)}
+# environment of the fp32 arms: DIFFPHORE_NODE_F16 (two-limb fp16 node-side kernel), DIFFPHORE_EDGE_X6 (fp32-grade operand split of the edge-side
+# convs), DIFFPHORE_PATH_SPLIT.  "f32" = what a LARGE batch of an fp32 model runs by default (f16x3 node-side kernel in fused launches - forced with
+# DIFFPHORE_PATH_SPLIT=0 - + f16x3 edge-side), "f32-f16x3" = that node-side kernel beside exact-fp32 edge-side convs, "f32-exact" = fp32 MFMA
+# everywhere, "f32-small" = the library's own choice for this 6-pose batch (the f16x3 node-side kernel with its conv split + f16x3 edge-side),
+# "f32-pathsplit" = the exact-fp32 path-split / conv-split node-side kernels (the small-batch default until the f16x3 kernel had a conv split;
+# DIFFPHORE_PATH_SPLIT=1) + f16x3 edge-side
 FP32_ARMS = {"f32": {"DIFFPHORE_PATH_SPLIT": "0"}, "f32-f16x3": {"DIFFPHORE_PATH_SPLIT": "0", "DIFFPHORE_EDGE_X6": "0"},
-             "f32-exact": {"DIFFPHORE_NODE_F16": "0", "DIFFPHORE_EDGE_X6": "0"}, "f32-small": {}}
+             "f32-exact": {"DIFFPHORE_NODE_F16": "0", "DIFFPHORE_EDGE_X6": "0"}, "f32-small": {}, "f32-pathsplit": {"DIFFPHORE_PATH_SPLIT": "1"}}
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32-f16x3", "f32-exact", "f32-small", "bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f32-f16x3", "f32-exact", "f32-small", "f32-pathsplit", "bf16x3", "bf16"])
 def test_configs4_full_100_step_schedule_vs_oracle(precision, monkeypatch):
     """BASELINE configs[4] over its WHOLE calibrated schedule (100 reverse steps, /root/reference/src/utils/sampling.py:204-255 accumulates every
     step's error): 6 poses (3 samples of 2 target-fishing complexes), same start poses and pre-drawn noise for the HIP path and the fp64
