@@ -198,8 +198,8 @@ int dp_tp_conv_node_fused(const DpConvArgs* convs, int32_t n, void* stream);
  * part[conv][node][out_stride] (DEVICE scratch, part_floats >= n * n_nodes * out_stride) and a second, tiny launch adds the convs, their
  * BatchNorm shifts and the residual / previous output up in a fixed order: deterministic, equal to dp_tp_conv_node_fused to fp32
  * rounding, n x shorter when latency-bound.  Requires convs[0].path_split == 1, scat_ptr[0] == 0, n_nodes == scat_ptr[B], 2 <= n <= 3.
- * DP_PREC_BF16 (round 5): the conv split without the path split (grid x n); DP_PREC_F16X3: runs unsplit (its 8-node groups already double the
- * workgroups; dp_forward keeps the smallest fp32 batches on the DP_PREC_F32 split kernels). */
+ * DP_PREC_BF16 / DP_PREC_F16X3 (round 5): the conv split without the path split (grid x n; the f16x3 kernel's 8-node groups already double
+ * the workgroups); dp_forward asks for it while the fused launch would have at most 384 (f16x3) / 256 (bf16) workgroups. */
 int dp_tp_conv_node_fused_split(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream);
 /* what DP_ALGO_AUTO resolves to for a batch of B poses at `precision` (returns DP_ALGO_EDGE or DP_ALGO_NODE) */
 int dp_resolve_conv_algo(int32_t algo, int32_t precision, int32_t B);

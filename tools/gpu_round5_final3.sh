@@ -15,5 +15,7 @@ python -m pytest tests/test_workloads_gpu.py -q -s -k "full_100 or matches_oracl
 bash tools/profile_config.sh r5_cfg3 3 > gpurun_out/r5_cfg3.log 2>&1
 bash tools/profile_config.sh r5_cfg4 4 > gpurun_out/r5_cfg4.log 2>&1
 bash tools/pmc_conv.sh r5f16k3 --algo node --prec f16x3 --kind 3 --mode p2l > /dev/null 2>&1
+python tools/batch_sweep.py --batches 1,8,20,40,64,96,128,256,512 --reps 2 --out gpurun_out/r5_batch_sweep.csv > /dev/null 2>&1 < /dev/null
+python tools/batch_sweep.py --precision bf16 --batches 1,8,20,40,64,128,256,512 --reps 2 --out gpurun_out/r5_batch_sweep_bf16.csv > /dev/null 2>&1 < /dev/null
 bash tools/pmc_bench.sh r5lig3 "tp_conv_node_f16_kernel<3, true" > /dev/null 2>&1
 tail -3 gpurun_out/r5_gpu_suite.txt; tail -c 400 gpurun_out/r5_bench_full.json; ls gpurun_out | grep "^r5\|pmc_r5\|pmcb_r5"
