@@ -2,6 +2,7 @@
 """Build libdiffphore_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  In-tree output so it ships with gpurun."""
 import glob
 import hashlib
+import re
 import os
 import subprocess
 import sys
@@ -12,14 +13,24 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wno-unused-result"]
 
 
+_CODE = re.compile(r'"(?:\\.|[^"\\\n])*"|\'(?:\\.|[^\'\\\n])*\'|//[^\n]*|/\*.*?\*/', re.S)
+
+
+def _code_only(text: str) -> str:
+    """the source without comments, every run of white space as one blank (string and character literals kept as they are): what the hash below is
+    taken over - a reworded comment or a re-wrapped line is not a different kernel"""
+    text = _CODE.sub(lambda m: m.group(0) if m.group(0)[0] in "\"'" else " ", text)
+    return " ".join(text.split())
+
+
 def source_hash() -> str:
-    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h), first 16 hex digits: compiled into the library (dp_build_info) and
-    used to key committed PMC profiles to the sources they were measured on."""
+    """sha256 over the CODE of the kernel sources (csrc/*.hip, csrc/*.h, include/*.h; comments and white space do not count), first 16 hex
+    digits: compiled into the library (dp_build_info) and used to key committed PMC profiles to the sources they were measured on."""
     h = hashlib.sha256()
     root = os.path.normpath(os.path.join(HERE, "..", ".."))
     for f in sorted(glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(root, "include", "*.h"))):
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, "r", encoding="utf-8").read()).encode())
     return h.hexdigest()[:16]
 
 

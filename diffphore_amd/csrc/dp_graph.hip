@@ -148,8 +148,8 @@ __device__ __forceinline__ void store_flag_row_f16x2(uint16_t* __restrict__ tab,
   if (tid < 64) tab[(size_t)n_rows * 64 + tid] = tid == 20 ? (uint16_t)0x3C00 : (uint16_t)0;
 }
 // The edge kernels hold ONE ROW PER THREAD in registers, rows of consecutive threads consecutive in memory.  A thread that stores its own 36- / 80- /
-// 128-byte row makes every store instruction of a wave touch 64 different cache lines (measured: the 128-byte two-limb image doubled both edge
-// kernels, 50 -> 102 us).  rows_store stages the workgroup's rows in LDS ([256][ROW | 1] dwords: an odd stride, conflict-free) and writes them back
+// 128-byte row makes every store instruction of a wave touch 64 different cache lines (the 128-byte two-limb image had doubled both edge
+// kernels, 50 -> 102 us; staged: cross_edges_kernel 77 us, lig_edges_kernel 92 us - that one is bound by its dependent gathers).  rows_store stages the workgroup's rows in LDS ([256][ROW | 1] dwords: an odd stride, conflict-free) and writes them back
 // as dwords in memory order - 256 contiguous bytes per wave and instruction.  n_rows = live rows of the workgroup (a prefix of its threads),
 // dst = the row of thread 0.  Every thread of the workgroup must call it (two workgroup barriers).
 constexpr int ROWBUF_DWORDS = 256 * 33;
