@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in the header but not exported"
 
 
+def test_source_hash_ignores_comments_and_layout_but_not_code():
+    """build.source_hash is taken over the code only: rewording a comment or re-wrapping a line does not re-key the committed PMC records, any
+    token change does; string / character literals are code"""
+    from diffphore_amd.csrc.build import _code_only
+    base = 'int a = 1; // note\nconst char* s = "// kept /* kept */";\n/* block\n   comment */ char c = \'"\';   int   b;'
+    assert _code_only(base) == 'int a = 1; const char* s = "// kept /* kept */"; char c = \'"\'; int b;'
+    assert _code_only(base.replace("// note", "// another note").replace("int   b", "int\n b")) == _code_only(base)
+    assert _code_only(base.replace("a = 1", "a = 2")) != _code_only(base)
+    assert _code_only(base.replace("// kept", "// changed")) != _code_only(base)
+
+
 def test_committed_traffic_records_match_the_kernel_sources():
     """bench.py quotes `roofline.traffic` only from a PMC record taken on the SAME kernel sources (profiles/conv_hbm_traffic.json, keyed by
     build.source_hash()): a kernel edit - even a comment - without a new tools/gpu_round5_final3.sh run would make the driver's bench line say
