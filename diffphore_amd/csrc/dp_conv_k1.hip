@@ -1,0 +1,7 @@
+// dp_conv_k1.hip - the edge-side fused conv (dp_conv_impl.h) instantiated for layer kind 1: one translation unit per kind, so that the six
+// compile side by side
+#include "dp_conv_impl.h"
+
+#ifndef DP_CONV_ONE_TU
+int dp_conv_launch_k1(const DpConvArgs& a, hipStream_t st) { return dp::launch<1>(a, st); }
+#endif

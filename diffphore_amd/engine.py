@@ -834,8 +834,9 @@ class Engine:
     `conv_algo`: formulation of the fused layer convs - "edge" (per-edge radial GEMM), "node" (node-side contraction, dense cross
     edge sets) or None / "auto" ($DIFFPHORE_CONV_ALGO, else the library's choice by precision and batch)."""
 
-    def __init__(self, model: DeviceModel, pb: PackedBatch, conv_algo: Optional[str] = None):
+    def __init__(self, model: DeviceModel, pb: PackedBatch, conv_algo: Optional[str] = None, exact: bool = False):
         self.model, self.pb, self.ws = model, pb, Workspace(pb)
+        self.exact = bool(exact)                     # fp32 MFMA everywhere whatever the environment says: what sampling._run_parts replays a flagged batch on
         self.L = _declare()
         conv_algo = conv_algo or os.environ.get("DIFFPHORE_CONV_ALGO", "auto")
         if conv_algo not in CONV_ALGOS:
@@ -848,11 +849,11 @@ class Engine:
         if fuse not in CONV_FUSE:
             raise ValueError(f"DIFFPHORE_CONV_FUSE must be one of {sorted(CONV_FUSE)} (got {fuse!r})")
         self.ws.struct.conv_fuse = CONV_FUSE[fuse]
-        x6 = os.environ.get("DIFFPHORE_EDGE_X6", "1")
+        x6 = "0" if exact else os.environ.get("DIFFPHORE_EDGE_X6", "1")
         if x6 not in ("0", "1"):
             raise ValueError(f"DIFFPHORE_EDGE_X6 must be 0 or 1 (got {x6!r})")
         self.ws.struct.edge_bf16x6 = int(x6)         # 1 (default): edge-side convs of an fp32 model as a two-limb fp16 split (until round 4: bf16x6); 0: exact fp32 MFMA
-        f16 = os.environ.get("DIFFPHORE_NODE_F16", "1")
+        f16 = "0" if exact else os.environ.get("DIFFPHORE_NODE_F16", "1")
         if f16 not in ("0", "1"):
             raise ValueError(f"DIFFPHORE_NODE_F16 must be 0 or 1 (got {f16!r})")
         self.ws.struct.node_f16 = int(f16)           # 1 (default): node-side convs of an fp32 model as two fp16 limbs per operand (DP_PREC_F16X3); 0: fp32 MFMA
@@ -901,6 +902,11 @@ class Engine:
                 self.L.dp_sample_graph_destroy(self._graph)
             except Exception:      # noqa: BLE001
                 pass
+
+    def limb_kernels(self) -> bool:
+        """whether this fp32 model's convs run on the two-limb fp16 kernels (DP_PREC_F16X3): fp32-grade INSIDE fp16's exponent range
+        (dp_conv_node_f16_impl.h: |feature|, |T| 2^5 < 65504) - a value beyond it becomes non-finite and surfaces as status bit 0"""
+        return self.model.precision == "f32" and (self.edge_side_convs == "f16x3" or (self.node_side_convs == "f16x3" and self.conv_algo == "node"))
 
     def path_split_on(self) -> bool:
         """whether the ligand-side node-side launches of this batch take the fp32 kernels' path split (dp_graph.hip: two workgroups per node group

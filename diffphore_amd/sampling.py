@@ -340,14 +340,42 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
         _enqueue_run(eng, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, vis, dev_noise)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(pb.device))
-        return part, eng, done
+        return part, eng, done, item
+
+    replayable = visualization_list is None and not bool(getattr(model_args, "keep_update", False)) and \
+        not (randomize or {}).get("keep_update", False) and os.environ.get("DIFFPHORE_EXACT_REPLAY", "1") != "0"
+
+    def replay_exact(item, eng):
+        """A batch of an fp32 model that ran the two-limb fp16 kernels came back with a Kabsch flag (status bit 0 = some pose went non-finite
+        or degenerate).  Those kernels are fp32-grade only inside fp16's exponent range (Engine.limb_kernels), the reference has no such
+        limit: run the batch once more on the exact-fp32 kernels - same start state (the host graphs are untouched until write-back), same
+        start randomisation, same noise - before anything is reported.  What is still flagged then is flagged in the reference's own
+        arithmetic."""
+        part, uids, pb, Z, T_all, rz = item
+        pb.set_state(torch.cat([g["ligand"].pos for g in part]), torch.cat([g["ligand"].norm.reshape(-1, 33) for g in part]))
+        dev_noise = _device_noise(seed, None, uids, 0, len(part), pb.device) if on_dev else None
+        if rz is not None:
+            _randomize_launch(pb, *rz, randomize["no_torsion"])
+        elif randomize is not None and on_dev:
+            _randomize_on_device(pb, dev_noise, randomize)
+        eng2 = Engine(model.device_model, pb, conv_algo=eng.conv_algo, exact=True)
+        _enqueue_run(eng2, Z, T_all, part, *common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, None, dev_noise)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(pb.device))
+        if timing is not None:
+            timing["exact_replays"] = timing.get("exact_replays", 0) + 1
+        return eng2, done
 
     item = pull()
     cur = launch(item, True) if item is not None else None
     while cur is not None:
-        part, eng, done = cur
+        part, eng, done, cur_item = cur
         item = pull()                                # host stage of the next batch (the caller's lazy loading included) ...
         nxt = launch(item, False) if item is not None else None      # ... and its loop, queued behind the running one
+        if write_back and replayable and eng.limb_kernels():
+            done.synchronize()
+            if bool((d2h(eng.ws.t["status"]) & 1).any()):
+                eng, done = replay_exact(cur_item, eng)
         if timing is not None and nxt is None:
             done.synchronize()
             timing["loop_s"] = _time.time() - _t0

@@ -430,6 +430,63 @@ def test_hip_path_matches_reference_model_and_sampler_golden(golden_dir, algo, m
         assert np.abs(nrm - G[f"samp_{name}_norm"]).max() < 1e-3
 
 
+@pytest.mark.parametrize("noise_mode", ["seed", "host"])
+def test_flagged_batch_of_the_limb_kernels_is_replayed_on_exact_fp32(noise_mode, monkeypatch):
+    """The two-limb fp16 kernels an fp32 model runs by default are fp32-grade only inside fp16's exponent range; beyond it a pose goes
+    non-finite and comes back with status bit 0, where the reference (plain fp32) has no such limit.  `_run_parts` therefore replays a
+    flagged batch once on the exact-fp32 kernels - same start state, start randomisation and noise - before anything is reported.  Here
+    the flag is injected behind the first run's loop (the kernels' own overflow behaviour is tests/test_conv_f16_gpu.py's business): the
+    call must not raise, must report one replay, and must return bit for bit what an exact-fp32 run of the same call returns - on-device
+    noise (seed) and the reference-order host draws (whose later steps are drawn lazily, behind the first launch) alike.  With the replay
+    switched off the flag raises the reference's SVD error as before."""
+    from diffphore_amd import sampling
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.score_model import TensorProductScoreModel
+    gs = synthetic.synthetic_pairs(131, 6, (12, 20), (1, 5), (8, 16))
+    S = 5
+    sched = get_t_schedule(S)
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    m = TensorProductScoreModel(device="cuda").load_state_dict(weights.init_state_dict())
+    rz = dict(no_torsion=False, no_random=False, tr_sigma_max=cfg.tr_sigma_max)
+
+    def run(timing=None):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        kw = dict(seed=77) if noise_mode == "seed" else dict(batch_size=4)
+        out, _ = sampling.sampling_phore(copy.deepcopy(gs), m, S, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, randomize=rz,
+                                         timing=timing, **kw)
+        return out
+
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.setenv(k, "0")
+    exact = run()
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.delenv(k)
+    limb = run()
+    assert any(not torch.equal(x["ligand"].pos, y["ligand"].pos) for x, y in zip(exact, limb))      # two different arithmetics ...
+    assert max((x["ligand"].pos - y["ligand"].pos).abs().max().item() for x, y in zip(exact, limb)) < 1e-3      # ... of the same grade
+
+    seen = []
+    enqueue = sampling._enqueue_run
+
+    def flagging(eng, *a, **k):
+        enqueue(eng, *a, **k)
+        seen.append(eng.limb_kernels())
+        if eng.limb_kernels():
+            eng.ws.t["status"][2:3].bitwise_or_(1)       # behind the loop, on the launch stream: "pose 2 went non-finite"
+    monkeypatch.setattr(sampling, "_enqueue_run", flagging)
+    timing = {}
+    replayed = run(timing)
+    assert seen == [True, False] and timing.get("exact_replays") == 1
+    for x, y in zip(replayed, exact):
+        assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
+    monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
+    with pytest.raises(RuntimeError, match="Kabsch alignment failed to converge for poses \\[2\\]"):
+        run()
+
+
 def test_sampler_without_any_torsion_and_no_torsion_flag():
     """A batch in which no ligand has a rotatable bond (tor score is `torch.empty(0)`, :354-358) and the `no_torsion` switch on a
     batch that does have torsions: both must run, stay finite and agree with the oracle."""
