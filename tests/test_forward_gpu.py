@@ -487,6 +487,46 @@ def test_flagged_batch_of_the_limb_kernels_is_replayed_on_exact_fp32(noise_mode,
         run()
 
 
+def test_real_fp16_range_overflow_is_replayed_on_exact_fp32(monkeypatch):
+    """The same replay on a REAL range overflow: ligand atom embeddings scaled by 10 push the radial hidden vectors x tensor-product
+    operands of the later layers past what two fp16 limbs hold (|T| 2^5 < 65504, dp_conv_node_f16_impl.h) while every fp32 product stays
+    finite (scores of magnitude 10^6: a diverged model, but one the reference evaluates).  The limb kernels alone end in the reference's SVD
+    error (status bit 0: non-finite pose); with the replay the call returns what the exact-fp32 kernels return, bit for bit."""
+    from diffphore_amd import sampling
+    from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
+    from diffphore_amd.score_model import TensorProductScoreModel
+    gs = synthetic.synthetic_pairs(4242, 6, (12, 20), 0, (8, 16))
+    sched = get_t_schedule(1)
+    cfg = config.ModelConfig()
+    args = types.SimpleNamespace(**{k: getattr(cfg, k) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max",
+                                                                 "tor_sigma_min", "tor_sigma_max")}, no_torsion=False)
+    sd = weights.init_state_dict()
+    for k in sd:
+        if k.startswith("encoder.lig_node_embedding.atom_embedding_list"):
+            sd[k] = sd[k] * 10.0
+    m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+
+    def run(timing=None):
+        out, _ = sampling.sampling_phore(copy.deepcopy(gs), m, 1, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, seed=5, timing=timing)
+        return out
+
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.setenv(k, "0")
+    exact = run()
+    assert all(bool(torch.isfinite(g["ligand"].pos).all()) for g in exact)
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
+    with pytest.raises(RuntimeError, match="Kabsch alignment failed to converge"):
+        run()
+    monkeypatch.delenv("DIFFPHORE_EXACT_REPLAY")
+    timing = {}
+    replayed = run(timing)
+    assert timing.get("exact_replays") == 1
+    for x, y in zip(replayed, exact):
+        assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
+
+
 def test_sampler_without_any_torsion_and_no_torsion_flag():
     """A batch in which no ligand has a rotatable bond (tor score is `torch.empty(0)`, :354-358) and the `no_torsion` switch on a
     batch that does have torsions: both must run, stay finite and agree with the oracle."""
