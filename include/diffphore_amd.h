@@ -67,7 +67,7 @@ enum DpPrecision {
   DP_PREC_F16X3 = 6     /* fp32-GRADE on the 16-bit pipe.  Node-side kernel (dp_conv_node_f16_impl.h): every operand of the three GEMMs as TWO fp16 limbs
                            (hi = rne16(v), lo = rne16(v - hi): 22 significand bits; exact power-of-two scales map the operands into fp16's
                            range), cross products hi*hi + hi*lo + lo*hi (+ lo*lo in the second contraction) on v_mfma_f32_16x16x32_f16, fp32
-                           accumulate.  Held to the same tolerances as DP_PREC_F32.  Precondition: |features|, |edge embedding| < 65504 (beyond: non-finite -> status bit 0; the Python samplers replay such a batch on DP_PREC_F32).
+                           accumulate.  Held to the same tolerances as DP_PREC_F32.  Precondition: |features|, |edge embedding| < 65504 (beyond: non-finite -> status bit 0; the Python host replays such a batch on DP_PREC_F32).
                            Edge-side kernel (dp_conv.hip, round 5): the radial contraction W2 hid with both operands as two fp16 limbs, 3 cross
                            products on v_mfma_f32_32x32x16_f16 (weights from dp_pack_conv_weights(kind, DP_PREC_F16X3): W2 * 2^w, w in a trailing
                            quad; the caller passes bn_scale * 2^-w).  Not a model precision: dp_forward uses it for the convs of a DP_PREC_F32

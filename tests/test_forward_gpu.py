@@ -526,6 +526,28 @@ def test_real_fp16_range_overflow_is_replayed_on_exact_fp32(monkeypatch):
     for x, y in zip(replayed, exact):
         assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
 
+    # the bare forward(data) has no status word: it checks its scores and recomputes non-finite ones on the exact kernels
+    from oracle import sampler as osampler
+
+    def scores():
+        b = Batch.from_data_list(copy.deepcopy(gs))
+        osampler.set_time_phore(b, 0.5, 0.5, 0.5, b.num_graphs)
+        mm = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+        tr, rot, tor = mm(b)
+        again = mm(b)                               # the batch keeps its exact engine
+        assert torch.allclose(again[0], tr, rtol=0, atol=0, equal_nan=True) and torch.allclose(again[1], rot, rtol=0, atol=0, equal_nan=True)
+        return tr, rot, mm
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.setenv(k, "0")
+    tr_e, rot_e, _ = scores()
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.delenv(k)
+    tr_r, rot_r, mm = scores()
+    assert bool(torch.isfinite(tr_e).all()) and torch.equal(tr_r, tr_e) and torch.equal(rot_r, rot_e) and mm._engine.exact
+    monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
+    tr_l, _, mm = scores()
+    assert not bool(torch.isfinite(tr_l).all()) and not mm._engine.exact
+
 
 def test_sampler_without_any_torsion_and_no_torsion_flag():
     """A batch in which no ligand has a rotatable bond (tor score is `torch.empty(0)`, :354-358) and the `no_torsion` switch on a
