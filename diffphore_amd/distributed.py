@@ -6,6 +6,7 @@ The reference has no distributed code; poses are independent th
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, List, Sequence, Tuple
 
 import torch
@@ -165,14 +166,15 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     batches = screen_plan(n_units, costs, rank, world, samples_per_complex, max_poses)
     mine = [i for bt in batches for i in bt]
-    if len(batches) >= 3 and len(batches[0]) >= 8:
+    ramp = os.environ.get("DIFFPHORE_SCREEN_RAMP", "1") != "0"      # 0: A/B switch - the first device batch whole, as the others
+    if ramp and len(batches) >= 3 and len(batches[0]) >= 8:
         # geometric ramp: nothing runs until the first device batch is built and packed, so the first full batch is dealt as 1/8, 1/8, 1/4, 1/2 of
         # its units - the GPU starts after an eighth of the host work and each piece is built while the previous (at most equally long) one
         # runs; poses do not depend on the batching (seeded noise per pose uid)
         b0 = batches[0]
         e = max(1, len(b0) // 8)
         batches = [b0[:e], b0[e:2 * e], b0[2 * e:4 * e], b0[4 * e:]] + batches[1:]
-    elif len(batches) >= 3 and len(batches[0]) >= 4:
+    elif ramp and len(batches) >= 3 and len(batches[0]) >= 4:
         q = len(batches[0]) // 4
         batches = [batches[0][:q], batches[0][q:]] + batches[1:]
     steps = int(getattr(args, "inference_steps", 20))
