@@ -933,6 +933,23 @@ class Engine:
                                      ws.rot.data_ptr(), ws.tor.data_ptr(), _stream()), "dp_forward")
         return ws.tr, ws.rot, ws.tor[:ws.n_tor]
 
+    def forward_in_range(self):
+        """forward() for callers without a status word to look at: if this engine runs the two-limb fp16 kernels (fp32-grade only inside fp16's
+        exponent range, `limb_kernels`) and the scores come out non-finite, they are recomputed on an exact-fp32 engine over the same packed
+        batch.  -> (the engine that produced the scores - keep using it -, tr, rot, tor).  One host sync; DIFFPHORE_EXACT_REPLAY=0 = plain
+        forward()."""
+        tr, rot, tor = self.forward()
+        if not self.limb_kernels() or os.environ.get("DIFFPHORE_EXACT_REPLAY", "1") == "0":
+            return self, tr, rot, tor
+        finite = torch.isfinite(tr).all() & torch.isfinite(rot).all()
+        if tor.numel():
+            finite = finite & torch.isfinite(tor).all()
+        if bool(finite):
+            return self, tr, rot, tor
+        eng = Engine(self.model, self.pb, conv_algo=self.conv_algo, exact=True)
+        eng.ws.t["status"].copy_(self.ws.t["status"])        # per-pose flags of earlier steps stay with the batch
+        return (eng,) + tuple(eng.forward())
+
     def update(self, sp: DpStepParams, z_tr=None, z_rot=None, z_tor=None):
         ws = self.ws
         _lib.check(self.L.dp_conformer_update(C.byref(self.pb.struct), C.byref(sp), ws.tr.data_ptr(), ws.rot.data_ptr(),

@@ -613,7 +613,7 @@ def sampling_phore_with_fitscore(data_list, model, inference_steps, tr_schedule,
             tr_g, _, _ = _g_params(model_args, *t_to_sigma(tr_schedule[t_idx], rot_schedule[t_idx], tor_schedule[t_idx]))
             sp.tr_c1 = 0.5 * tr_g * np.sqrt(dt_tr)
         pb.set_time(float(tr_schedule[t_idx]), float(rot_schedule[t_idx]), float(tor_schedule[t_idx]))
-        eng.forward()
+        eng = eng.forward_in_range()[0]            # (scores beyond the two-limb fp16 kernels' range: this step and the following ones on exact fp32)
         reps = R if branching else 1
         noisy = not (ode or no_random or last)
         cand_pos, cand_norm = [], []

@@ -6,7 +6,6 @@ on the model device, and leaves `node_sigma_emb` / `graph_sigma_emb` on `data` l
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import numpy as np
@@ -171,17 +170,11 @@ class TensorProductScoreModel:
         pb.set_state(torch.as_tensor(data["ligand"].pos), torch.as_tensor(data["ligand"].norm))
         ct = data.complex_t
         pb.set_time(ct["tr"], ct["rot"], ct["tor"])
-        tr, rot, tor = eng.forward()
-        if eng.limb_kernels() and os.environ.get("DIFFPHORE_EXACT_REPLAY", "1") != "0":
-            # the two-limb fp16 kernels are fp32-grade only inside fp16's exponent range (Engine.limb_kernels); the reference has no such
-            # limit: non-finite scores are recomputed once on the exact-fp32 kernels, which this batch then keeps (one host sync per call - a
-            # forward() is consumed by its caller anyway; the samplers' device loop does the same per batch through the status word)
-            finite = torch.isfinite(tr).all() & torch.isfinite(rot).all()
-            if tor.numel():
-                finite = finite & torch.isfinite(tor).all()
-            if not bool(finite):
-                eng = self._engine = Engine(self.device_model, pb, conv_algo=eng.conv_algo, exact=True)
-                tr, rot, tor = eng.forward()
+        # the two-limb fp16 kernels are fp32-grade only inside fp16's exponent range; the reference has no such limit: non-finite scores are
+        # recomputed once on the exact-fp32 kernels, which this batch then keeps (Engine.forward_in_range: one host sync per call - a
+        # forward() is consumed by its caller anyway; the samplers' device loop does the same per batch through the status word)
+        eng, tr, rot, tor = eng.forward_in_range()
+        self._engine = eng
         tp = eng.ws.t["tparams"]
         data["ligand"].node_sigma_emb = tp[:, :20].repeat_interleave(torch.as_tensor(pb.nl, device=tp.device), dim=0)
         data["phore"].node_sigma_emb = tp[:, :20].repeat_interleave(torch.as_tensor(pb.np_, device=tp.device), dim=0)

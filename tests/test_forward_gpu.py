@@ -547,6 +547,24 @@ def test_real_fp16_range_overflow_is_replayed_on_exact_fp32(monkeypatch):
     monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
     tr_l, _, mm = scores()
     assert not bool(torch.isfinite(tr_l).all()) and not mm._engine.exact
+    monkeypatch.delenv("DIFFPHORE_EXACT_REPLAY")
+
+    # ... and so does the branching sampler (per-step forward + update): from the first step whose scores leave the range on, exact fp32
+    noise = dict(tr=torch.zeros(1, 1, len(gs), 3), rot=torch.zeros(1, 1, len(gs), 3), tor=torch.zeros(1, 1, 0))
+
+    def branch():
+        out, _ = sampling.sampling_phore_with_fitscore(copy.deepcopy(gs), m, 1, sched, sched, sched, "cuda", t_to_sigma_fn(args), args, noise=noise)
+        return out
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.setenv(k, "0")
+    b_exact = branch()
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.delenv(k)
+    for x, y in zip(branch(), b_exact):
+        assert bool(torch.isfinite(y["ligand"].pos).all()) and torch.equal(x["ligand"].pos, y["ligand"].pos)
+    monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
+    with pytest.raises(RuntimeError, match="Kabsch alignment failed to converge"):
+        branch()
 
 
 def test_sampler_without_any_torsion_and_no_torsion_flag():
