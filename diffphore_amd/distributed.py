@@ -152,8 +152,8 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
         * isolates failures per complex, as the reference's loop does with its try / except and SVD retries (src/inference.py:200-219): a
           `load_unit` exception, a complex over the kernel limits or a sample whose Kabsch alignment fails never ends the run.  A
           Kabsch-flagged complex is re-sampled up to `retries` times with a fresh noise key (the reference re-draws and retries up to five
-          times; a batch that the two-limb fp16 kernels of an fp32 model bring back flagged has already been replayed once on the exact-fp32
-          kernels by the sampler - sampling._run_parts - so a flag that reaches this loop is one the reference's arithmetic raises too); what still fails is reported as `on_result(i, None)` (or a None entry of the returned list) and, when the caller passes
+          times; a complex that the two-limb fp16 kernels of an fp32 model bring back flagged is first run again with the SAME key on the
+          exact-fp32 kernels - see below - so what reaches the fresh-key retries is flagged in the reference's arithmetic too); what still fails is reported as `on_result(i, None)` (or a None entry of the returned list) and, when the caller passes
           a list as `failed`, appended to it as (i, reason).
 
     Returns (indices owned by this rank in processing order - heaviest first when `costs` is given -, list of pose arrays or None).  Peak host memory: two device batches of
@@ -227,12 +227,12 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
                 flagged.append(i)
         return flagged
 
-    def run(batch_list, run_seed, final):
+    def run(batch_list, run_seed, final, exact=False):
         """stream `batch_list`; every finished complex is handed over at once, units that never reach the device are failures; -> flagged units"""
         loaded, flagged = [], []
         stream = sampling_phore_stream(parts_of(batch_list, loaded), model, steps, sched, sched, sched, device, t_to_sigma_fn(args), args, seed=run_seed,
                                        no_random=getattr(args, "no_random", False), ode=getattr(args, "ode", False),
-                                       no_final_step_noise=getattr(args, "no_final_step_noise", False), isolate=True,
+                                       no_final_step_noise=getattr(args, "no_final_step_noise", False), isolate=True, exact=exact, replay=False,
                                        randomize=dict(no_torsion=getattr(args, "no_torsion", False), no_random=False, tr_sigma_max=args.tr_sigma_max))
         k = 0
 
@@ -261,13 +261,23 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
         return flagged
 
     done_bad: set = set()
-    retry = run(batches, int(seed) & 0xFFFFFFFFFFFFFFFF, retries <= 0)
-    # retries of the Kabsch-flagged complexes with a fresh noise key each (the pose uids stay: only the seed changes)
+    # An fp32 model runs its convs on the two-limb fp16 kernels, fp32-grade only inside fp16's exponent range (engine.Engine.limb_kernels): a
+    # complex they bring back flagged is first run again with the SAME noise key on the exact-fp32 kernels - poses are independent and their noise
+    # is keyed by (seed, pose uid), so that IS the exact-fp32 result of the original run - and only what is flagged in the reference's own
+    # arithmetic too goes on to the fresh-key retries (which stay on the exact kernels).  Only the flagged complexes are re-run, not their batches.
+    limb = getattr(getattr(model, "device_model", None), "precision", None) == "f32" and \
+        (os.environ.get("DIFFPHORE_NODE_F16", "1") != "0" or os.environ.get("DIFFPHORE_EDGE_X6", "1") != "0") and \
+        os.environ.get("DIFFPHORE_EXACT_REPLAY", "1") != "0"
+    seed0 = int(seed) & 0xFFFFFFFFFFFFFFFF
+    retry = run(batches, seed0, retries <= 0 and not limb)
     per = max(1, max_poses // samples_per_complex)
+    cut = lambda units: [units[lo:lo + per] for lo in range(0, len(units), per)]      # noqa: E731
+    if retry and limb:
+        retry = run(cut(retry), seed0, retries <= 0, exact=True)
+    # retries of the Kabsch-flagged complexes with a fresh noise key each (the pose uids stay: only the seed changes)
     for attempt in range(1, retries + 1):
         if not retry:
             break
-        retry = run([retry[lo:lo + per] for lo in range(0, len(retry), per)], (int(seed) + 0x9E3779B97F4A7C15 * attempt) & 0xFFFFFFFFFFFFFFFF,
-                    attempt == retries)
+        retry = run(cut(retry), (int(seed) + 0x9E3779B97F4A7C15 * attempt) & 0xFFFFFFFFFFFFFFFF, attempt == retries, exact=limb)
     collected = None if kept is None else [kept.get(i) for i in mine]
     return mine, collected

@@ -299,7 +299,7 @@ def sampling_phore(data_list, model, inference_steps, tr_schedule, rot_schedule,
 
 
 def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_random, ode, no_final_step_noise, batch_size,
-               visualization_list, randomize, seed, write_back, timing=None, isolate=False):
+               visualization_list, randomize, seed, write_back, timing=None, isolate=False, exact=False, replay=True):
     """The device-batch pipeline behind `sampling_phore` and `sampling_phore_stream`.  `parts_iter` yields
     (pose list, noise tables | None, pre-drawn start randomisation | None, pose uids); the NEXT item is pulled - whatever lazy loading
     the iterator does included - and host-staged while the GPU runs the current batch (the step loop is enqueued without any host
@@ -330,7 +330,7 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
             _randomize_launch(pb, *rz, randomize["no_torsion"])
         elif randomize is not None and on_dev:
             _randomize_on_device(pb, dev_noise, randomize)
-        eng = Engine(model.device_model, pb)
+        eng = Engine(model.device_model, pb, exact=exact)
         if timing is not None and first:
             torch.cuda.synchronize()
             timing["pack_and_noise_s"] = _time.time() - _t0
@@ -342,7 +342,7 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
         done.record(torch.cuda.current_stream(pb.device))
         return part, eng, done, item
 
-    replayable = visualization_list is None and not bool(getattr(model_args, "keep_update", False)) and \
+    replayable = replay and visualization_list is None and not bool(getattr(model_args, "keep_update", False)) and \
         not (randomize or {}).get("keep_update", False) and os.environ.get("DIFFPHORE_EXACT_REPLAY", "1") != "0"
 
     def replay_exact(item, eng):
@@ -391,19 +391,21 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
 
 def sampling_phore_stream(parts, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args, *, seed: int,
                           no_random=False, ode=False, no_final_step_noise=False, randomize: Optional[dict] = None, write_back=True,
-                          isolate=False):
+                          isolate=False, exact=False, replay=True):
     """`sampling_phore` over a STREAM of device batches for library-scale runs (virtual screening shards 10^5 ligands x 40
     samples per GPU; the reference's loop is `for graph in dataset: [deepcopy(graph) x N] -> randomize -> sample`, inference.py:139-228).
     `parts` is an iterable (typically a generator that builds its poses lazily) of `(pose_list, pose_uids)`; each pose list is one device
     batch.  Noise - and with `randomize=` the start randomisation - is drawn on the device from (`seed`, pose uid), so nothing depends on
     how the stream is cut into batches or ranks.  A generator: yields each pose list after its final positions are written back
     (`g['ligand'].pos`); the caller consumes and drops it, the pipeline keeps at most two batches of host objects alive.  `isolate`: yield
-    (pose list, per-pose status words) and never raise for a flagged pose (Kabsch failure): one bad ligand must not end a library run."""
+    (pose list, per-pose status words) and never raise for a flagged pose (Kabsch failure): one bad ligand must not end a library run.
+    `exact`: every batch on the exact-fp32 kernels (Engine(exact=True)); `replay=False`: no whole-batch exact replay of a flagged batch - for
+    callers that re-run the flagged COMPLEXES themselves (distributed.screen)."""
     if seed is None:
         raise ValueError("the streaming sampler draws its noise on the device: seed is required")
     common = (inference_steps, tr_schedule, rot_schedule, tor_schedule)
     yield from _run_parts(((p, None, None, u) for p, u in parts), model, device, common, t_to_sigma, model_args, no_random, ode,
-                          no_final_step_noise, 20, None, randomize, int(seed), write_back, isolate=isolate)
+                          no_final_step_noise, 20, None, randomize, int(seed), write_back, isolate=isolate, exact=exact, replay=replay)
 
 
 def _host_stage_noise_only(pb, N, inference_steps, tr_schedule, rot_schedule, tor_schedule, ode, no_random, no_final_step_noise, batch_size, noise,

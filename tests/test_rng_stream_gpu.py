@@ -294,6 +294,52 @@ def test_screen_isolates_failing_units(monkeypatch, kernels):
     assert [c is None for c in coll2] == [i in why for i in mine2]
 
 
+def test_screen_reruns_range_overflow_units_on_exact_fp32(monkeypatch):
+    """An fp32 model whose features leave the two-limb fp16 kernels' range (atom embeddings x 10: the limb kernels go non-finite, every fp32
+    product stays finite - tests/test_forward_gpu.py): `screen()` runs the flagged complexes once more with the SAME noise key on the exact-fp32
+    kernels before any fresh-key retry - every unit is delivered, and with what a screen on the exact kernels delivers (same seed: bit for
+    bit up to the batching, which a pose's result does not depend on beyond fp32 rounding).  With the rerun switched off the units fail."""
+    from diffphore_amd import distributed as D
+    from diffphore_amd import engine
+    from diffphore_amd.score_model import TensorProductScoreModel
+    sd = weights.init_state_dict()
+    for k in sd:
+        if k.startswith("encoder.lig_node_embedding.atom_embedding_list"):
+            sd[k] = sd[k] * 10.0
+    m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+    units = [synthetic.synthetic_pairs(900 + i, 1, 12 + i, 0, 9 + i)[0] for i in range(5)]
+    args, NS = _args(), 2
+    args.inference_steps = 1
+    made = []
+    real = engine.Engine.__init__
+
+    def spy(self, model, pb, conv_algo=None, exact=False):
+        made.append((pb.B, bool(exact)))
+        real(self, model, pb, conv_algo=conv_algo, exact=exact)
+    monkeypatch.setattr(engine.Engine, "__init__", spy)
+
+    def go(**kw):
+        got, failed = {}, []
+        D.screen(5, lambda i: units[i], m, args, samples_per_complex=NS, max_poses=4 * NS, seed=31, on_result=got.__setitem__, failed=failed, **kw)
+        return got, failed
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.setenv(k, "0")
+    exact, f0 = go()
+    assert not f0 and all(np.isfinite(exact[i]).all() for i in range(5))
+    for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
+        monkeypatch.delenv(k)
+    made.clear()
+    got, f1 = go()
+    assert not f1 and sorted(got) == list(range(5))
+    assert [e for _, e in made] == [False, False, True, True], made        # two limb batches (4 + 1 units), then the 5 flagged units again, exact
+    worst = max(_rmsd(got[i][s_], exact[i][s_]) / max(1.0, float(np.abs(exact[i][s_]).max())) for i in range(5) for s_ in range(NS))
+    print("worst relative deviation from the exact screen:", worst)
+    assert worst < 1e-5
+    monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
+    got2, f2 = go(retries=1)
+    assert sorted(i for i, _ in f2) == list(range(5)) and all(got2[i] is None for i in range(5))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
