@@ -13,7 +13,7 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 10
+DP_ABI_VERSION = 11
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
@@ -22,7 +22,7 @@ PREC_BF16 = 5          # plain bf16 operands, fp32 accumulate: node-side dp_conv
 PREC_F16X3 = 6         # node-side kernel only, fp32-grade: two fp16 limbs per operand on v_mfma_f32_16x16x32_f16 (dp_conv_node_f16_impl.h); not a
                        # model precision - what the node-side convs of an "f32" model run on unless DIFFPHORE_NODE_F16=0
 PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "bf16x9": PREC_BF16X9, "bf16": PREC_BF16}
-EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER, EDGES_LLPAIR = range(5)
+EDGES_CSR, EDGES_P2L, EDGES_L2P, EDGES_CENTER, EDGES_LLPAIR, EDGES_LIST = range(6)
 ALGO_AUTO, ALGO_EDGE, ALGO_NODE = range(3)
 
 
@@ -40,6 +40,7 @@ class DpConvArgs(C.Structure):
         ("resid", VOIDP), ("resid_stride", c_i32), ("resid_width", c_i32), ("phase_split", c_i32),
         ("w1n", VOIDP), ("w2n", VOIDP), ("algo", c_i32), ("path_split", c_i32),
         ("pair_a", VOIDP), ("pair_b", VOIDP), ("pair_ptr", VOIDP), ("edge_emb_bf", VOIDP), ("emb_flag_row", c_i32), ("no_tail", c_i32),
+        ("s0_only", c_i32), ("feat_idx", VOIDP), ("msg_out", VOIDP), ("n_list", c_i32), ("sh0_zero", c_i32),
     ]
 
 

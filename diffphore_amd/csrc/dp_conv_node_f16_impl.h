@@ -33,7 +33,11 @@
 
 #ifndef DPF_ABL     // timing ablations of THIS kernel (tools/build_variant.sh; results are wrong by construction): 1 no gathered-operand loads, 2 no SH-factor
 #define DPF_ABL 0   // reads, 3 no z arithmetic / limb extraction, 4 no GEMM-A MFMAs, 5 no T split / stores, 6 no T reads, 7 no GEMM-B MFMAs, 8 no W2 loads,
-#endif              // 9 no edge-embedding loads (GEMM1), 10 z built for every fourth node only (bound of a z build shared by the four waves)
+#endif              // 9 no edge-embedding loads (GEMM1), 10 z built for every fourth node only (bound of a z build shared by the four waves),
+                    // 11 OPTIMISTIC cost model of "the SH factor on the hidden-vector side" (profiles/r6_experiments.md): no per-node
+                    // operand build at all (the gathered input's limbs serve every node), the extra GEMM-A MFMA sets that form needs (one per
+                    // (sh component, input component) pair with a non-zero CG coefficient), and ONE build of the nine (hid * s_j) limb pairs
+                    // per node and pass - as if 576 registers were there to keep them
 
 namespace dpf {
 using namespace dpn;
@@ -202,7 +206,16 @@ __device__ __forceinline__ Grp grp_of8(const DpConvArgs& a, int bid) {     // as
   return r;
 }
 
-template <int KIND, int MODE, bool HALF, int P>
+// first path that reads the second half of the input columns (NPATH if none)
+template <int KIND> constexpr int first_half1_path() {
+  for (int i = 0; i < Spec<KIND>::NPATH; ++i)
+    if (x_half_of<KIND>(i) == 1) return i;
+  return Spec<KIND>::NPATH;
+}
+// S0: the conv's spherical harmonics are e0 = (1, 0, ..., 0) on every edge the launch covers (DpConvArgs.s0_only: the normals convs, whose
+// few other edges the caller adds through the edge-side kernel): the paths that multiply by an l > 0 component have a zero operand and are
+// skipped - GEMM-A and GEMM-B of the l = 0 paths only, whose operand is the gathered input itself (no per-node operand build at all)
+template <int KIND, int MODE, bool HALF, bool S0, int P>
 struct StageH {
   static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t wrs, __amdgpu_buffer_rsrc_t xrs, unsigned gstride4, int et, int tid, float* sX, int q,
                                              int lane, const u32x4 (&hid)[2 * NBH], unsigned tl_base, unsigned dummy_base, const float* sS,
@@ -214,6 +227,9 @@ struct StageH {
       constexpr bool VEC = d_out_of(ZT) == 3;
       constexpr int NG = VEC ? 3 : 1, NTERM = n_terms<ZT>(), MT = path_mt<KIND>(P), AB = acc_base<KIND>(P), NTILE = VEC ? 2 : 1;
       constexpr int NJ = HALF ? 4 : 8, NT2 = HALF ? 1 : 2;
+      static_assert(!S0 || first_half1_path<KIND>() == S::NPATH || !needs_s<S::P[first_half1_path<KIND>() < S::NPATH ? first_half1_path<KIND>() : 0].ztype>(),
+                    "s0-only: the path that re-stages the input columns is an l = 0 path");
+      if constexpr (!(S0 && needs_s<ZT>())) {
       if constexpr (P > 0 && x_half_of<KIND>(P) != x_half_of<KIND>(P > 0 ? P - 1 : 0)) {
         __syncthreads();                            // every wave is done with the first half of the input columns
         stage_x(xrs, gstride4, et, 1, tid, sX);
@@ -290,7 +306,7 @@ struct StageH {
 #endif
           }
         };
-        if constexpr (needs_s<ZT>()) {
+        if constexpr (needs_s<ZT>() && DPF_ABL != 11) {
           const char* sbase = reinterpret_cast<const char*>(sS);
           int soff[NTERM];
 #pragma unroll
@@ -429,12 +445,27 @@ struct StageH {
             for (int tl = 0; tl < NTILE; ++tl)
 #pragma unroll
               for (int k = 0; k < 2; ++k) Dp[np & 1][k][tl] = mfma_a(hid[2 * np + k], zh[tl], Dp[np & 1][k][tl]);
+#if DPF_ABL == 11
+            {
+              // MFMA sets of the re-associated form per supertile and node: Z011 3 (one per m), Z110 3 (one per i), Z111 6, Z121 9 - minus the NTILE above
+              constexpr int XSETS = !needs_s<ZT>() ? 0 : (ZT == Z011 ? 3 : ZT == Z110 ? 3 : ZT == Z111 ? 6 : 9) - NTILE;
+#pragma unroll
+              for (int x = 0; x < XSETS; ++x)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                  f32x4& D = Dp[np & 1][k][x % NTILE];
+                  D = mfma_a(hid[NBH + 2 * np + k], zh[x % NTILE], D);
+                  D = mfma_a(hid[2 * np + k], zl[x % NTILE], D);
+                  D = mfma_a(hid[2 * np + k], zh[x % NTILE], D);
+                }
+            }
+#endif
             if (np > 0) store_p(np - 1);
             __builtin_amdgcn_sched_barrier(0);
           }
           store_p(NBH / 2 - 1);
         }
-        if constexpr (needs_s<ZT>()) store_t(NBH - 1);
+        if constexpr (needs_s<ZT>() && DPF_ABL != 11) store_t(NBH - 1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM-B: out[w][slot] += W2_limb[w][(u,k)] (T_hi | T_lo)[(u,k)][slot], K = (two in-channels) x (the wave's 16 hidden rows) ----------
         {
@@ -466,13 +497,14 @@ struct StageH {
           }
         }
       }
-      StageH<KIND, MODE, HALF, P + 1>::run(wrs, xrs, gstride4, et, tid, sX, q, lane, hid, tl_base, dummy_base, sS, acc);
+      }   // !(S0 && needs_s)
+      StageH<KIND, MODE, HALF, S0, P + 1>::run(wrs, xrs, gstride4, et, tid, sX, q, lane, hid, tl_base, dummy_base, sS, acc);
     }
   }
 };
 
 // one pass (32 edge slots per node; HALF: 16) of one conv: stage the SH factors, GEMM1 -> hid (two fp16 limbs, A fragments), then the path stages
-template <int KIND, int MODE, bool HALF>
+template <int KIND, int MODE, bool HALF, bool S0>
 __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t ers, __amdgpu_buffer_rsrc_t wrs, const Grp& grp, const Wg& r, int et, int tid,
                                          float* s_T, float* s_S, float* s_X, const float* s_inv, f32x4 (&acc)[n_acc4<KIND>()]) {
   const int lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -517,6 +549,8 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
   const unsigned gstride4 = uni((unsigned)a.gather_stride * 4u);
   stage_x(xrs, gstride4, et, 0, tid, s_X);
   constexpr int SLOTS = HALF ? 16 : 32;
+  static_assert(!(S0 && MODE == LL), "s0-only is a mode of the dense cross convs");
+  if constexpr (!S0) {          // (s0-only: no path reads the factors)
 #pragma unroll
   for (int idx = tid; idx < NBH * SLOTS; idx += 256) {
     const int nn = idx / SLOTS, el = idx % SLOTS, e = 32 * et + el;
@@ -543,6 +577,7 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
     }
 #pragma unroll
     for (int i = 0; i < SCOMP; ++i) s_S[((nn * 2 + (el >> 4)) * SCOMP + i) * 16 + (el & 15)] = v[i];
+  }
   }
   __syncthreads();
 
@@ -637,14 +672,28 @@ __device__ __forceinline__ void pass_f16(const DpConvArgs& a, __amdgpu_buffer_rs
     __builtin_amdgcn_sched_barrier(0);
   }
   finish(NSTEP - 1);
+#if DPF_ABL == 11
+  {   // nine (hid * s_j) limb pairs per node, built once per pass (16 VALU instructions each), results discarded
+    const f32x2 fa0 = {ug[0][0], ug[0][1]}, fa1 = {ug[0][2], ug[0][3]};
+#pragma unroll
+    for (int nn = 0; nn < NBH; ++nn)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const float sj = s_inv[nn] + (float)j;
+        const HL2 r0 = split4_mul(fa0, f32x2{sj, sj}, fa1, f32x2{sj, sj});
+        const HL2 r1 = split4_mul(fa1, f32x2{sj, -sj}, fa0, f32x2{-sj, sj});
+        asm volatile("" ::"v"(r0.h0), "v"(r0.h1), "v"(r0.l0), "v"(r0.l1), "v"(r1.h0), "v"(r1.h1), "v"(r1.l0), "v"(r1.l1));
+      }
+  }
+#endif
   if constexpr (MODE == LL) __syncthreads();      // s_pair lives in wave 0's T image: every wave is done reading it before T tiles land there
   const unsigned tl_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(q * TIMG_B);
   const unsigned dummy_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(4 * TIMG_B);
-  StageH<KIND, MODE, HALF, 0>::run(wrs, xrs, gstride4, et, tid, s_X, q, lane, hid, tl_base, dummy_base, s_S, acc);
+  StageH<KIND, MODE, HALF, S0, 0>::run(wrs, xrs, gstride4, et, tid, s_X, q, lane, hid, tl_base, dummy_base, s_S, acc);
 }
 
 // every pass of one conv of the (possibly fused) launch; `hs` = 2^(S - w) of this conv
-template <int KIND, int MODE, bool HALFOK>
+template <int KIND, int MODE, bool HALFOK, bool S0 = false>
 __device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, int tid, float hs, float* s_T, float* s_S, float* s_X, float* s_inv,
                                          f32x4 (&acc)[n_acc4<KIND>()]) {
   const Wg r = wg_of<MODE>(a, grp.pose);
@@ -666,17 +715,20 @@ __device__ __forceinline__ void conv_f16(const DpConvArgs& a, const Grp& grp, in
     // HALFOK = false: the lean instantiation for launches whose poses never end on a short pass (FusedArgs.lean, from DpConvArgs.no_tail): half the
     // code, fewer registers parked across it; on such a batch the two instantiations are bit-identical
     if constexpr (HALFOK) {
-      if (r.En - 32 * et <= 16) pass_f16<KIND, MODE, true>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
-      else pass_f16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
+      if (r.En - 32 * et <= 16) pass_f16<KIND, MODE, true, S0>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
+      else pass_f16<KIND, MODE, false, S0>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
     } else {
-      pass_f16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
+      pass_f16<KIND, MODE, false, S0>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_X, s_inv, acc);
     }
   }
 }
 
 __device__ __forceinline__ float w2_exponent(const DpConvArgs& a) { return *reinterpret_cast<const float*>(a.w2n); }
 
-template <int KIND, bool HAS_LL, int XMODE, bool HALFOK>
+// S0K: every conv of the launch is s0-only (DpConvArgs.s0_only; cross convs only) - its own instantiation, launched on its own: inlined beside the
+// full conv behind a run-time branch the s0 passes change that function's register allocation (78 -> 150 spilled registers in the full conv's
+// passes at layer 3, step -3 %), behind a real call the accumulators go to scratch (step -25 %): profiles/r6_experiments.md section 2
+template <int KIND, bool HAS_LL, int XMODE, bool HALFOK, bool S0K = false>
 #ifndef DP_WG_PER_CU
 #define DP_WG_PER_CU 2            // 1 = timing experiment: one wave per SIMD with the whole 512-register file (r5_experiments.md section 7)
 #endif
@@ -713,7 +765,7 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(Fus
 #pragma unroll 1
     for (int cx = c_lo; cx < c_hi; ++cx) {
       const DpConvArgs& a = fa.conv[cx];
-      conv_f16<KIND, XMODE, HALFOK>(a, grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(a))), s_T, s_S, s_X, s_inv, acc);
+      conv_f16<KIND, XMODE, HALFOK, S0K>(a, grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(a))), s_T, s_S, s_X, s_inv, acc);
     }
   }
   // ---- sum the four k-partials and the two limb halves of the node slots, un-scale, BatchNorm shift, residual stream ----------------------
@@ -755,6 +807,14 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(Fus
 template <int KIND, bool HALFOK> int launch_f16_h(const FusedArgs& fa, int xmode, hipStream_t st) {
   const DpConvArgs& a = fa.conv[0];
   const dim3 grid((unsigned)(a.B * a.slices * 2 * (fa.conv_split ? fa.n_ll + fa.n_x : 1))), block(256);
+  int n_s0 = 0;
+  for (int i = 0; i < fa.n_ll + fa.n_x; ++i) n_s0 += fa.conv[i].s0_only ? 1 : 0;
+  if (n_s0) {                                     // s0-only convs: their own instantiation, never mixed with full convs in one launch
+    if (fa.n_ll || n_s0 != fa.n_x) return DP_E_UNSUPPORTED;
+    if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_P2L, HALFOK, true>), grid, block, 0, st, fa);
+    else hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_L2P, HALFOK, true>), grid, block, 0, st, fa);
+    return (int)hipGetLastError();
+  }
   if (fa.n_ll) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, true, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
   else if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
   else hipLaunchKernelGGL((tp_conv_node_f16_kernel<KIND, false, DP_EDGES_L2P, HALFOK>), grid, block, 0, st, fa);

@@ -836,6 +836,13 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while (B * slices < 512 && slices < 8) ++slices;
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
+  // the normals convs (phore_to_lig_norm / lig_to_phore_norm) split into their l = 0 part on every pair (node-side, s0-only instantiation) and the
+  // other paths on the listed pairs whose harmonics are not e0
+#ifdef DP_S0_TIMING      // timing build (wrong results): the l = 0 part only
+  const bool xs_lig = f16_lig, xs_ph = f16_ph;
+#else
+  const bool xs_lig = false, xs_ph = false;
+#endif
   auto node_path_split = [&](int B_, int slices_) {
     return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(B_, slices_, f16_ok)));
   };
@@ -927,15 +934,23 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.out = hl2; c.accumulate = 1;
       if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_pl; c.phase_split = 0; c.path_split = node_path_split(B, slices_pl); c.no_tail = b->no_tail_np;
                        c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x;
-                       if (f16_lig) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; c.path_split = f16_csplit(slices_pl); } }
+                       if (f16_lig) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; c.path_split = f16_csplit(slices_pl); }
+      }
     }
+    if (xs_lig) ligc[2].s0_only = 1;            // the normals conv as its l = 0 part (own launch) + the listed pairs (below)
     if (node_side && fuse && node_ll && k->conv_fuse != 2) {
-      // one launch: the three convs scatter onto the same atoms and their outputs add up (:703-706)
-      ligc[1].accumulate = ligc[2].accumulate = 0;
-      if ((rc = timed_fused(ligc, 3, 0, 2, st))) return fail(rc);
+      // one launch: the convs scatter onto the same atoms and their outputs add up (:703-706)
+      ligc[1].accumulate = 0;
+      if (!xs_lig) {
+        ligc[2].accumulate = 0;
+        if ((rc = timed_fused(ligc, 3, 0, 2, st))) return fail(rc);
+      } else {
+        if ((rc = timed_fused(ligc, 2, 0, 1, st))) return fail(rc);
+        if ((rc = timed(ligc[2], l, 2, st))) return fail(rc);
+      }
     } else {
       if ((rc = timed(ligc[0], l, 0, st))) return fail(rc);
-      if (node_side && fuse) {
+      if (node_side && fuse && !xs_lig) {
         if ((rc = timed_fused(ligc + 1, 2, 1, 2, st))) return fail(rc);
       } else {
         for (int nv = 0; nv < 2; ++nv)
@@ -963,9 +978,11 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.out = hp2; c.accumulate = 1;
         if (node_side) { c.algo = DP_ALGO_NODE; c.w1n = cw.w1n; c.w2n = cw.w2n; c.slices = slices_lp; c.phase_split = 0; c.path_split = node_path_split(B, slices_lp); c.no_tail = b->no_tail_nl;
                          c.precision = w->precision; c.edge_emb_bf = k->x_emb_bf; c.emb_flag_row = b->n_x;
-                         if (f16_ph) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; c.path_split = f16_csplit(slices_lp); } }
+                         if (f16_ph) { c.precision = DP_PREC_F16X3; c.w1n = cw.w1h; c.w2n = cw.w2h; c.path_split = f16_csplit(slices_lp); }
       }
-      if (node_side && fuse) {
+      }
+      if (xs_ph) phc[1].s0_only = 1;
+      if (node_side && fuse && !xs_ph) {
         if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);
       } else {
         for (int nv = 0; nv < 2; ++nv)

@@ -231,6 +231,9 @@ int dp_build_info(DpBuildInfo* out) {
   out->abi_version = DP_ABI_VERSION;
   // (bf16 node-kernel ablations are reported as 100 + n, f16x3 node-kernel ablations as 200 + n, the lean path-split experiment as 300)
   out->nabl = DP_NABL ? DP_NABL : (DP_BABL ? 100 + DP_BABL : (DPF_ABL ? 200 + DPF_ABL : (DP_SPLIT_LEAN_ON ? 300 : 0)));
+#ifdef DP_S0_TIMING       // dp_forward skips the sparse part of the normals convs (timing build, wrong results)
+  if (!out->nabl) out->nabl = 400;
+#endif
   out->ablate = DP_ABLATE;
 #ifdef DP_PROF
   out->prof = 1;

@@ -19,10 +19,32 @@ namespace dpk {
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct Sizes { int64_t n_lig, n_ph, n_bond, n_tor, n_pp, n_x, ll_cap, n_llp, n_mask; int32_t max_nl, max_np, max_t; };
+struct Sizes { int64_t n_lig, n_ph, n_bond, n_tor, n_pp, n_x, ll_cap, n_llp, n_mask, n_xs; int32_t max_nl, max_np, max_t; };
+
+constexpr int EX_TYPE = 10;      // the exclusion-sphere column of the one-hot `phoretype` (process_pharmacophore.py:28-38: the last of 11)
+// type of pharmacophore node j: the first column that is exactly 1 (dp_pack_fill validates the one-hot), -1 if none
+static inline int type_of(const float* t) {
+  for (int k = 0; k < 11; ++k)
+    if (t[k] == 1.f) return k;
+  return -1;
+}
+// number of cross pairs of one complex with agreement != 0 (DpBatch.xs_*): node j is not an exclusion sphere and phorefp[i, type(j)] != 0
+static int64_t count_xs(const DpGraphView& v) {
+  int cnt[11] = {0};
+  for (int i = 0; i < v.n_atoms; ++i)
+    for (int t = 0; t < 11; ++t) cnt[t] += v.phorefp[(size_t)i * 11 + t] != 0.f ? 1 : 0;
+  int64_t n = 0;
+  for (int j = 0; j < v.n_phore; ++j) {
+    const int ty = type_of(v.ph_type + (size_t)j * 11);
+    if (ty >= 0 && ty != EX_TYPE) n += cnt[ty];
+  }
+  return n;
+}
 
 static int sizes_of(int32_t n, const DpPoseRef* poses, Sizes* s) {
   memset(s, 0, sizeof(*s));
+  const DpGraphView* last = nullptr;               // the samples of one complex share a view and follow each other: counted once
+  int64_t last_xs = 0;
   for (int i = 0; i < n; ++i) {
     const DpGraphView* v = poses[i].view;
     if (!v || !poses[i].pos || !poses[i].norm) return DP_E_BADARG;
@@ -32,6 +54,11 @@ static int sizes_of(int32_t n, const DpPoseRef* poses, Sizes* s) {
     s->n_lig += nl; s->n_ph += np; s->n_bond += nb; s->n_tor += nt; s->n_pp += v->n_pp; s->n_x += nl * np;
     s->ll_cap += nb + nl * std::min<int64_t>(std::max<int64_t>(nl - 1, 0), 33);
     s->n_llp += nl * nl; s->n_mask += nt * nl;
+    if (v != last) {
+      if (!v->phorefp || !v->ph_type) return DP_E_BADARG;
+      last = v; last_xs = count_xs(*v);
+    }
+    s->n_xs += last_xs;
     s->max_nl = std::max<int32_t>(s->max_nl, (int32_t)nl); s->max_np = std::max<int32_t>(s->max_np, (int32_t)np);
     s->max_t = std::max<int32_t>(s->max_t, (int32_t)nt);
   }
@@ -55,6 +82,8 @@ static size_t layout_of(int32_t n, const Sizes& s, DpPackLayout* L) {
   L->ph_scalar = take((size_t)s.n_ph * 2 * 4); L->ph_type = take((size_t)s.n_ph * 4);
   L->pp_src = take((size_t)s.n_pp * 4); L->pp_dst = take((size_t)s.n_pp * 4); L->pp_rowptr = take((size_t)s.n_ph * 4); L->pp_rowend = take((size_t)s.n_ph * 4);
   L->pos = take((size_t)s.n_lig * 3 * 4); L->norm = take((size_t)s.n_lig * 33 * 4);
+  L->xs_src = take((size_t)s.n_xs * 4); L->xs_nbr = take((size_t)s.n_xs * 4); L->xs_feat = take((size_t)s.n_xs * 4); L->xs_rowptr = take((size_t)(s.n_lig + 1) * 4);
+  L->xt_src = take((size_t)s.n_xs * 4); L->xt_nbr = take((size_t)s.n_xs * 4); L->xt_feat = take((size_t)s.n_xs * 4); L->xt_rowptr = take((size_t)(s.n_ph + 1) * 4);
   L->bytes = (int64_t)off;
   return off;
 }
@@ -73,6 +102,7 @@ int dp_pack_query(int32_t n, const DpPoseRef* poses, DpBatch* totals, DpPackLayo
   totals->n_lig = (int32_t)s.n_lig; totals->n_ph = (int32_t)s.n_ph; totals->n_bond = (int32_t)s.n_bond; totals->n_tor = (int32_t)s.n_tor;
   totals->n_pp = (int32_t)s.n_pp; totals->n_x = (int32_t)s.n_x; totals->ll_cap = (int32_t)s.ll_cap; totals->n_llp = (int32_t)s.n_llp;
   totals->max_nl = s.max_nl; totals->max_np = s.max_np; totals->max_t = s.max_t;
+  totals->n_xs = (int32_t)s.n_xs;
   memset(layout, 0, sizeof(*layout));
   dpk::layout_of(n, s, layout);
   return DP_OK;
@@ -90,6 +120,10 @@ int dp_pack_fill(int32_t n, const DpPoseRef* poses, const DpPackLayout* L, void*
           *x_ptr = I(L->x_ptr), *ll_ptr = I(L->ll_ptr), *mask_ptr = I(L->mask_ptr), *pose_ptr = I(L->pose_ptr), *llp_ptr = I(L->llp_ptr);
   lig_ptr[0] = ph_ptr[0] = bond_ptr[0] = tor_ptr[0] = pp_ptr[0] = x_ptr[0] = ll_ptr[0] = mask_ptr[0] = pose_ptr[0] = llp_ptr[0] = 0;
   int32_t fl = 0;
+  int32_t *xs_src = I(L->xs_src), *xs_nbr = I(L->xs_nbr), *xs_feat = I(L->xs_feat), *xs_row = I(L->xs_rowptr);
+  int32_t *xt_src = I(L->xt_src), *xt_nbr = I(L->xt_nbr), *xt_feat = I(L->xt_feat), *xt_row = I(L->xt_rowptr);
+  int32_t n_xs = 0, n_xt = 0;
+  const int64_t xs_cap = (L->xs_nbr - L->xs_src) / 4;      // room the layout reserved (dp_pack_query counted the pairs of the same views)
   std::vector<int32_t> deg, cur;
   std::vector<int64_t> keys;
   for (int i = 0; i < n; ++i) {
@@ -167,10 +201,35 @@ int dp_pack_fill(int32_t n, const DpPoseRef* poses, const DpPackLayout* L, void*
       const int slot = cur[(size_t)s]++;
       ps[slot] = p0 + s; pd[slot] = p0 + d;
     }
+    // cross pairs with agreement != 0, by atom and by node (DpBatch.xs_* / xt_*)
+    for (int a = 0; a < nl; ++a) {
+      xs_row[l0 + a] = n_xs;
+      const float* fp = v.phorefp + (size_t)a * 11;
+      for (int j = 0; j < np; ++j) {
+        const int ty = pty[j];
+        if (ty != dpk::EX_TYPE && fp[ty] != 0.f) {
+          if (n_xs >= xs_cap) return DP_E_BADARG;
+          xs_src[n_xs] = l0 + a; xs_nbr[n_xs] = p0 + j; xs_feat[n_xs] = x_ptr[i] + a * np + j; ++n_xs;
+        }
+      }
+    }
+    for (int j = 0; j < np; ++j) {
+      xt_row[p0 + j] = n_xt;
+      const int ty = pty[j];
+      if (ty == dpk::EX_TYPE) continue;
+      for (int a = 0; a < nl; ++a)
+        if (v.phorefp[(size_t)a * 11 + ty] != 0.f) {
+          if (n_xt >= xs_cap) return DP_E_BADARG;
+          xt_src[n_xt] = p0 + j; xt_nbr[n_xt] = l0 + a; xt_feat[n_xt] = x_ptr[i] + a * np + j; ++n_xt;
+        }
+    }
     // diffusion state
     memcpy(F(L->pos) + (size_t)l0 * 3, poses[i].pos, (size_t)nl * 3 * 4);
     memcpy(F(L->norm) + (size_t)l0 * 33, poses[i].norm, (size_t)nl * 33 * 4);
   }
+  xs_row[lig_ptr[n]] = n_xs;
+  xt_row[ph_ptr[n]] = n_xt;
+  if (n_xs != n_xt) return DP_E_BADARG;
   *flags = fl;
   return DP_OK;
 }
@@ -186,6 +245,7 @@ int dp_pack_bind(const DpPackLayout* L, void* base, int32_t flags, DpBatch* b) {
   b->mask_rotate = (const uint8_t*)(p + L->mask_rotate);
   DP_F(phorefp); DP_F(norm_angle1); DP_F(norm_angle2); DP_F(ph_pos); DP_F(ph_norm); DP_I(ph_x); DP_F(ph_scalar); DP_I(ph_type);
   DP_I(pp_src); DP_I(pp_dst); DP_I(pp_rowptr); DP_I(pp_rowend);
+  DP_I(xs_src); DP_I(xs_nbr); DP_I(xs_feat); DP_I(xs_rowptr); DP_I(xt_src); DP_I(xt_nbr); DP_I(xt_feat); DP_I(xt_rowptr);
 #undef DP_I
 #undef DP_F
   b->pos = (float*)(p + L->pos);

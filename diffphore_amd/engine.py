@@ -25,6 +25,10 @@ DEFAULT_PRECISION = "f32"
 # ----------------------------------------------------------------------------------------------------------------------
 # ctypes mirrors of include/diffphore_amd.h
 # ----------------------------------------------------------------------------------------------------------------------
+# the cross pairs with agreement != 0 (DpBatch.xs_* by atom, xt_* by pharmacophore node: include/diffphore_amd.h)
+_XS_ARRAYS = ("xs_src", "xs_nbr", "xs_feat", "xs_rowptr", "xt_src", "xt_nbr", "xt_feat", "xt_rowptr")
+
+
 class DpBatch(C.Structure):
     _fields_ = ([("B", c_i32)] + [(n, c_i32) for n in ("n_lig", "n_ph", "n_bond", "n_tor", "n_pp", "n_x", "ll_cap", "n_llp")]
                 + [(n, c_i32) for n in ("max_nl", "max_np", "max_t", "no_tail_nl", "no_tail_np")]
@@ -32,7 +36,8 @@ class DpBatch(C.Structure):
                                         "pose_ptr", "llp_ptr", "lig_x", "bond_src", "bond_dst", "bond_type", "tor_u", "tor_v",
                                         "mask_rotate", "phorefp", "norm_angle1", "norm_angle2", "ph_pos", "ph_norm", "ph_x",
                                         "ph_scalar", "ph_type", "pp_src", "pp_dst", "pp_rowptr", "pp_rowend", "pos", "norm",
-                                        "t")])
+                                        "t")]
+                + [("n_xs", c_i32)] + [(n, VOIDP) for n in _XS_ARRAYS])
 
 
 class DpGraphView(C.Structure):
@@ -47,7 +52,7 @@ class DpPoseRef(C.Structure):
 
 _PACK_ARRAYS = ("lig_ptr", "ph_ptr", "bond_ptr", "tor_ptr", "pp_ptr", "x_ptr", "ll_ptr", "mask_ptr", "pose_ptr", "llp_ptr",
                 "lig_x", "bond_src", "bond_dst", "bond_type", "tor_u", "tor_v", "mask_rotate", "phorefp", "norm_angle1", "norm_angle2",
-                "ph_pos", "ph_norm", "ph_x", "ph_scalar", "ph_type", "pp_src", "pp_dst", "pp_rowptr", "pp_rowend", "pos", "norm")
+                "ph_pos", "ph_norm", "ph_x", "ph_scalar", "ph_type", "pp_src", "pp_dst", "pp_rowptr", "pp_rowend", "pos", "norm") + _XS_ARRAYS
 
 
 class DpPackLayout(C.Structure):
@@ -664,6 +669,30 @@ class PackedBatch:
         deg = np.bincount(ps, minlength=n_ph)
         rowptr = np.cumsum(deg) - deg                 # CSR over the globally sorted edge list == per-pose offsets + in-pose prefix
         H["pp_rowptr"], H["pp_rowend"] = rowptr.astype(np.int32), (rowptr + deg).astype(np.int32)
+        # cross pairs with agreement != 0 (node j is not an exclusion sphere and phorefp[i, type(j)] != 0), by atom and by node: DpBatch.xs_* / xt_*
+        fp_all, ty_all = H["phorefp"].reshape(-1, 11), H["ph_type"]
+        xs, xt = [[], [], []], [[], [], []]
+        for p in range(B):
+            l0, p0, x0 = int(self.lig_ptr[p]), int(self.ph_ptr[p]), int(self.x_ptr[p])
+            n_l, n_p = int(nl[p]), int(npn[p])
+            ty = ty_all[p0:p0 + n_p]
+            agree = (fp_all[l0:l0 + n_l][:, ty] != 0) & (ty != 10)[None, :]            # [atoms, nodes]
+            ai, aj = np.nonzero(agree)                                                # row-major: by (atom, node)
+            tj, ti = np.nonzero(agree.T)                                              # by (node, atom)
+            for dst, (a_, j_) in ((xs, (ai, aj)), (xt, (ti, tj))):
+                dst[2].append(x0 + a_ * n_p + j_)
+            xs[0].append(l0 + ai); xs[1].append(p0 + aj)
+            xt[0].append(p0 + tj); xt[1].append(l0 + ti)
+        i32cat = lambda parts: np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, dtype=np.int32)      # noqa: E731
+        for pre, lists, n_nodes in (("xs", xs, int(self.lig_ptr[-1])), ("xt", xt, n_ph)):
+            src = i32cat(lists[0])
+            H[pre + "_src"], H[pre + "_nbr"], H[pre + "_feat"] = src, i32cat(lists[1]), i32cat(lists[2])
+            cnt = np.bincount(src, minlength=n_nodes)
+            H[pre + "_rowptr"] = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        self._n_xs = int(H["xs_src"].size)
+        for k_ in ("xs_src", "xs_nbr", "xs_feat", "xt_src", "xt_nbr", "xt_feat"):
+            if H[k_].size == 0:
+                H[k_] = np.zeros(1, dtype=np.int32)
         self._host = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in H.items()}
         self._host_pos = torch.from_numpy(cat([l.pos for l in L], np.float32))
         self._host_norm = torch.from_numpy(np.concatenate([A(l.norm).astype(np.float32, copy=False).reshape(A(l.pos).shape[0], 33) for l in L]))
@@ -700,6 +729,8 @@ class PackedBatch:
                      tor_v=int(tot.n_tor), mask_rotate=max(int(self.mask_ptr[-1]), 1), phorefp=n_lig * 11, norm_angle1=n_lig * 11, norm_angle2=n_lig * 11,
                      ph_pos=n_ph * 3, ph_norm=n_ph * 3, ph_x=n_ph * 3, ph_scalar=n_ph * 2, ph_type=n_ph, pp_src=int(tot.n_pp), pp_dst=int(tot.n_pp),
                      pp_rowptr=n_ph, pp_rowend=n_ph)
+        n_xs = int(tot.n_xs)
+        sizes.update(xs_src=n_xs, xs_nbr=n_xs, xs_feat=n_xs, xs_rowptr=n_lig + 1, xt_src=n_xs, xt_nbr=n_xs, xt_feat=n_xs, xt_rowptr=n_ph + 1)
         fl = {"phorefp", "norm_angle1", "norm_angle2", "ph_pos", "ph_norm", "ph_scalar"}
         self.static = {k: view(k, n, u8 if k == "mask_rotate" else (f32 if k in fl else i32)) for k, n in sizes.items()}
         for k, cols in (("lig_x", 16), ("phorefp", 11), ("norm_angle1", 11), ("norm_angle2", 11), ("ph_pos", 3), ("ph_norm", 3), ("ph_x", 3), ("ph_scalar", 2)):
@@ -731,6 +762,7 @@ class PackedBatch:
         s.n_lig, s.n_ph, s.n_bond, s.n_tor = int(self.lig_ptr[-1]), n_ph, int(self.bond_ptr[-1]), int(self.tor_ptr[-1])
         s.n_pp, s.n_x, s.ll_cap = int(self.pp_ptr[-1]), int(self.x_ptr[-1]), int(self.ll_ptr[-1])
         s.n_llp = int(self.llp_ptr[-1]) if self.ll_pairs_ok else 0
+        s.n_xs = self._n_xs
         s.max_nl, s.max_np, s.max_t = int(nl.max()), int(npn.max()), int(nt.max())
         # hints for the node-side convs: no pose ends on a pass of <= 16 edge slots -> the lean kernel instantiation (DpConvArgs.no_tail)
         tail = lambda v: bool((((v - 1) % 32) < 16).any())                     # noqa: E731  (v mod 32 in 1..16)

@@ -31,7 +31,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 10
+#define DP_ABI_VERSION 11
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -49,8 +49,9 @@ enum DpEdgeMode {
   DP_EDGES_P2L = 1,     /* dense cross, scatter = ligand atom i, gather = phore node j      (:682-689) */
   DP_EDGES_L2P = 2,     /* dense cross, scatter = phore node j, gather = ligand atom i      (:695-700) */
   DP_EDGES_CENTER = 3,  /* scatter = pose, one edge per ligand atom                         (:381-406) */
-  DP_EDGES_LLPAIR = 4   /* node-side kernel only: ligand-ligand edges as a dense atom x atom pair table of one pose; pair (i, j) carries
+  DP_EDGES_LLPAIR = 4,  /* node-side kernel only: ligand-ligand edges as a dense atom x atom pair table of one pose; pair (i, j) carries
                            up to two edges (radius + bond, build_lig_conv_graph :715-739) found through pair_a / pair_b */
+  DP_EDGES_LIST = 5     /* edge-side kernel, DP_PREC_F16X3 only: an explicit edge list whose per-edge messages are written out (DpConvArgs.msg_out) */
 };
 
 /* arithmetic of the radial-MLP second layer (the 60 x numel contraction that dominates the path) */
@@ -153,6 +154,19 @@ typedef struct DpConvArgs {
                                 (edges per node mod 32 is 0 or > 16 for every pose), so the launch may use the instantiation without the
                                 half-pass variant (half the code, ~40 % fewer spilled registers, ~2 % faster).  0 = unknown: the general
                                 kernel.  Results are identical either way when the hint is true. */
+  int32_t s0_only;           /* node-side DP_PREC_F16X3 kernel, modes P2L / L2P: 1 = the caller guarantees that edge_sh is e0 = (1, 0, ..., 0) on every
+                                edge this conv is asked to cover, so only the tensor-product paths through the l = 0 component are evaluated (the
+                                other paths' operands are identically zero).  dp_forward sets it on the two "normals" convs of a layer
+                                (phore_to_lig_norm / lig_to_phore_norm, score_model_phore.py:686-689,698-700): their spherical harmonics are e0
+                                wherever the pharmacophore type does not agree with the atom's fingerprint (:874-894 - r = 0 there), and the few
+                                pairs that do agree (DpBatch.xs_*) are added by an edge-side launch over exactly those pairs (DP_EDGES_LIST) */
+  /* DP_EDGES_LIST (edge-side kernel at DP_PREC_F16X3 only): an explicit list of n_list edges anywhere in the batch - edge k scatters onto node
+   * edge_scat[k], gathers node nbr[k], reads row feat_idx[k] of edge_emb / edge_sh; attr_swap as for DP_EDGES_CSR.  The launch writes the edges'
+   * MESSAGES msg_out[k][D_out] (no mean, no BatchNorm: dp_list_reduce finishes the conv) - 128 edges per workgroup whatever nodes they belong to */
+  const int32_t* feat_idx;
+  float* msg_out;
+  int32_t n_list;
+  int32_t sh0_zero;          /* DP_EDGES_LIST: 1 = component 0 of every edge_sh row is read as 0 (the l = 0 part of the conv is computed elsewhere) */
 } DpConvArgs;
 
 /* Fused gather -> radial MLP (MFMA) -> Clebsch-Gordan tensor product -> per-node segmented mean -> e3nn BatchNorm(eval).
@@ -247,6 +261,16 @@ typedef struct DpBatch {
   float* pos;                 /* [n_lig,3] */
   float* norm;                /* [n_lig,33] ligand normal buffer (atom-major [N,11,3]) */
   const float* t;             /* [B,3] diffusion times (tr, rot, tor) per pose            diffusion_utils.py:181-207 */
+  /* The cross pairs (atom i, pharmacophore node j) whose "normals" spherical harmonics can differ from e0 = (1, 0, ..., 0): the pairs with
+   * agreement != 0, i.e. node j is not an exclusion sphere and phorefp[i, type(j)] != 0 (score_model_phore.py:790-793,874-894: the vector the
+   * harmonics are taken of is cross(...) * sum(agreement), exactly 0 without agreement).  STATIC (pose-independent), built by dp_pack_fill;
+   * listed twice, as CSR over the scatter nodes of each direction.  dp_forward evaluates the two normals convs of a layer as their l = 0 part on
+   * every pair (DpConvArgs.s0_only) + the other paths on these pairs only (DP_EDGES_LIST).  NULL / n_xs < 0 = not provided: the dense convs. */
+  int32_t n_xs;               /* number of such pairs in the batch */
+  const int32_t *xs_src, *xs_nbr, *xs_feat;   /* [n_xs] sorted by (pose, atom, node): global atom id, global node id, dense cross row x_ptr[p] + i N_p + j */
+  const int32_t* xs_rowptr;                   /* [n_lig + 1] the pairs of atom a are xs_rowptr[a] .. xs_rowptr[a + 1] */
+  const int32_t *xt_src, *xt_nbr, *xt_feat;   /* [n_xs] sorted by (pose, node, atom): global node id, global atom id, the same dense cross row */
+  const int32_t* xt_rowptr;                   /* [n_ph + 1] */
 } DpBatch;
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -277,6 +301,7 @@ typedef struct DpPackLayout {
   int64_t lig_ptr, ph_ptr, bond_ptr, tor_ptr, pp_ptr, x_ptr, ll_ptr, mask_ptr, pose_ptr, llp_ptr;
   int64_t lig_x, bond_src, bond_dst, bond_type, tor_u, tor_v, mask_rotate, phorefp, norm_angle1, norm_angle2;
   int64_t ph_pos, ph_norm, ph_x, ph_scalar, ph_type, pp_src, pp_dst, pp_rowptr, pp_rowend, pos, norm;
+  int64_t xs_src, xs_nbr, xs_feat, xs_rowptr, xt_src, xt_nbr, xt_feat, xt_rowptr;
   int64_t bytes;
 } DpPackLayout;
 /* totals (B, n_*, max_*) of the batch into *totals and the block layout into *layout; DP_E_TOOLARGE for a pose over the kernel limits

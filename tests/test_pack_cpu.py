@@ -19,7 +19,8 @@ def _native_arrays(pb):
                llp_ptr=B + 1, lig_x=n_lig * 16, bond_src=tot.n_bond, bond_dst=tot.n_bond, bond_type=tot.n_bond, tor_u=tot.n_tor, tor_v=tot.n_tor,
                mask_rotate=int(pb.mask_ptr[-1]), phorefp=n_lig * 11, norm_angle1=n_lig * 11, norm_angle2=n_lig * 11, ph_pos=n_ph * 3, ph_norm=n_ph * 3,
                ph_x=n_ph * 3, ph_scalar=n_ph * 2, ph_type=n_ph, pp_src=tot.n_pp, pp_dst=tot.n_pp, pp_rowptr=n_ph, pp_rowend=n_ph, pos=n_lig * 3,
-               norm=n_lig * 33)
+               norm=n_lig * 33, xs_src=tot.n_xs, xs_nbr=tot.n_xs, xs_feat=tot.n_xs, xs_rowptr=n_lig + 1, xt_src=tot.n_xs, xt_nbr=tot.n_xs, xt_feat=tot.n_xs,
+               xt_rowptr=n_ph + 1)
     fl = {"phorefp", "norm_angle1", "norm_angle2", "ph_pos", "ph_norm", "ph_scalar", "pos", "norm"}
     out = {}
     for k, n in cnt.items():
@@ -48,6 +49,8 @@ def test_native_pack_equals_numpy_pack():
         w = v.numpy().reshape(-1)
         if k == "mask_rotate" and int(b.mask_ptr[-1]) == 0:
             continue
+        if k[:3] in ("xs_", "xt_") and not k.endswith("rowptr") and b._n_xs == 0:
+            continue
         assert np.array_equal(na[k], w.view(na[k].dtype) if w.dtype != na[k].dtype and w.dtype.itemsize == na[k].dtype.itemsize else w.astype(na[k].dtype)), k
     assert np.array_equal(na["pos"], b._host_pos.numpy().reshape(-1)) and np.array_equal(na["norm"], b._host_norm.numpy().reshape(-1))
     for k in ("lig_ptr", "ph_ptr", "bond_ptr", "tor_ptr", "pp_ptr", "x_ptr", "ll_ptr", "mask_ptr", "llp_ptr"):
@@ -59,6 +62,21 @@ def test_native_pack_equals_numpy_pack():
         len(poses), int(b.lig_ptr[-1]), int(b.ph_ptr[-1]), int(b.bond_ptr[-1]), int(b.tor_ptr[-1]), int(b.pp_ptr[-1]), int(b.x_ptr[-1]), int(b.ll_ptr[-1]),
         int(b.llp_ptr[-1]))
     assert (t.max_nl, t.max_np, t.max_t) == (int(b.nl.max()), int(b.np_.max()), int(b.nt.max()))
+    # the cross pairs with agreement != 0 (DpBatch.xs_* / xt_*): the same set in both orders, exactly the pairs the definition names
+    assert t.n_xs == b._n_xs > 0
+    fp, ty = b._host["phorefp"].numpy().reshape(-1, 11), b._host["ph_type"].numpy()
+    want = set()
+    for p in range(len(poses)):
+        for i in range(int(b.lig_ptr[p]), int(b.lig_ptr[p + 1])):
+            for j in range(int(b.ph_ptr[p]), int(b.ph_ptr[p + 1])):
+                if ty[j] != 10 and fp[i, ty[j]] != 0:
+                    want.add((i, j, int(b.x_ptr[p]) + (i - int(b.lig_ptr[p])) * int(b.np_[p]) + (j - int(b.ph_ptr[p]))))
+    assert set(zip(na["xs_src"].tolist(), na["xs_nbr"].tolist(), na["xs_feat"].tolist())) == want and len(want) == t.n_xs
+    assert set(zip(na["xt_nbr"].tolist(), na["xt_src"].tolist(), na["xt_feat"].tolist())) == want
+    assert np.all(np.diff(na["xs_src"]) >= 0) and np.all(np.diff(na["xt_src"]) >= 0)
+    assert na["xs_rowptr"][-1] == t.n_xs == na["xt_rowptr"][-1]
+    for a_ in range(int(t.n_lig)):
+        assert np.all(na["xs_src"][na["xs_rowptr"][a_]:na["xs_rowptr"][a_ + 1]] == a_)
     assert a._flags & 2 and a._flags & 4                                            # the 16-atom / 33-node complex ends on short passes
     # dp_pack_bind: pointers = base + offsets, hints from the flags
     s = engine.DpBatch()
