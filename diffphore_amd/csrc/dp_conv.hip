@@ -11,9 +11,39 @@ int dp_conv_launch_k4(const DpConvArgs& a, hipStream_t st) { return dp::launch<4
 int dp_conv_launch_k5(const DpConvArgs& a, hipStream_t st) { return dp::launch<5>(a, st); }
 #endif
 
+namespace dp {
+// finishes a DP_EDGES_LIST conv: the scatter MEAN over the node's FULL degree (the listed edges are a subset of a dense conv's edges: the degree
+// is the pose's number of gather nodes), the BatchNorm scale, and the sum onto `out`.  One workgroup per pose; a node's messages are added in list
+// order by one thread per channel: deterministic.
+__global__ __launch_bounds__(256) void list_reduce_kernel(const float* __restrict__ msg, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ scat_ptr,
+                                                          const int32_t* __restrict__ deg_ptr, int d_out, const float* __restrict__ bn_scale,
+                                                          float* __restrict__ out, int out_stride) {
+  const int p = blockIdx.x;
+  const int n0 = scat_ptr[p], n1 = scat_ptr[p + 1];
+  if (rowptr[n0] == rowptr[n1]) return;             // no listed edge in this pose
+  const int deg = deg_ptr[p + 1] - deg_ptr[p];
+  const float inv = 1.f / (float)(deg > 1 ? deg : 1);
+  for (int i = threadIdx.x; i < (n1 - n0) * d_out; i += 256) {
+    const int n = n0 + i / d_out, c = i % d_out;
+    const int k0 = rowptr[n], k1 = rowptr[n + 1];
+    if (k0 == k1) continue;
+    float s = 0.f;
+    for (int k = k0; k < k1; ++k) s += msg[(size_t)k * d_out + c];
+    out[(size_t)n * out_stride + c] += (s * inv) * bn_scale[c];
+  }
+}
+}  // namespace dp
+
 extern "C" {
 
 int dp_abi_version(void) { return DP_ABI_VERSION; }
+
+int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int32_t* scat_ptr, const int32_t* deg_ptr, int32_t d_out,
+                   const float* bn_scale, float* out, int32_t out_stride, void* stream) {
+  if (!msg || !rowptr || B <= 0 || !scat_ptr || !deg_ptr || d_out <= 0 || !bn_scale || !out || out_stride < d_out) return DP_E_BADARG;
+  hipLaunchKernelGGL(dp::list_reduce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, msg, rowptr, scat_ptr, deg_ptr, d_out, bn_scale, out, out_stride);
+  return (int)hipGetLastError();
+}
 
 int dp_conv_max_nodes(int32_t precision) { return precision == DP_PREC_F32 ? dp::MAX_NODES : dp::MAX_NODES_B; }
 
@@ -82,6 +112,19 @@ int dp_resolve_conv_algo(int32_t algo, int32_t precision, int32_t B) {
 
 int dp_tp_conv(const DpConvArgs* a, void* stream) {
   if (a && a->algo == DP_ALGO_NODE) return dp_tp_conv_node(a, stream);
+  if (a && a->mode == DP_EDGES_LIST) {           // explicit edge list -> per-edge messages (kinds 0-3, DP_PREC_F16X3; finished by dp_list_reduce)
+    if (a->n_list < 0 || (a->n_list > 0 && (!a->nbr || !a->edge_scat || !a->feat_idx || !a->msg_out)) || !a->gather_tab || !a->attr1_tab || !a->attr2_tab ||
+        !a->edge_emb || !a->edge_sh || !a->w1p || !a->w2p)
+      return DP_E_BADARG;
+    if (a->kind < 0 || a->kind > 3) return DP_E_UNSUPPORTED;
+    hipStream_t st_ = (hipStream_t)stream;
+    switch (a->kind) {
+      case 0: return dp_conv_launch_k0(*a, st_);
+      case 1: return dp_conv_launch_k1(*a, st_);
+      case 2: return dp_conv_launch_k2(*a, st_);
+      default: return dp_conv_launch_k3(*a, st_);
+    }
+  }
   if (!a || a->B <= 0 || a->slices <= 0 || !a->scat_ptr || !a->gather_tab || !a->attr1_tab || !a->edge_emb || !a->edge_sh ||
       !a->w1p || !a->w2p || !a->bn_scale || !a->bn_shift || !a->out)
     return DP_E_BADARG;

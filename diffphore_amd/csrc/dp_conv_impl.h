@@ -301,6 +301,13 @@ struct WgRange {
 __device__ __forceinline__ WgRange wg_range(const DpConvArgs& a, int bid = -1) {
   WgRange r;
   if (bid < 0) bid = blockIdx.x;
+  if (a.mode == DP_EDGES_LIST) {        // workgroup = 128 consecutive edges of the list, whatever nodes they belong to (messages are written out)
+    r.pose = r.sc0 = r.n_lo = r.l0 = r.p0 = r.NL = r.NP = r.x0 = 0;
+    r.k_begin = bid * 128;
+    r.k_end = r.k_begin + 128 < a.n_list ? r.k_begin + 128 : a.n_list;
+    r.n_hi = r.n_loc = r.k_begin < a.n_list ? 1 : 0;
+    return r;
+  }
   r.pose = bid / a.slices;
   const int slice = bid % a.slices;
   r.sc0 = a.scat_ptr[r.pose];
@@ -350,6 +357,14 @@ __device__ __forceinline__ EdgeRef decode_edge(const DpConvArgs& a, const WgRang
     const int sg = in_rng ? sabs : r.n_lo;
     e.a1 = a.attr_swap ? e.gather : sg;
     e.a2 = a.attr_swap ? sg : e.gather;
+  } else if (a.mode == DP_EDGES_LIST) {
+    const int kk = valid ? k : r.k_begin;
+    e.feat = a.feat_idx[kk];
+    e.gather = a.nbr[kk];
+    const int sabs = a.edge_scat[kk];
+    e.scat_local = valid ? 0 : -1;
+    e.a1 = a.attr_swap ? e.gather : sabs;
+    e.a2 = a.attr_swap ? sabs : e.gather;
   } else if (a.mode == DP_EDGES_P2L) {
     const int kk = valid ? k : r.k_begin;
     const int i = kk / r.NP, j = kk - i * r.NP;
@@ -400,6 +415,7 @@ __device__ __forceinline__ void load_tp_operands(const DpConvArgs& a, const Edge
   const float* ps = a.edge_sh + (size_t)e.feat * a.sh_stride;
 #pragma unroll
   for (int i = 0; i < S::SH_DIM; ++i) sh[i] = ps[i];
+  if (a.mode == DP_EDGES_LIST && a.sh0_zero) sh[0] = 0.f;      // the l = 0 part of the conv is computed elsewhere (DpConvArgs.s0_only)
 #pragma unroll
   for (int i = 0; i < 9; ++i) M[i] = 0.f;
   if constexpr (S::SH_DIM == 9) {              // sqrt(10) * sum_j sh2[j] C(1,2,1)[i,j,k]  (1/sqrt10 folded into W2p)
@@ -510,6 +526,19 @@ __device__ __forceinline__ void merge_wave_partials(const float* s_msg, int ld, 
         const int node = s_pnode[q];
         if (node >= 0) s_acc[node * D_OUT + ch] += s_msg[(size_t)q * 32 * ld + col];
       }
+    }
+  }
+}
+
+// DP_EDGES_LIST: the wave's staged message rows go out as they are - dst = row of the wave's first edge in msg_out [n_list, D_OUT], n_rows of them exist
+template <int D_OUT, int NCOL, typename ChanFn>
+__device__ __forceinline__ void wave_emit(const float* rows, int ld, int lane, float* __restrict__ dst, int n_rows, ChanFn chan) {
+#pragma unroll
+  for (int p = 0; p < (NCOL + 63) / 64; ++p) {
+    const int col = lane + 64 * p;
+    if (col < NCOL) {
+      const int ch = chan(col);
+      for (int ei = 0; ei < n_rows; ++ei) dst[(size_t)ei * D_OUT + ch] = rows[ei * ld + col];
     }
   }
 }
@@ -887,12 +916,13 @@ struct OperandPipe {
 // Stage TILE of the split-bf16 pipeline.  The packed weights stream L2 -> LDS through a RING-deep ring filled by LDS-DMA
 // RING-1 tiles ahead (an L2 round trip under load is ~2k cycles, longer than one bf16 tile), so a tile costs:
 //   issue DMA(tile+RING-1) | ds_read operands | 12 or 24 bf16 MFMAs | VALU contraction | counted vmcnt | s_barrier.
-template <int KIND, int NS, int TILE, bool FULL = false, bool F16 = false>
+// EMIT (DP_EDGES_LIST): the staged messages are written to `emit` (the wave's first row of msg_out; emit_rows rows exist) instead of being summed
+template <int KIND, int NS, int TILE, bool FULL = false, bool F16 = false, bool EMIT = false>
 struct StageB {
   static __device__ __forceinline__ void run(gptrq w2p, int wave, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
                                              const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
                                              const float (&M)[9], float (&acc)[NACC<KIND>], float* row, int half,
-                                             float* s_msg, int* s_pnode, float* s_acc, int scat_local) {
+                                             float* s_msg, int* s_pnode, float* s_acc, int scat_local, float* emit = nullptr, int emit_rows = 0) {
     using G = Geo<KIND>;
     constexpr int NT0 = n_tiles_phase<KIND>(0);
     constexpr int NQ = TILE_QUADS<KIND, NS>;
@@ -902,11 +932,17 @@ struct StageB {
         PROF_MARK(3);
         stage_phase<KIND, 0, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0) / 2>{});
         const auto chan0 = [](int c) { return kChanLut<KIND, 0>.v[c]; };
+        if constexpr (EMIT) {
+          // (the stores count on vmcnt like the ring's DMA pieces: the counted waits below then ask for no less than before - loads land in order)
+          wave_emit<Spec<KIND>::D_OUT, n_acc_phase<KIND>(0)>(s_msg + (size_t)wave * 32 * MSG_LD_B<KIND>, MSG_LD_B<KIND>, lane, emit, emit_rows, chan0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are read before phase 1 restages them (each wave its own)
+        } else {
         wave_segsum<Spec<KIND>::D_OUT, n_acc_phase<KIND>(0)>(s_msg + (size_t)wave * 32 * MSG_LD_B<KIND>, MSG_LD_B<KIND>, lane, scat_local,
                                                              s_acc, &s_pnode[wave], chan0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS only: the weight ring's DMA stays in flight across this barrier
         __builtin_amdgcn_s_barrier();                          // (phase-1 tiles end in barriers: rows are not restaged before wave 0 is done)
         if (wave == 0) merge_wave_partials<Spec<KIND>::D_OUT, n_acc_phase<KIND>(0), WAVES_B>(s_msg, MSG_LD_B<KIND>, lane, s_pnode, s_acc, chan0);
+        }
 #pragma unroll
         for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
         PROF_MARK(4);
@@ -961,13 +997,17 @@ struct StageB {
         __builtin_amdgcn_s_barrier();
       }
       __builtin_amdgcn_sched_barrier(0);
-      StageB<KIND, NS, TILE + 1, FULL, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local);
+      StageB<KIND, NS, TILE + 1, FULL, F16, EMIT>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local, emit, emit_rows);
     } else {
       constexpr int PHL = n_tiles_phase<KIND>(1) > 0 ? 1 : 0;
       PROF_MARK(5);
       if constexpr (PHL == 1 && n_tiles_phase<KIND>(1) < 2 && n_tiles_phase<KIND>(0) > 0) __syncthreads();   // wave 0 may still be merging phase 0
       stage_phase<KIND, PHL, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(PHL) / 2>{});
       const auto chanl = [](int c) { return kChanLut<KIND, PHL>.v[c]; };
+      if constexpr (EMIT) {
+        wave_emit<Spec<KIND>::D_OUT, n_acc_phase<KIND>(PHL)>(s_msg + (size_t)wave * 32 * MSG_LD_B<KIND>, MSG_LD_B<KIND>, lane, emit, emit_rows, chanl);
+        return;
+      }
       wave_segsum<Spec<KIND>::D_OUT, n_acc_phase<KIND>(PHL)>(s_msg + (size_t)wave * 32 * MSG_LD_B<KIND>, MSG_LD_B<KIND>, lane, scat_local,
                                                              s_acc, &s_pnode[wave], chanl);
       __syncthreads();
@@ -1079,7 +1119,7 @@ struct StageP {
 #define DP_PIPE_NS1 1      // 0: the one-product kernel on StageB like the split kernels (A/B builds)
 #endif
 
-template <int KIND, int NS, bool FULL = false, bool F16 = false>
+template <int KIND, int NS, bool FULL = false, bool F16 = false, bool EMIT = false>
 __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArgs a) {
   using S = Spec<KIND>;
   using G = Geo<KIND>;
@@ -1140,10 +1180,15 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (NS == 1)
         StageP<KIND, 0, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local, D0);
+    } else if constexpr (EMIT) {
+      const int k0 = kc + wave * 32, left = r.k_end - k0;
+      StageB<KIND, NS, 0, FULL, F16, true>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local,
+                                                a.msg_out + (size_t)k0 * S::D_OUT, left < 0 ? 0 : (left > 32 ? 32 : left));
     } else {
       StageB<KIND, NS, 0, FULL, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local);
     }
   }
+  if constexpr (EMIT) return;
   __syncthreads();
   conv_epilogue<KIND, WAVES_B * 64>(a, r, s_acc);
   PROF_MARK(7);
@@ -1151,6 +1196,16 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
 
 template <int KIND> int launch(const DpConvArgs& a_in, hipStream_t st) {
   DpConvArgs a = a_in;
+  if (a.mode == DP_EDGES_LIST) {                 // explicit edge list, messages written out: the two-limb fp16 form of the layer convs only
+    if constexpr (KIND <= 3) {
+      if (a.precision != DP_PREC_F16X3) return DP_E_UNSUPPORTED;
+      if (a.n_list <= 0) return DP_OK;
+      hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2, false, true, true>), dim3((unsigned)((a.n_list + CHUNK_B - 1) / CHUNK_B)), dim3(WAVES_B * 64), 0, st, a);
+      return (int)hipGetLastError();
+    } else {
+      return DP_E_UNSUPPORTED;
+    }
+  }
   // phase-split needs both phases to exist and is implemented by the fp32-MFMA kernel only
   if (a.precision != DP_PREC_F32 || n_tiles_phase<KIND>(0) == 0 || n_tiles_phase<KIND>(1) == 0) a.phase_split = 0;
   dim3 grid((unsigned)(a.B * a.slices * (a.phase_split ? 2 : 1)));

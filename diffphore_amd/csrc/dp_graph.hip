@@ -836,13 +836,46 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while (B * slices < 512 && slices < 8) ++slices;
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
-  // the normals convs (phore_to_lig_norm / lig_to_phore_norm) split into their l = 0 part on every pair (node-side, s0-only instantiation) and the
-  // other paths on the listed pairs whose harmonics are not e0
+  // The two "normals" convs of a layer (phore_to_lig_norm / lig_to_phore_norm, :686-689,698-700).  Their spherical harmonics are e0 = (1, 0, ..., 0) on
+  // every cross pair without type agreement (:874-894: the vector they are taken of is cross(...) * sum(agreement)), and the pairs WITH agreement are a
+  // static, short list (DpBatch.xs_* / xt_*: 3 % of the pairs of the synthetic workloads, 5 feature nodes of 79 in the shipped example).  The conv is
+  // bilinear in (features, harmonics), so it is evaluated as
+  //     [paths through the l = 0 component, on every pair]   node-side kernel, s0-only instantiation: no per-node operand build, a third of the columns
+  //   + [the other paths, on the listed pairs only]          edge-side kernel over the list (DP_EDGES_LIST, harmonics read with component 0 = 0) + dp_list_reduce
+  // - the same sum term by term, minus the terms that multiply by an exact zero.  Taken when the f16x3 node-side kernels run, the batch carries the
+  // lists and they are short (a dense list costs more edge-side than the node-side conv it replaces); DpWork.xn_sparse = 2 keeps the dense convs.
 #ifdef DP_S0_TIMING      // timing build (wrong results): the l = 0 part only
   const bool xs_lig = f16_lig, xs_ph = f16_ph;
+  const bool xs_list = false;
 #else
-  const bool xs_lig = false, xs_ph = false;
+  const bool xs_have = b->xs_src && b->xs_nbr && b->xs_feat && b->xs_rowptr && b->xt_src && b->xt_nbr && b->xt_feat && b->xt_rowptr && b->n_xs >= 0 &&
+                       k->xs_msg != nullptr && w->p2l_norm_conv[0].w2x && w->p2l_norm_conv[0].bn_scale_x && w->l2p_norm_conv[0].w2x && w->l2p_norm_conv[0].bn_scale_x;
+  const bool xs_want = k->xn_sparse == 1 || (k->xn_sparse == 0 && (long long)b->n_xs * 4 <= (long long)b->n_x);
+  const bool xs_lig = f16_lig && xs_have && xs_want, xs_ph = f16_ph && xs_have && xs_want;
+  const bool xs_list = true;
 #endif
+  // the listed pairs of one normals conv: messages edge-side, then mean / BatchNorm scale / sum onto the conv's output rows (after the launch that wrote them)
+  auto xs_launch = [&](int l_, bool lig_side, const float* hl_, const float* hp_, float* out_, hipStream_t s_) -> int {
+    if (!xs_list || b->n_xs <= 0) return DP_OK;
+    const DpConvW& cw = lig_side ? w->p2l_norm_conv[l_] : w->l2p_norm_conv[l_];
+    static const int DOUT[4] = {50, 80, 100, 100};
+    float* msg = k->xs_msg + (lig_side ? (size_t)0 : (size_t)b->n_xs * 100);
+    DpConvArgs c;
+    memset(&c, 0, sizeof(c));
+    c.kind = l_; c.mode = DP_EDGES_LIST; c.B = B; c.slices = 1; c.precision = DP_PREC_F16X3; c.max_scatter = 1;
+    c.n_list = b->n_xs; c.sh0_zero = 1; c.msg_out = msg;
+    c.edge_scat = lig_side ? b->xs_src : b->xt_src; c.nbr = lig_side ? b->xs_nbr : b->xt_nbr; c.feat_idx = lig_side ? b->xs_feat : b->xt_feat;
+    // attr1 = the ligand atom, attr2 = the pharmacophore node in both directions (:682-700): scatter / gather for phore->ligand, swapped for ligand->phore
+    c.attr_swap = lig_side ? 0 : 1;
+    c.gather_tab = lig_side ? hp_ : hl_; c.attr1_tab = hl_; c.attr2_tab = hp_;
+    c.gather_stride = c.attr1_stride = c.attr2_stride = 100;
+    c.edge_emb = k->x_emb; c.edge_sh = k->x_nsh; c.sh_stride = 9;
+    c.w1p = cw.w1p; c.w2p = cw.w2x;
+    int r = dp_tp_conv(&c, s_);
+    if (r) return r;
+    return dp_list_reduce(msg, lig_side ? b->xs_rowptr : b->xt_rowptr, B, lig_side ? b->lig_ptr : b->ph_ptr, lig_side ? b->ph_ptr : b->lig_ptr, DOUT[l_],
+                          cw.bn_scale_x, out_, 100, s_);
+  };
   auto node_path_split = [&](int B_, int slices_) {
     return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(B_, slices_, f16_ok)));
   };
@@ -957,6 +990,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
           if ((rc = timed(ligc[1 + nv], l, 1 + nv, st))) return fail(rc);
       }
     }
+    if (xs_lig && (rc = xs_launch(l, true, hl, hp, hl2, st))) return fail(rc);
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
       {
         DpConvArgs c = a;
@@ -988,6 +1022,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         for (int nv = 0; nv < 2; ++nv)
           if ((rc = timed(phc[nv], l, 4 + nv, sp_))) return fail(rc);
       }
+      if (xs_ph && (rc = xs_launch(l, false, hl, hp, hp2, sp_))) return fail(rc);
     }
     if (two) join();
     cur ^= 1;

@@ -89,7 +89,8 @@ class DpWork(C.Structure):
                 + [(n, VOIDP) for n in ("c_emb", "c_sh", "gpred", "t_rowptr", "t_rowend", "t_nbr", "t_src", "t_emb", "t_sh",
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("prof_events", VOIDP), ("conv_algo", c_i32)]
-                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("path_split", c_i32), ("conv_fuse", c_i32), ("node_f16", c_i32)])
+                + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("path_split", c_i32), ("conv_fuse", c_i32), ("node_f16", c_i32),
+                                                                                 ("xs_msg", VOIDP), ("xn_sparse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -218,7 +219,8 @@ class DeviceModel:
                 node = name != "ph_conv" and prec == _lib.PREC_F32
                 node_bf = name != "ph_conv" and prec == _lib.PREC_BF16
                 # edge-side in an fp32 model (phore-phore always, ligand-ligand for large ligands): two-limb fp16 second layer as well (w2x, bnx)
-                x6 = ((name == "ph_conv" and l < 3) or name == "lig_conv") and prec == _lib.PREC_F32
+                # ... and the two normals convs: the pairs whose harmonics are not e0 run edge-side as an explicit list (DP_EDGES_LIST)
+                x6 = ((name == "ph_conv" and l < 3) or name in ("lig_conv", "l2p_norm_conv", "p2l_norm_conv")) and prec == _lib.PREC_F32
                 # node-side in an fp32 model: the fp32-grade two-limb fp16 fragments as well (DP_PREC_F16X3: what those convs run on by default)
                 for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6, node_bf16=node_bf, node_f16=node).items():
                     H[f"{name}.{l}.{part}"] = t
@@ -891,6 +893,11 @@ class Engine:
         self.ws.struct.node_f16 = int(f16)           # 1 (default): node-side convs of an fp32 model as two fp16 limbs per operand (DP_PREC_F16X3); 0: fp32 MFMA
         self.node_side_convs = ("f16x3" if f16 == "1" else "f32") if model.precision == "f32" else model.precision
         self.edge_side_convs = ("f16x3" if x6 == "1" else "f32") if model.precision == "f32" else model.precision
+        xn = os.environ.get("DIFFPHORE_XN_SPARSE", "auto")
+        if xn not in ("auto", "1", "0"):
+            raise ValueError(f"DIFFPHORE_XN_SPARSE must be auto, 1 or 0 (got {xn!r})")
+        # the normals convs as their l = 0 part + the listed pairs with agreement != 0 (DpWork.xn_sparse): library's choice / whenever possible / never
+        self.ws.struct.xn_sparse = {"auto": 0, "1": 1, "0": 2}[xn]
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         ps = os.environ.get("DIFFPHORE_PATH_SPLIT", "auto")
         if ps not in ("auto", "1", "0"):

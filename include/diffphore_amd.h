@@ -172,6 +172,12 @@ typedef struct DpConvArgs {
 /* Fused gather -> radial MLP (MFMA) -> Clebsch-Gordan tensor product -> per-node segmented mean -> e3nn BatchNorm(eval).
  * Replaces TensorProductConvLayer.forward, score_model_phore.py:134-149. */
 int dp_tp_conv(const DpConvArgs* args, void* stream);
+/* Finishes a DP_EDGES_LIST launch: out[n][c] += bn_scale[c] * (sum of msg[k][c] over the listed edges k of node n, rowptr[n] .. rowptr[n + 1], in list
+ * order) / max(deg, 1), deg = deg_ptr[p + 1] - deg_ptr[p] of the node's pose p (nodes scat_ptr[p] .. scat_ptr[p + 1]): the scatter MEAN of
+ * TensorProductConvLayer.forward (score_model_phore.py:141) runs over ALL edges of the dense conv the list is a part of, then BatchNorm's scale.
+ * bn_scale: what the messages' weights were packed with (DpConvW.bn_scale_x for DP_PREC_F16X3).  Deterministic (one thread per node and channel). */
+int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int32_t* scat_ptr, const int32_t* deg_ptr, int32_t d_out,
+                   const float* bn_scale, float* out, int32_t out_stride, void* stream);
 /* the node-side kernel directly (dp_tp_conv dispatches here when args->algo == DP_ALGO_NODE) */
 int dp_tp_conv_node(const DpConvArgs* args, void* stream);
 int dp_conv_node_max_nodes(void);
@@ -417,6 +423,13 @@ typedef struct DpWork {
   int32_t node_f16;                 /* 1 = the node-side convs of an fp32 model use DpConvW.w1h / w2h when present and the launch is not path-split:
                                        DP_PREC_F16X3, fp32-grade two-limb fp16 operands on the 16-bit matrix pipe (the default dp_work_bind sets);
                                        0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+  float* xs_msg;                    /* [2, n_xs, 100] per-edge messages of the listed pairs of the two normals convs of a layer (DP_EDGES_LIST; the two
+                                       sides of a layer may run on two streams: one half each) */
+  int32_t xn_sparse;                /* the two normals convs of a layer (phore_to_lig_norm / lig_to_phore_norm): 0 = library's choice - when they run on the
+                                       f16x3 node-side kernel, the batch carries the pair lists (DpBatch.xs_*) and at most a quarter of the cross pairs is
+                                       listed, each is evaluated as its l = 0 part on every pair (DpConvArgs.s0_only, its own node-side launch) + the
+                                       other paths on the listed pairs (DP_EDGES_LIST + dp_list_reduce): the same sum, term by term, without the terms
+                                       that multiply by an exact zero; 1 = whenever possible, 2 = never (the dense conv; A/B runs and tests) */
 } DpWork;
 
 typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */

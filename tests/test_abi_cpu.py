@@ -110,7 +110,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
     L = engine._declare()
     b = engine.DpBatch()
     assert L.dp_work_bytes(C.byref(b)) == 0                                   # B == 0 -> rejected
-    b.B, b.n_lig, b.n_ph, b.n_bond, b.n_tor, b.n_pp, b.n_x, b.ll_cap = 4, 120, 128, 250, 32, 900, 3840, 4200
+    b.B, b.n_lig, b.n_ph, b.n_bond, b.n_tor, b.n_pp, b.n_x, b.ll_cap, b.n_xs = 4, 120, 128, 250, 32, 900, 3840, 4200, 117
     n1 = L.dp_work_bytes(C.byref(b))
     assert n1 > 4 * (3840 * (20 + 9 + 9 + 1) + 4200 * 29 + 2 * 120 * 100)     # at least the big per-edge / per-node arrays
     w = engine.DpWork()
@@ -118,7 +118,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
     base = 1 << 20                                                            # a fake (aligned) device address: bind touches no memory
     assert L.dp_work_bind(C.byref(b), base, n1, C.byref(w), *[C.byref(p) for p in ptrs]) == 0
     fields = [getattr(w, n) for n, _ in engine.DpWork._fields_ if n not in ("h_l", "h_p", "prof_start", "prof_stop", "prof_layer",
-                                                                            "prof_conv", "prof_events", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "path_split", "edge_bf16x6", "ll_node_max_atoms", "aux_mode", "node_f16")]
+                                                                            "prof_conv", "prof_events", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "path_split", "edge_bf16x6", "ll_node_max_atoms", "aux_mode", "node_f16", "xn_sparse")]
     fields += list(w.h_l) + list(w.h_p) + [p.value for p in ptrs]
     assert all(f is not None and base <= f < base + n1 and f % 256 == 0 for f in fields) and len(set(fields)) == len(fields)
     assert L.dp_work_bind(C.byref(b), base, n1 - 1, C.byref(w), *[C.byref(p) for p in ptrs]) == -3
