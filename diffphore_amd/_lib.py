@@ -41,6 +41,7 @@ class DpConvArgs(C.Structure):
         ("w1n", VOIDP), ("w2n", VOIDP), ("algo", c_i32), ("path_split", c_i32),
         ("pair_a", VOIDP), ("pair_b", VOIDP), ("pair_ptr", VOIDP), ("edge_emb_bf", VOIDP), ("emb_flag_row", c_i32), ("no_tail", c_i32),
         ("s0_only", c_i32), ("feat_idx", VOIDP), ("msg_out", VOIDP), ("n_list", c_i32), ("sh0_zero", c_i32),
+        ("list_msg", VOIDP), ("list_rowptr", VOIDP), ("list_scale", VOIDP),
     ]
 
 

@@ -116,7 +116,7 @@ int dp_tp_conv(const DpConvArgs* a, void* stream) {
     if (a->n_list < 0 || (a->n_list > 0 && (!a->nbr || !a->edge_scat || !a->feat_idx || !a->msg_out)) || !a->gather_tab || !a->attr1_tab || !a->attr2_tab ||
         !a->edge_emb || !a->edge_sh || !a->w1p || !a->w2p)
       return DP_E_BADARG;
-    if (a->kind < 0 || a->kind > 3) return DP_E_UNSUPPORTED;
+    if (a->kind < 0 || a->kind > 3 || !a->sh0_zero) return DP_E_UNSUPPORTED;      // (the list kernel skips the tiles of the l = 0 paths)
     hipStream_t st_ = (hipStream_t)stream;
     switch (a->kind) {
       case 0: return dp_conv_launch_k0(*a, st_);

@@ -916,6 +916,18 @@ struct OperandPipe {
 // Stage TILE of the split-bf16 pipeline.  The packed weights stream L2 -> LDS through a RING-deep ring filled by LDS-DMA
 // RING-1 tiles ahead (an L2 round trip under load is ~2k cycles, longer than one bf16 tile), so a tile costs:
 //   issue DMA(tile+RING-1) | ds_read operands | 12 or 24 bf16 MFMAs | VALU contraction | counted vmcnt | s_barrier.
+// a tile whose 16 weight rows all belong to paths through the l = 0 harmonic (Z000 / Z101): a DP_EDGES_LIST launch reads that component as 0
+// (DpConvArgs.sh0_zero, required), so the tile's products are multiplied by zero - its MFMAs and contraction are skipped (the ring still carries it)
+template <int KIND, int TILE> constexpr bool tile_l0_only() {
+  for (int r = 0; r < 16; ++r) {
+    const Triple t = triple_at<KIND>(TILE * 16 + r);
+    if (!t.valid) continue;
+    const int z = Spec<KIND>::P[t.p].ztype;
+    if (z != Z000 && z != Z101) return false;
+  }
+  return true;
+}
+
 // EMIT (DP_EDGES_LIST): the staged messages are written to `emit` (the wave's first row of msg_out; emit_rows rows exist) instead of being summed
 template <int KIND, int NS, int TILE, bool FULL = false, bool F16 = false, bool EMIT = false>
 struct StageB {
@@ -957,6 +969,7 @@ struct StageB {
         dma_tile<KIND, NS>(src, s_w + ((TILE + R - 1) % R) * NQ, wave, lane);
       }
       const unsigned lds_w = (unsigned)(__UINTPTR_TYPE__)(lptrq)s_w + lane * 16;   // LDS byte address of this lane's quad
+      if constexpr (!(EMIT && tile_l0_only<KIND, TILE>())) {
       f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if DP_ABLATE == 2
       for (int r_ = 0; r_ < 16; ++r_) D[r_] = hb.v[0][0][0] == (__bf16)123.f ? 1.f : 0.5f;
@@ -989,6 +1002,7 @@ struct StageB {
 #else
       contract_tile<KIND, TILE>(D, xr, sh, M, acc, std::make_integer_sequence<int, 16>{});
 #endif
+      }
       if constexpr (TILE + 1 < G::NT) {
         // tile TILE+1 must have landed; tiles TILE+2 .. min(TILE+R-1, NT-1) may stay in flight across the barrier
         constexpr int last = (TILE + R - 1 < G::NT - 1) ? (TILE + R - 1) : (G::NT - 1);

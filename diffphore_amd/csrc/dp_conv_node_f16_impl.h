@@ -755,6 +755,39 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(Fus
   float w_min = w2_exponent(fa.conv[0]);
   for (int k = 1; k < n_conv; ++k) w_min = fminf(w_min, w2_exponent(fa.conv[k]));
   const float s_exp = w_min + (float)A0;
+  // what the epilogue adds to the accumulators: BatchNorm shifts, the residual / previous output, the listed pairs of an s0-only conv.  Read BEHIND
+  // the passes (in front of them, to hide the list term's dependent loads, the s0-only kernels ran 8 % longer: 163.6k vs 165.8k pose-steps/s)
+  constexpr int EP_ROUNDS = (NBH * S::D_OUT + 255) / 256;
+  float er[EP_ROUNDS], eb[EP_ROUNDS];
+  auto load_ep = [&]() {
+    const DpConvArgs& a = fa.conv[0];
+#pragma unroll
+    for (int it = 0; it < EP_ROUNDS; ++it) {
+      const int i = tid + 256 * it;
+      const bool live = i < grp.n_loc * S::D_OUT;
+      const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
+      const int node = grp.n_lo + (live ? n : 0);
+      float sh = 0.f;
+      for (int k = 0; k < (cx_only < 0 ? n_conv : 0); ++k) sh += fa.conv[k].bn_shift[live ? ch : 0];
+      if constexpr (S0K) {
+        // the conv's listed pairs (DpConvArgs.list_*: messages of a DP_EDGES_LIST launch): scatter mean over the conv's full degree, their BatchNorm scale
+        for (int k = 0; k < (cx_only < 0 ? n_conv : 0); ++k) {
+          const DpConvArgs& ck = fa.conv[k];
+          if (ck.list_msg == nullptr || !live) continue;
+          const int k0 = ck.list_rowptr[node], k1 = ck.list_rowptr[node + 1];
+          if (k0 == k1) continue;
+          float sm = 0.f;
+          for (int kk = k0; kk < k1; ++kk) sm += ck.list_msg[(size_t)kk * S::D_OUT + ch];
+          const int deg = wg_of<XMODE>(ck, grp.pose).En;
+          sh += (sm / (float)max(deg, 1)) * ck.list_scale[ch];
+        }
+      }
+      eb[it] = sh;
+      const float* src = a.accumulate ? a.out + (size_t)node * a.out_stride + (live ? ch : 0)
+                                      : (a.resid != nullptr && live && ch < a.resid_width ? a.resid + (size_t)node * a.resid_stride + ch : nullptr);
+      er[it] = (live && src != nullptr && cx_only < 0) ? *src : 0.f;
+    }
+  };
   if constexpr (HAS_LL) {
     if (cx_only <= 0) conv_f16<KIND, LL, HALFOK>(fa.conv[0], grp, tid, ldexpf(1.f, (int)(s_exp - w2_exponent(fa.conv[0]))), s_T, s_S, s_X, s_inv, acc);
   }
@@ -769,24 +802,10 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_f16_kernel(Fus
     }
   }
   // ---- sum the four k-partials and the two limb halves of the node slots, un-scale, BatchNorm shift, residual stream ----------------------
+  load_ep();
   {
     const DpConvArgs& a = fa.conv[0];
     const float oscale = ldexpf(1.f, -(int)s_exp);
-    constexpr int EP_ROUNDS = (NBH * S::D_OUT + 255) / 256;
-    float er[EP_ROUNDS], eb[EP_ROUNDS];
-#pragma unroll
-    for (int it = 0; it < EP_ROUNDS; ++it) {
-      const int i = tid + 256 * it;
-      const bool live = i < grp.n_loc * S::D_OUT;
-      const int n = i / S::D_OUT, ch = i - n * S::D_OUT;
-      const int node = grp.n_lo + (live ? n : 0);
-      float sh = 0.f;
-      for (int k = 0; k < (cx_only < 0 ? n_conv : 0); ++k) sh += fa.conv[k].bn_shift[live ? ch : 0];
-      eb[it] = sh;
-      const float* src = a.accumulate ? a.out + (size_t)node * a.out_stride + (live ? ch : 0)
-                                      : (a.resid != nullptr && live && ch < a.resid_width ? a.resid + (size_t)node * a.resid_stride + ch : nullptr);
-      er[it] = (live && src != nullptr && cx_only < 0) ? *src : 0.f;
-    }
     __syncthreads();
     AccStore<KIND, 0>::run(acc, s_T + q * (NB * S::D_OUT), lane);
     __syncthreads();

@@ -854,11 +854,11 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   const bool xs_lig = f16_lig && xs_have && xs_want, xs_ph = f16_ph && xs_have && xs_want;
   const bool xs_list = true;
 #endif
-  // the listed pairs of one normals conv: messages edge-side, then mean / BatchNorm scale / sum onto the conv's output rows (after the launch that wrote them)
-  auto xs_launch = [&](int l_, bool lig_side, const float* hl_, const float* hp_, float* out_, hipStream_t s_) -> int {
+  // the listed pairs of one normals conv: their messages through the edge-side kernel BEFORE the conv's s0-only launch, whose epilogue folds them in
+  // (scatter mean over the full degree, BatchNorm scale: DpConvArgs.list_*)
+  auto xs_launch = [&](int l_, bool lig_side, const float* hl_, const float* hp_, DpConvArgs& s0conv, hipStream_t s_) -> int {
     if (!xs_list || b->n_xs <= 0) return DP_OK;
     const DpConvW& cw = lig_side ? w->p2l_norm_conv[l_] : w->l2p_norm_conv[l_];
-    static const int DOUT[4] = {50, 80, 100, 100};
     float* msg = k->xs_msg + (lig_side ? (size_t)0 : (size_t)b->n_xs * 100);
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
@@ -871,10 +871,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.gather_stride = c.attr1_stride = c.attr2_stride = 100;
     c.edge_emb = k->x_emb; c.edge_sh = k->x_nsh; c.sh_stride = 9;
     c.w1p = cw.w1p; c.w2p = cw.w2x;
-    int r = dp_tp_conv(&c, s_);
-    if (r) return r;
-    return dp_list_reduce(msg, lig_side ? b->xs_rowptr : b->xt_rowptr, B, lig_side ? b->lig_ptr : b->ph_ptr, lig_side ? b->ph_ptr : b->lig_ptr, DOUT[l_],
-                          cw.bn_scale_x, out_, 100, s_);
+    s0conv.list_msg = msg; s0conv.list_rowptr = lig_side ? b->xs_rowptr : b->xt_rowptr; s0conv.list_scale = cw.bn_scale_x;
+    return dp_tp_conv(&c, s_);
   };
   auto node_path_split = [&](int B_, int slices_) {
     return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(B_, slices_, f16_ok)));
@@ -979,6 +977,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         if ((rc = timed_fused(ligc, 3, 0, 2, st))) return fail(rc);
       } else {
         if ((rc = timed_fused(ligc, 2, 0, 1, st))) return fail(rc);
+        if ((rc = xs_launch(l, true, hl, hp, ligc[2], st))) return fail(rc);
         if ((rc = timed(ligc[2], l, 2, st))) return fail(rc);
       }
     } else {
@@ -986,11 +985,11 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       if (node_side && fuse && !xs_lig) {
         if ((rc = timed_fused(ligc + 1, 2, 1, 2, st))) return fail(rc);
       } else {
+        if (xs_lig && (rc = xs_launch(l, true, hl, hp, ligc[2], st))) return fail(rc);
         for (int nv = 0; nv < 2; ++nv)
           if ((rc = timed(ligc[1 + nv], l, 1 + nv, st))) return fail(rc);
       }
     }
-    if (xs_lig && (rc = xs_launch(l, true, hl, hp, hl2, st))) return fail(rc);
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
       {
         DpConvArgs c = a;
@@ -1019,10 +1018,10 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       if (node_side && fuse && !xs_ph) {
         if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);
       } else {
+        if (xs_ph && (rc = xs_launch(l, false, hl, hp, phc[1], sp_))) return fail(rc);
         for (int nv = 0; nv < 2; ++nv)
           if ((rc = timed(phc[nv], l, 4 + nv, sp_))) return fail(rc);
       }
-      if (xs_ph && (rc = xs_launch(l, false, hl, hp, hp2, sp_))) return fail(rc);
     }
     if (two) join();
     cur ^= 1;

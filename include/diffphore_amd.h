@@ -166,7 +166,14 @@ typedef struct DpConvArgs {
   const int32_t* feat_idx;
   float* msg_out;
   int32_t n_list;
-  int32_t sh0_zero;          /* DP_EDGES_LIST: 1 = component 0 of every edge_sh row is read as 0 (the l = 0 part of the conv is computed elsewhere) */
+  int32_t sh0_zero;          /* DP_EDGES_LIST: must be 1 = component 0 of every edge_sh row is read as 0: the tensor-product paths through the l = 0 harmonic
+                                are NOT part of a list launch (that part of the conv is the s0_only launch) */
+  /* s0_only convs: the messages of the conv's listed pairs (a DP_EDGES_LIST launch that ran before this one), folded in by this launch's epilogue
+   * instead of a dp_list_reduce launch: out[n][c] also gets list_scale[c] * sum(list_msg[k][c], k = list_rowptr[n] .. list_rowptr[n + 1]) / degree.
+   * All three or none. */
+  const float* list_msg;
+  const int32_t* list_rowptr;
+  const float* list_scale;
 } DpConvArgs;
 
 /* Fused gather -> radial MLP (MFMA) -> Clebsch-Gordan tensor product -> per-node segmented mean -> e3nn BatchNorm(eval).

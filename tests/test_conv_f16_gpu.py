@@ -351,3 +351,109 @@ def test_edge_side_f16x3_vs_oracle(kind, mode):
     err6 = (out6.cpu().double() - want).abs().max().item() / ref.abs().max().item()
     print(f"    bf16x6 on the same inputs {err6:.2e}")
     assert err6 < TOL
+
+
+def _sparse_sh_case(kind, mode, seed, NL, NP, density):
+    """a dense cross conv whose spherical harmonics are e0 = (1, 0, ..., 0) on all but a random `density` of the pairs (the normals convs of the
+    model, score_model_phore.py:874-894), + the list of the other pairs by scatter node (what dp_pack_fill builds from the type agreement)"""
+    base, _, resid, dims, n_out, pk = _cross_case(kind, mode, seed, NL, NP)
+    g = torch.Generator().manual_seed(seed + 1)
+    sh = base["edge_sh"].cpu()
+    E = sh.shape[0]
+    keep = torch.rand(E, generator=g) < density
+    sh[~keep, 1:] = 0.0
+    sd = weights.init_state_dict(11)
+    fam = "phore_to_lig_conv_layers" if mode == "p2l" else "lig_to_phore_norm_conv_layers"
+    if kind == 3 and mode == "l2p":
+        fam = "lig_to_phore_conv_layers"
+    prefix = f"encoder.{fam}.{kind}"
+    hl, hp, emb = base["attr1_tab"].cpu(), base["attr2_tab"].cpu(), base["edge_emb"].cpu()
+    B = len(NL)
+    lig_ptr, ph_ptr, x_ptr = (base[k].cpu().numpy() for k in ("lig_ptr", "ph_ptr", "x_ptr"))
+    src = torch.cat([torch.arange(lig_ptr[b], lig_ptr[b + 1]).repeat_interleave(NP[b]) for b in range(B)])
+    dst = torch.cat([torch.arange(ph_ptr[b], ph_ptr[b + 1]).repeat(NL[b]) for b in range(B)])
+    attr = torch.cat([emb, hl[src, :20], hp[dst, :20]], 1)
+    if mode == "p2l":
+        ref = _oracle_conv(sd, prefix, kind, hp[dst], attr, sh, src, hl.shape[0])
+        scat, gath = src, dst
+    else:
+        ref = _oracle_conv(sd, prefix, kind, hl[src], attr, sh, dst, hp.shape[0])
+        scat, gath = dst, src
+    # the listed pairs, sorted by scatter node (stable: dense order inside a node), CSR over the scatter nodes
+    idx = torch.nonzero(keep).flatten()
+    order = torch.argsort(scat[idx], stable=True)
+    idx = idx[order]
+    rowptr = torch.zeros(n_out + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(scat[idx], minlength=n_out), 0)
+    x6 = packing.pack_conv(sd, prefix, kind, _lib.PREC_F32, x6=True)
+    lst = dict(edge_scat=_dev(_i32(scat[idx].numpy())), nbr=_dev(_i32(gath[idx].numpy())), feat_idx=_dev(_i32(idx.numpy())), n_list=int(idx.numel()),
+               rowptr=_dev(_i32(rowptr.numpy())), w2x=_dev(x6["w2x"]), bnx=_dev(x6["bnx"]))
+    return dict(base, edge_sh=_dev(sh)), ref, resid, dims, n_out, lst
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", ["p2l", "l2p"])
+@pytest.mark.parametrize("fold", [True, False])
+def test_s0_only_launch_plus_listed_pairs_equals_the_dense_conv(kind, mode, fold):
+    """What dp_forward does with the two normals convs of a layer (DpWork.xn_sparse): the conv's l = 0 paths on every pair (node-side kernel,
+    DpConvArgs.s0_only) + the other paths on the pairs whose harmonics are not e0 (DP_EDGES_LIST messages, folded into the s0-only launch's
+    epilogue or finished by dp_list_reduce) - against the fp64 oracle's DENSE conv, at the dense kernels' tolerance."""
+    NL, NP = [7, 30, 13, 1, 40, 17], [32, 5, 79, 33, 17, 48]
+    base, ref, resid, dims, n_out, lst = _sparse_sh_case(kind, mode, 2300 + kind, NL, NP, 0.06)
+    assert 0 < lst["n_list"] < 0.1 * base["edge_sh"].shape[0]
+    keep = []
+    st = torch.cuda.current_stream().cuda_stream
+    msg = torch.full((lst["n_list"], dims["d_out"]), float("nan")).cuda()
+    larg = dict(kind=kind, mode=_lib.EDGES_LIST, B=len(NL), slices=1, precision=_lib.PREC_F16X3, max_scatter=1, n_list=lst["n_list"], sh0_zero=1, msg_out=msg,
+                edge_scat=lst["edge_scat"], nbr=lst["nbr"], feat_idx=lst["feat_idx"], attr_swap=0 if mode == "p2l" else 1,
+                gather_tab=base["gather_tab"], gather_stride=dims["d_in"], attr1_tab=base["attr1_tab"], attr1_stride=dims["d_in"],
+                attr2_tab=base["attr2_tab"], attr2_stride=dims["d_in"], edge_emb=base["edge_emb"], edge_sh=base["edge_sh"], sh_stride=9,
+                w1p=base["w1p"], w2p=lst["w2x"])
+    _run(larg, keep)
+    assert torch.isfinite(msg).all()
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    s0 = dict(base, out=out, s0_only=1)
+    if fold:
+        s0.update(list_msg=msg, list_rowptr=lst["rowptr"], list_scale=lst["bnx"])
+    _run(s0, keep)
+    if not fold:
+        deg_ptr = base["ph_ptr"] if mode == "p2l" else base["lig_ptr"]
+        _lib.check(_lib.lib().dp_list_reduce(msg.data_ptr(), lst["rowptr"].data_ptr(), len(NL), base["scat_ptr"].data_ptr(), deg_ptr.data_ptr(), dims["d_out"],
+                                             lst["bnx"].data_ptr(), out.data_ptr(), dims["d_out"], st), "dp_list_reduce")
+        torch.cuda.synchronize()
+    got = out.cpu().double()
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    scale = ref.abs().max().item()
+    err = (got - want).abs().max().item() / scale
+    # the same inputs through the dense kernel
+    dense = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    _run(dict(base, out=dense), keep)
+    err_dense = (dense.cpu().double() - want).abs().max().item() / scale
+    print(f"kind {kind} {mode} fold={fold}: s0-only + {lst['n_list']} listed pairs vs fp64 oracle {err:.2e} (dense kernel {err_dense:.2e})")
+    assert err < TOL and err_dense < TOL, (err, err_dense)
+    # without the listed pairs the result is NOT the conv (the list carries real terms)
+    out0 = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    _run(dict(base, out=out0, s0_only=1), keep)
+    assert (out0.cpu().double() - want).abs().max().item() / scale > 100 * TOL
+    # bit-identical reruns
+    out2 = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    if fold:
+        _run(dict(s0, out=out2), keep)
+        assert torch.equal(out2.cpu().double(), got)
+
+
+def test_list_launch_rejects_what_it_does_not_cover():
+    base, ref, resid, dims, n_out, lst = _sparse_sh_case(1, "p2l", 5, [9], [12], 0.2)
+    a = _lib.DpConvArgs()
+    for k_, v in dict(kind=1, mode=_lib.EDGES_LIST, B=1, slices=1, precision=_lib.PREC_F16X3, n_list=lst["n_list"], sh0_zero=0).items():
+        setattr(a, k_, v)
+    import ctypes as C
+    assert _lib.lib().dp_tp_conv(C.byref(a), None) == -1          # missing pointers
+    msg = torch.zeros(lst["n_list"], dims["d_out"]).cuda()
+    for k_, v in dict(msg_out=msg, edge_scat=lst["edge_scat"], nbr=lst["nbr"], feat_idx=lst["feat_idx"], gather_tab=base["gather_tab"], attr1_tab=base["attr1_tab"],
+                      attr2_tab=base["attr2_tab"], edge_emb=base["edge_emb"], edge_sh=base["edge_sh"], w1p=base["w1p"], w2p=lst["w2x"]).items():
+        setattr(a, k_, v.data_ptr())
+    assert _lib.lib().dp_tp_conv(C.byref(a), None) == -2          # sh0_zero = 0: the list kernel does not evaluate the l = 0 paths
+    a.sh0_zero, a.kind = 1, 5
+    assert _lib.lib().dp_tp_conv(C.byref(a), None) == -2          # layer convs only

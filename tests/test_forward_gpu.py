@@ -117,6 +117,45 @@ def test_edge_side_convs_on_the_bf16_pipe_vs_exact_fp32(algo, monkeypatch):
     assert not all(torch.equal(a, b) for a, b in zip(res["1"], res["0"]))        # the switch really selects another kernel
 
 
+@pytest.mark.parametrize("dense_fp", [False, True])
+def test_normals_convs_as_l0_part_plus_listed_pairs(dense_fp, monkeypatch):
+    """The two normals convs of a layer (phore_to_lig_norm / lig_to_phore_norm) as their l = 0 part on every pair + the other paths on the listed
+    pairs with type agreement (DpWork.xn_sparse; the harmonics of every other pair are exactly e0, score_model_phore.py:874-894): on, off and the
+    library's choice are held to the fp64 oracle at the same tolerance, and to each other.  `dense_fp`: every atom carries every fingerprint bit and
+    a normal for it - the list then holds every pair with a feature node (18 % of this batch's pairs instead of 3 %)."""
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import sampler as osampler
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", "node")
+    gs = _mixed_graphs() + synthetic.synthetic_pairs(98, 10, 30, 8, 32)
+    if dense_fp:
+        for g in gs:
+            g["ligand"].phorefp = torch.ones_like(g["ligand"].phorefp)
+            g["ligand"].norm = torch.nn.functional.normalize(torch.randn(g["ligand"].pos.shape[0], 11, 3, generator=torch.Generator().manual_seed(5)), dim=-1).reshape(-1, 33)
+    sd, om = _model()
+    batch = Batch.from_data_list(gs)
+    osampler.set_time_phore(batch, 0.4, 0.4, 0.4, batch.num_graphs)
+    tr_o, rot_o, tor_o = om(batch)
+    res, n_xs, n_x = {}, None, None
+    for xn in ("1", "0", "auto"):
+        monkeypatch.setenv("DIFFPHORE_XN_SPARSE", xn)
+        m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+        tr, rot, tor = m(batch)
+        torch.cuda.synchronize()
+        eng = m._engine
+        n_xs, n_x = int(eng.pb.struct.n_xs), int(eng.pb.struct.n_x)
+        errs = dict(h_l4=_rel(eng.ws.t["h_l0"][:, :100], om.debug["h_l4"]), h_p3=_rel(eng.ws.t["h_p1"][:, :100], om.debug["h_p3"]), tr=_rel(tr, tr_o),
+                    rot=_rel(rot, rot_o), tor=_rel(tor, tor_o))
+        print("xn_sparse =", xn, f"listed {n_xs} of {n_x} pairs", {k: f"{v:.1e}" for k, v in errs.items()})
+        assert all(v < 1e-5 for v in errs.values()), errs
+        res[xn] = (tr.cpu(), rot.cpu(), tor.cpu())
+    assert all(_rel(a, b) < 1e-5 for a, b in zip(res["1"], res["0"]))
+    assert not all(torch.equal(a, b) for a, b in zip(res["1"], res["0"]))        # the switch really selects other kernels
+    # the library's choice: the split while at most a quarter of the pairs is listed
+    same_as = "1" if 4 * n_xs <= n_x else "0"
+    assert (n_xs > 0.1 * n_x) == dense_fp
+    assert all(torch.equal(a, b) for a, b in zip(res["auto"], res[same_as]))
+
+
 def test_lig_graph_matches_oracle_edges():
     """radius graph (cap 32, index order, strict <) + bond edges: same multiset of (src,dst) as the oracle."""
     from diffphore_amd.score_model import TensorProductScoreModel
