@@ -50,11 +50,19 @@ NODE_MFMA_PER_WAVE_BF16 = {0: 35 + 16 * 6 + 50, 1: 35 + 16 * 13 + 105, 2: 35 + 1
 # 3 node tiles) x 3 cross products, GEMM-A 3 MFMAs per (node, column tile), GEMM-B 2 W2 limbs x (5 K chunks x M tiles x m components) per supertile
 # (the two T limbs ride in the N dimension).  Kind 3: 1 101 = SQ_INSTS_MFMA / waves of profiles/r5_f16_node_pmc.csv
 NODE_MFMA_PER_WAVE_F16 = {0: 57 + 24 * 6 + 100, 1: 57 + 24 * 13 + 210, 2: 57 + 24 * 20 + 320, 3: 57 + 24 * 26 + 420}
+# A normals conv as its s0-only node-side launch + its listed pairs (DpWork.xn_sparse, round 6): the launch evaluates the paths through the l = 0
+# harmonic only (Z000 / Z101: columns, second-layer rows and MFMAs below) on every pair, the other paths on the listed pairs edge-side
+NODE_COLS_S0 = {0: 20, 1: 50, 2: 80, 3: 100}
+NODE_W_S0 = {0: 400, 1: 700, 2: 1000, 3: 1400}
+NODE_MFMA_PER_WAVE_F16_S0 = {0: 57 + 24 * 2 + 40, 1: 57 + 24 * 4 + 70, 2: 57 + 24 * 6 + 100, 3: 57 + 24 * 8 + 140}
+NUMEL_NOT_L0 = {0: 200, 1: 600, 2: 1000, 3: 1200}              # radial-MLP outputs of the paths a DP_EDGES_LIST launch evaluates
+LIST_TP_FLOPS = {0: 1200, 1: 2800, 2: 4400, 3: 5600}           # 2 * sum over those paths of mul_in * mul_out * (2 l_out + 1)
 MFMA_F32_PEAK_TFLOPS = 157.3                                      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0                                    # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 PREC_OF_CONFIG = {5: "bf16"}                                      # configs[4] is "bf16 mixed precision"; every other config fp32
-PROF_LAYER, PROF_CONV = 3, 1                                     # layer-3 phore->ligand conv: the launch that carries it is the step's longest
+PROF_LAYER, PROF_CONV = 3, 1                                     # layer-3 phore->ligand conv: layer 3 has no pharmacophore side, its ligand-side launch runs ALONE
+                                                                 # (the step's longest launch by wall is layer 2's, beside the layer's other side)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")
 
 
@@ -274,12 +282,13 @@ def main():
             self.sps = [_step_params(t, S, self.sched, self.sched, self.sched, t2s, margs, False, False) for t in range(S)]
             self.T_dev = torch.tensor([[float(self.sched[t])] * 3 for t in range(S)], dtype=torch.float32, device=dev)   # diffusion times, resident
 
-        def timed_run(self, mdl, conv_algo, steps, warmup, prof=True, edge_x6=None, table_steps=0, node_f16=None):
+        def timed_run(self, mdl, conv_algo, steps, warmup, prof=True, edge_x6=None, table_steps=0, node_f16=None, env=None):
             """-> dict.  `edge_x6`: "0" forces exact fp32 on the edge-side convs of an fp32 model (DIFFPHORE_EDGE_X6), `node_f16`: "0" forces the
             exact-fp32 MFMA kernel on its node-side convs (DIFFPHORE_NODE_F16); `table_steps` > 0 adds an untimed pass that brackets EVERY
             tensor-product launch of the interaction layers (DpWork.prof_events) for the per-launch table."""
             pb, B, S_total, zs, sps, nT = self.pb, self.B, self.S_total, self.zs, self.sps, self.nT
             envs = {"DIFFPHORE_EDGE_X6": edge_x6, "DIFFPHORE_NODE_F16": node_f16}
+            envs.update(env or {})
             keep = {k_: os.environ.get(k_) for k_ in envs}
             for k_, v_ in envs.items():
                 if v_ is not None:
@@ -373,7 +382,7 @@ def main():
                         acc[(layer, f)].append(te_.ms(layer * 6 + f))
                 w.prof_events = None
                 te_.destroy()
-                table = [{"layer": layer, "first_conv": f, "convs": n, "node_side": bool(ns), "ms": float(np.nanmean(acc[(layer, f)]))}
+                table = [{"layer": layer, "first_conv": f, "convs": n, "node_side": bool(ns), "kind": int(ns), "ms": float(np.nanmean(acc[(layer, f)]))}
                          for (layer, f), (n, ns) in sorted(launches.items())]
             # what the node-side launches of THIS batch run: the two-limb fp16 kernel has no path-split form (small batches stay on the fp32 kernel)
             nsc = eng.node_side_convs if (eng.conv_algo == "node" and not (eng.node_side_convs == "f16x3" and eng.path_split_on())) else \
@@ -391,6 +400,14 @@ def main():
     elapsed, kern_ms, bad, finite, algo_used = main["elapsed"], main["kernel_ms"], main["bad"], main["finite"], main["algo"]
     prof_launch, edge_counts = wl.prof_launch, dict(wl.edge_counts)
     rank_poses = list(wl.rank_poses)
+    # the same step with everything on ONE stream (DIFFPHORE_TWO_STREAMS=0): a per-launch table whose launches do not overlap - clean per-launch
+    # fractions for layers 0-2, whose two sides share the chip in the default run (never `value`)
+    single = None
+    if a.config == 2 and a.conv_algo is None:
+        try:
+            single = wl.timed_run(model, a.conv_algo, min(a.steps, 20), 3, prof=False, table_steps=min(a.steps, 10), env={"DIFFPHORE_TWO_STREAMS": "0"})
+        except Exception as e:      # noqa: BLE001 - informational
+            single = {"error": str(e)[:200]}
     pb = pb0
     totals = torch.tensor([B, int(pb.x_ptr[-1])], device=dev, dtype=torch.float64)
     if dist is not None:
@@ -456,6 +473,42 @@ def main():
                          "breakdown_s": {k: round(v, 4) for k, v in tm2.items()}}
         del copy
 
+    e2e_one = None
+    if not a.no_e2e and world == 1 and a.config == 2 and a.precision is None and a.conv_algo is None:
+        # the reference's OWN call pattern (src/inference.py:184-209): ONE complex, 40 samples, 20 steps - randomize_position + sampling_phore on the
+        # 40 copies, wall clock of the two calls (host packing, noise, device loop, write-back), median of 5 after a warm-up; latency-bound
+        from diffphore_amd import synthetic
+        from diffphore_amd.sampling import sampling_phore
+        from diffphore_amd.score_model import TensorProductScoreModel
+        m1 = TensorProductScoreModel(device=dev, precision=precision)
+        m1.load_state_dict(sd)
+        sched20 = get_t_schedule(20)
+        e2e_one = []
+        for what, (na, nt_, npn) in (("configs[0] shape (20 atoms, 5 torsions, 79 pharmacophore nodes)", (20, 5, 79)),
+                                     ("configs[1] shape (30 atoms, 8 torsions, 32 pharmacophore nodes)", (30, 8, 32))):
+            try:
+                g0 = synthetic.synthetic_pairs(71, 1, na, nt_, npn)[0]
+                runs = []
+                for rep in range(6):
+                    gl = [g0.sample_copy() for _ in range(40)]
+                    np.random.seed(11 + rep); torch.manual_seed(11 + rep)
+                    tm1 = {}
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    randomize_position(gl, False, False, cfg.tr_sigma_max, device=dev)
+                    t1 = time.perf_counter()
+                    sampling_phore(gl, m1, 20, sched20, sched20, sched20, dev, t2s, margs, batch_size=40, timing=tm1)
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    runs.append((t2 - t0, t1 - t0, tm1.get("loop_s", float("nan")), tm1.get("pack_and_noise_s", float("nan")), tm1.get("write_back_s", float("nan"))))
+                runs = sorted(runs[1:])                      # first = warm-up (kernel load, engine caches)
+                med = runs[len(runs) // 2]
+                e2e_one.append({"shape": what, "samples": 40, "steps": 20, "wall_ms": med[0] * 1e3, "randomize_position_ms": med[1] * 1e3,
+                                "device_loop_ms": med[2] * 1e3, "ms_per_step_device": med[2] * 1e3 / 20, "pack_and_noise_ms": med[3] * 1e3,
+                                "write_back_ms": med[4] * 1e3, "pose_steps_per_s": 40 * 20 / med[0]})
+            except Exception as e:      # noqa: BLE001 - informational
+                e2e_one.append({"shape": what, "error": str(e)[:200]})
+
     e2e_screen = None
     if not a.no_e2e and world == 1 and (a.config in (4, 5) or (a.config == 2 and not a.no_other and a.precision is None and a.conv_algo is None and a.poses is None)):
         # secondary figure for the library workloads (configs[3] virtual screen / configs[4] target fishing): the streaming driver
@@ -516,8 +569,9 @@ def main():
 
     n_x = int(pb.x_ptr[-1])
 
-    def launch_work(pbx, ecounts, layer, convs, prec):
-        """Work of ONE launch of interaction layer `layer` that carries `convs` (numbering of DpWork.prof_conv): node-form algorithmic flops
+    def launch_work(pbx, ecounts, layer, convs, prec, s0=False):
+        """`s0`: the launch is a normals conv as s0-only node-side launch + DP_EDGES_LIST launch over its listed pairs (both inside the bracket).
+        Work of ONE launch of interaction layer `layer` that carries `convs` (numbering of DpWork.prof_conv): node-form algorithmic flops
         (DESIGN.md 5.1), SURVEY.md 8d's edge-side flops and operator-boundary bytes, and the MFMA flops the node-side kernel issues.
         `prec`: which node-side kernel - "f32" (fp32 MFMA, 16-node groups), "bf16" (bf16 operands, 16-node groups) or "f16x3" (two fp16 limbs
         per operand, 8-node groups)."""
@@ -529,7 +583,11 @@ def main():
         edges = {c: (n_ll_ if c == 0 else n_x_) for c in convs}
         gather = {c: (sum(nl_) if c in (0, 4, 5) else sum(np__)) for c in convs}
         n_edges = sum(edges.values())
-        node_flops = sum(edges[c] * 2 * 61 * (20 + NODE_COLS[layer]) + n_scat * 2 * 61 * (21 + NODE_W[layer]) + gather[c] * 2 * 61 * 20 for c in convs)
+        cols, wrows = (NODE_COLS_S0, NODE_W_S0) if s0 else (NODE_COLS, NODE_W)
+        node_flops = sum(edges[c] * 2 * 61 * (20 + cols[layer]) + n_scat * 2 * 61 * (21 + wrows[layer]) + gather[c] * 2 * 61 * 20 for c in convs)
+        n_listed = int(pbx.struct.n_xs) if s0 else 0
+        list_flops = n_listed * (2 * (60 * 60 + 60 * NUMEL_NOT_L0[layer]) + LIST_TP_FLOPS[layer])        # edge-side count of the listed pairs' paths
+        node_flops += list_flops
         bf = prec in ("bf16", "f16x3")            # 16x16x32 MFMAs on the 16-bit pipe
         grp = 8 if prec == "f16x3" else 16        # scatter nodes per workgroup
 
@@ -539,9 +597,9 @@ def main():
         scat_i = nl_ if lig_side else np__
         slots = {c: (nl_ if (c == 0 or not lig_side) else np__) for c in convs}
         passes = sum(((scat_i[i] + grp - 1) // grp) * pass_units(slots[c][i]) for c in convs for i in range(nB))
-        per_wave = {"bf16": NODE_MFMA_PER_WAVE_BF16, "f16x3": NODE_MFMA_PER_WAVE_F16}.get(prec, NODE_MFMA_PER_WAVE)[layer]
-        issued = passes * 4 * per_wave * (16384.0 if bf else 2048.0)
-        return dict(edges=n_edges, node_flops=node_flops, edge_flops=ALG_FLOPS_PER_EDGE[layer] * n_edges, alg_bytes=ALG_BYTES_PER_EDGE[layer] * n_edges,
+        per_wave = (NODE_MFMA_PER_WAVE_F16_S0 if s0 else {"bf16": NODE_MFMA_PER_WAVE_BF16, "f16x3": NODE_MFMA_PER_WAVE_F16}.get(prec, NODE_MFMA_PER_WAVE))[layer]
+        issued = passes * 4 * per_wave * (16384.0 if bf else 2048.0) + 3 * list_flops      # (+ the list launch's three limb products)
+        return dict(edges=n_edges, node_flops=node_flops, listed_pairs=n_listed, edge_flops=ALG_FLOPS_PER_EDGE[layer] * n_edges, alg_bytes=ALG_BYTES_PER_EDGE[layer] * n_edges,
                     issued_flops=issued, workgroups=int(sum((n + grp - 1) // grp for n in scat_i)))
 
     def step_weighted(pbx, ecounts, table, prec, peak):
@@ -554,9 +612,11 @@ def main():
             if not r_["node_side"] or not (r_["ms"] > 0):
                 continue
             cv = list(range(r_["first_conv"], r_["first_conv"] + r_["convs"]))
-            wk = launch_work(pbx, ecounts, r_["layer"], cv, prec)
+            wk = launch_work(pbx, ecounts, r_["layer"], cv, prec, s0=(r_.get("kind") == 2))
             fl += wk["node_flops"]; tm += r_["ms"]; iss += wk["issued_flops"]
             rows.append({"layer": r_["layer"], "convs": cv, "ms": round(r_["ms"], 4), "TFLOPs": wk["node_flops"] / (r_["ms"] * 1e-3) / 1e12})
+            if r_.get("kind") == 2:
+                rows[-1]["s0_only_plus_listed_pairs"] = wk["listed_pairs"]
         if tm <= 0:
             return None
         return {"achieved": fl / (tm * 1e-3) / 1e12, "frac": fl / (tm * 1e-3) / 1e12 / peak, "issued_frac": iss / (tm * 1e-3) / 1e12 / peak,
@@ -633,6 +693,22 @@ def main():
                             "x (T_hi | T_lo in N) per GEMM-B MFMA) / launch time = matrix-pipe occupancy"}
     else:
         rf_flops, rf_note, rf_issue = flops, "SURVEY.md 8d: 2*(60*60+60*numel)+TP flop per edge-conv (edge-side formulation)", None
+    sw_main = step_weighted(pb, edge_counts, main["launch_table"], node_kern, peak)
+    sw_single = None
+    if single is not None and "error" not in single:
+        sw_single = step_weighted(pb, edge_counts, single["launch_table"], node_kern, peak)
+        if sw_single is not None:
+            sw_single["ms_per_step_single_stream"] = single["elapsed"] / min(a.steps, 20) * 1e3
+            sw_single["note"] = ("the same step with DIFFPHORE_TWO_STREAMS=0: nothing overlaps, every launch's time is its own (this arm is slower as a whole: "
+                                 "ms_per_step_single_stream)")
+    whole_step = None
+    if sw_main is not None:
+        fl_step = sw_main["achieved"] * 1e12 * sw_main["node_launch_ms_per_step"] * 1e-3          # sum of node-form flops over the node-side launches
+        ms_step = elapsed / a.steps * 1e3
+        whole_step = {"node_form_flops_per_step": fl_step, "achieved": fl_step / (ms_step * 1e-3) / 1e12, "frac": fl_step / (ms_step * 1e-3) / 1e12 / peak,
+                      "unit": "TFLOP/s", "note": "node-form algorithmic flops of every node-side launch of a step (the normals convs counted as what they "
+                                                 "evaluate: l = 0 paths on every pair + the other paths on the listed pairs) / ms_per_step / the 16-bit MFMA peak: the "
+                                                 "fraction of the pipe the WHOLE step sustains, serial head and tail of the step included"}
     traffic, traffic_src = measured_traffic(a.config, B, precision, algo_used) if world == 1 else (None, None)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else float("nan")
 
@@ -672,7 +748,7 @@ def main():
                        "ranks": {"pose_steps_per_s": rank_rate, "seconds": main["rank_seconds"], "poses": rank_poses,
                                  "imbalance_max_over_mean": (max(main["rank_seconds"]) / (sum(main["rank_seconds"]) / len(main["rank_seconds"]))),
                                  "weight_broadcast_ms": bcast_ms.get(precision)},
-                       "edge_counts": edge_counts, "alt_runs": alt, "e2e": e2e, "e2e_screen": e2e_screen, "other_configs": other},
+                       "edge_counts": edge_counts, "alt_runs": alt, "e2e": e2e, "e2e_one_complex": e2e_one, "e2e_screen": e2e_screen, "other_configs": other},
             # The dominant kernel generates the per-edge TP weights on the matrix pipe in registers (they never reach HBM), so it is
             # bound by the matrix pipe (fp32 model) or by VALU issue (bf16 model); SURVEY.md 8d asks for both views when the radial MLP is fused into
             # the TP kernel.  alg_flops_per_edge is the EDGE-SIDE count of SURVEY.md 8d (radial GEMM per edge); the node-side formulation computes
@@ -683,6 +759,12 @@ def main():
                          "frac": rf_flops / (kern_ms * 1e-3) / 1e12 / peak if kern_ms > 0 else None,
                          "alg_flops_per_launch": rf_flops, "flop_count": rf_note,
                          "step_weighted": step_weighted(pb, edge_counts, main["launch_table"], node_kern, peak),
+                         "step_weighted_single_stream": sw_single,
+                         "whole_step": whole_step,
+                         "launch_note": ("the bracketed launch is the layer-3 ligand-side launch: layer 3 has no pharmacophore side, so it is the one conv launch "
+                                         "of a step that runs ALONE on the chip (its events measure the kernel, not an overlap) - not the longest by wall: "
+                                         "the layer-2 ligand-side launch is, sharing the chip with the layer's pharmacophore side (step_weighted.launches; "
+                                         "step_weighted_single_stream has every launch on its own)"),
                          "edge_side_count": {"achieved": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None,
                                              "frac": flops / (kern_ms * 1e-3) / 1e12 / peak if kern_ms > 0 else None,
                                              "note": "SURVEY.md 8d's per-edge count (radial GEMM per edge) x edges / launch time: what an edge-side "

@@ -73,7 +73,11 @@ class ModelConfig:
                            "batch_norm", "use_second_order_repr", "consider_norm", "auto_phorefp", "angle_match",
                            "new", "phoretype_match", "boarder", "by_radius", "use_att", "use_phore_match_feat",
                            "atom_weight", "cross_distance_transition", "phore_direction_transition",
-                           "phoretype_match_transition", "multiple", "scale_by_sigma")
+                           "phoretype_match_transition", "multiple", "scale_by_sigma",
+                           # cut-offs: the ligand radius graph and the torsion-bond graph are built with 5 A inside the kernels (dp_graph.hip:
+                           # lig_graph_kernel, tor_graph_kernel); the other three only set the range of a Gaussian basis, which the kernels read
+                           # from the state_dict's offsets - held to the released values all the same: nothing else has been checked
+                           "lig_max_radius", "phore_max_radius", "cross_max_distance", "center_max_distance")
                if getattr(self, k) != getattr(want, k)]
         if tuple(self.clash_cutoff) != want.clash_cutoff:
             bad.append("clash_cutoff")

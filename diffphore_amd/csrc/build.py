@@ -83,7 +83,8 @@ def build(force=False, verbose=True):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+    # exports: the dp_* entry points only (exports.map) - the C++ launchers that connect the translation units are not part of the ABI
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(HERE, "exports.map")] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -745,22 +745,59 @@ static bool plan_node_ll(const DpBatch* b, const DpWeights* w, const DpWork* k) 
          k->ll_pair_bond != nullptr && b->max_nl <= (k->ll_node_max_atoms > 0 ? k->ll_node_max_atoms : DP_NODE_LL_MAX_ATOMS);
 }
 
+// which node-side launches run the two-limb fp16 kernel, and whether the normals convs split into an s0-only launch + their listed pairs
+struct F16Plan { bool f16_ok, f16_lig, f16_ph, xs_lig, xs_ph; };
+static F16Plan plan_f16(const DpBatch* b, const DpWeights* w, const DpWork* k) {
+  F16Plan p;
+  const bool node_side = plan_node_side(b, w, k), node_ll = plan_node_ll(b, w, k);
+  const int nb_ = dp_conv_node_max_nodes();
+  // node-side convs of an fp32 model at fp32 grade on the 16-bit matrix pipe (DP_PREC_F16X3, two fp16 limbs per operand) when the blob carries
+  // those images; DpWork.path_split = 1 (A/B runs) keeps the fp32 path-split kernels
+  p.f16_ok = node_side && w->precision == DP_PREC_F32 && k->node_f16 != 0 && w->p2l_conv[0].w2h != nullptr && k->x_emb_bf != nullptr;
+  auto split_of = [&](int slices_) {
+    return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((p.f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(b->B, slices_, p.f16_ok)));
+  };
+  p.f16_lig = p.f16_ok && !split_of((b->max_nl + nb_ - 1) / nb_) && (!node_ll || (w->lig_conv[0].w2h != nullptr && k->ll_emb_bf != nullptr));
+  p.f16_ph = p.f16_ok && !split_of((b->max_np + nb_ - 1) / nb_);
+  // The two "normals" convs of a layer (phore_to_lig_norm / lig_to_phore_norm, :686-689,698-700).  Their spherical harmonics are e0 = (1, 0, ..., 0) on
+  // every cross pair without type agreement (:874-894: the vector they are taken of is cross(...) * sum(agreement)), and the pairs WITH agreement are a
+  // static, short list (DpBatch.xs_* / xt_*: 3 % of the pairs of the synthetic workloads, 5 feature nodes of 79 in the shipped example).  The conv is
+  // bilinear in (features, harmonics), so it is evaluated as
+  //     [paths through the l = 0 component, on every pair]   node-side kernel, s0-only instantiation: no per-node operand build, a third of the columns
+  //   + [the other paths, on the listed pairs only]          edge-side kernel over the list (DP_EDGES_LIST, component 0 read as 0), folded into the
+  //                                                          s0-only launch's epilogue
+  // - the same sum term by term, minus the terms that multiply by an exact zero.  Taken when the f16x3 node-side kernels run, the batch carries the
+  // lists and they are short (a long list costs more edge-side than the node-side conv it replaces); DpWork.xn_sparse = 2 keeps the dense convs.
+#ifdef DP_S0_TIMING      // timing build (wrong results): the l = 0 part only
+  p.xs_lig = p.f16_lig; p.xs_ph = p.f16_ph;
+#else
+  const bool xs_have = b->xs_src && b->xs_nbr && b->xs_feat && b->xs_rowptr && b->xt_src && b->xt_nbr && b->xt_feat && b->xt_rowptr && b->n_xs >= 0 &&
+                       k->xs_msg != nullptr && w->p2l_norm_conv[0].w2x && w->p2l_norm_conv[0].bn_scale_x && w->l2p_norm_conv[0].w2x && w->l2p_norm_conv[0].bn_scale_x;
+  const bool xs_want = k->xn_sparse == 1 || (k->xn_sparse == 0 && (long long)b->n_xs * 4 <= (long long)b->n_x);
+  p.xs_lig = p.f16_lig && xs_have && xs_want; p.xs_ph = p.f16_ph && xs_have && xs_want;
+#endif
+  return p;
+}
+
 int dp_forward_launch_of(const DpBatch* b, const DpWeights* w, const DpWork* k, int32_t layer, int32_t conv, int32_t* first, int32_t* count,
                          int32_t* node_side_out) {
   if (!b || !w || !k || !first || !count || layer < 0 || layer > 3 || conv < 0 || conv > 5 || (layer == 3 && conv > 2)) return DP_E_BADARG;
   const bool node_side = plan_node_side(b, w, k), node_ll = plan_node_ll(b, w, k), fuse = k->conv_fuse != 1;
+  const F16Plan pl = plan_f16(b, w, k);
   int f = conv, n = 1;
-  bool ns = false;
+  bool ns = false, s0 = false;
   if (conv <= 2) {                                  // ligand side: lig_conv, phore_to_lig, phore_to_lig_norm
-    if (node_side && fuse && node_ll && k->conv_fuse != 2) { f = 0; n = 3; }
-    else if (node_side && fuse && conv >= 1) { f = 1; n = 2; }
+    if (pl.xs_lig && conv == 2) { s0 = true; }      // the normals conv: its own s0-only launch (+ the listed pairs)
+    else if (node_side && fuse && node_ll && k->conv_fuse != 2) { f = 0; n = pl.xs_lig ? 2 : 3; }
+    else if (node_side && fuse && conv >= 1 && !pl.xs_lig) { f = 1; n = 2; }
     ns = conv == 0 ? node_ll : node_side;
   } else if (conv >= 4) {                           // pharmacophore side: lig_to_phore, lig_to_phore_norm (conv 3 = phore_conv, edge-side)
-    if (node_side && fuse) { f = 4; n = 2; }
+    if (pl.xs_ph) s0 = conv == 5;
+    else if (node_side && fuse) { f = 4; n = 2; }
     ns = node_side;
   }
   *first = f; *count = n;
-  if (node_side_out) *node_side_out = ns ? 1 : 0;
+  if (node_side_out) *node_side_out = ns ? (s0 ? 2 : 1) : 0;
   return DP_OK;
 }
 
@@ -793,15 +830,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   // the three graph / embedding kernels only share their inputs (positions, time parameters): the ligand radius graph runs on the second
   // stream beside the node embeddings and the cross edges (each is one workgroup per pose and latency-bound on its own)
   if (aux) fork();
-  // node-side convs of an fp32 model at fp32 grade on the 16-bit matrix pipe (DP_PREC_F16X3, two fp16 limbs per operand) when the blob carries
-  // those images; the kernel has no path-split / conv-split form, so launches that take the path split (small batches) stay on the fp32 kernel
-  const int nb_ = dp_conv_node_max_nodes();
-  const bool f16_ok = node_side && w->precision == DP_PREC_F32 && k->node_f16 != 0 && w->p2l_conv[0].w2h != nullptr && k->x_emb_bf != nullptr;
-  auto split_of = [&](int slices_) {
-    return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(B, slices_, f16_ok)));
-  };
-  const bool f16_lig = f16_ok && !split_of((b->max_nl + nb_ - 1) / nb_) && (!node_ll || (w->lig_conv[0].w2h != nullptr && k->ll_emb_bf != nullptr));
-  const bool f16_ph = f16_ok && !split_of((b->max_np + nb_ - 1) / nb_);
+  const F16Plan pl = plan_f16(b, w, k);
+  const bool f16_ok = pl.f16_ok, f16_lig = pl.f16_lig, f16_ph = pl.f16_ph;
   // the 16-bit images of the edge embeddings are written only for the convs that read them (DP_PREC_BF16 or DP_PREC_F16X3, node-side)
   const bool bf_node = node_side && w->precision == DP_PREC_BF16;
   if (bf_node && (!k->x_emb_bf || (node_ll && !k->ll_emb_bf))) return DP_E_BADARG;
@@ -836,22 +866,11 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     while (B * slices < 512 && slices < 8) ++slices;
   }
   const bool fuse = k->conv_fuse != 1;        // node-side convs that scatter onto the same nodes share one launch
-  // The two "normals" convs of a layer (phore_to_lig_norm / lig_to_phore_norm, :686-689,698-700).  Their spherical harmonics are e0 = (1, 0, ..., 0) on
-  // every cross pair without type agreement (:874-894: the vector they are taken of is cross(...) * sum(agreement)), and the pairs WITH agreement are a
-  // static, short list (DpBatch.xs_* / xt_*: 3 % of the pairs of the synthetic workloads, 5 feature nodes of 79 in the shipped example).  The conv is
-  // bilinear in (features, harmonics), so it is evaluated as
-  //     [paths through the l = 0 component, on every pair]   node-side kernel, s0-only instantiation: no per-node operand build, a third of the columns
-  //   + [the other paths, on the listed pairs only]          edge-side kernel over the list (DP_EDGES_LIST, harmonics read with component 0 = 0) + dp_list_reduce
-  // - the same sum term by term, minus the terms that multiply by an exact zero.  Taken when the f16x3 node-side kernels run, the batch carries the
-  // lists and they are short (a dense list costs more edge-side than the node-side conv it replaces); DpWork.xn_sparse = 2 keeps the dense convs.
-#ifdef DP_S0_TIMING      // timing build (wrong results): the l = 0 part only
-  const bool xs_lig = f16_lig, xs_ph = f16_ph;
+  // the normals convs as s0-only launch + listed pairs (plan_f16)
+  const bool xs_lig = pl.xs_lig, xs_ph = pl.xs_ph;
+#ifdef DP_S0_TIMING
   const bool xs_list = false;
 #else
-  const bool xs_have = b->xs_src && b->xs_nbr && b->xs_feat && b->xs_rowptr && b->xt_src && b->xt_nbr && b->xt_feat && b->xt_rowptr && b->n_xs >= 0 &&
-                       k->xs_msg != nullptr && w->p2l_norm_conv[0].w2x && w->p2l_norm_conv[0].bn_scale_x && w->l2p_norm_conv[0].w2x && w->l2p_norm_conv[0].bn_scale_x;
-  const bool xs_want = k->xn_sparse == 1 || (k->xn_sparse == 0 && (long long)b->n_xs * 4 <= (long long)b->n_x);
-  const bool xs_lig = f16_lig && xs_have && xs_want, xs_ph = f16_ph && xs_have && xs_want;
   const bool xs_list = true;
 #endif
   // the listed pairs of one normals conv: their messages through the edge-side kernel BEFORE the conv's s0-only launch, whose epilogue folds them in
@@ -900,6 +919,17 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
     if (ev_all(layer, which, 0)) note(hipEventRecord(ev_all(layer, which, 0), s_));
     const int r = dp_tp_conv(&c, s_);
+    if (ev_all(layer, which, 1)) note(hipEventRecord(ev_all(layer, which, 1), s_));
+    if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
+    return r;
+  };
+  // a normals conv as two launches - its listed pairs (messages), then its s0-only launch, which folds them in - inside ONE pair of timing events
+  auto timed_xs = [&](DpConvArgs& c, int layer, int which, bool lig_side, const float* hl_, const float* hp_, hipStream_t s_) -> int {
+    const bool prof = k->prof_start && k->prof_stop && k->prof_layer == layer && k->prof_conv == which;
+    if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
+    if (ev_all(layer, which, 0)) note(hipEventRecord(ev_all(layer, which, 0), s_));
+    int r = xs_launch(layer, lig_side, hl_, hp_, c, s_);
+    if (!r) r = dp_tp_conv(&c, s_);
     if (ev_all(layer, which, 1)) note(hipEventRecord(ev_all(layer, which, 1), s_));
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
     return r;
@@ -977,17 +1007,15 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         if ((rc = timed_fused(ligc, 3, 0, 2, st))) return fail(rc);
       } else {
         if ((rc = timed_fused(ligc, 2, 0, 1, st))) return fail(rc);
-        if ((rc = xs_launch(l, true, hl, hp, ligc[2], st))) return fail(rc);
-        if ((rc = timed(ligc[2], l, 2, st))) return fail(rc);
+        if ((rc = timed_xs(ligc[2], l, 2, true, hl, hp, st))) return fail(rc);
       }
     } else {
       if ((rc = timed(ligc[0], l, 0, st))) return fail(rc);
       if (node_side && fuse && !xs_lig) {
         if ((rc = timed_fused(ligc + 1, 2, 1, 2, st))) return fail(rc);
       } else {
-        if (xs_lig && (rc = xs_launch(l, true, hl, hp, ligc[2], st))) return fail(rc);
         for (int nv = 0; nv < 2; ++nv)
-          if ((rc = timed(ligc[1 + nv], l, 1 + nv, st))) return fail(rc);
+          if ((rc = (xs_lig && nv) ? timed_xs(ligc[2], l, 2, true, hl, hp, st) : timed(ligc[1 + nv], l, 1 + nv, st))) return fail(rc);
       }
     }
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
@@ -1018,9 +1046,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       if (node_side && fuse && !xs_ph) {
         if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);
       } else {
-        if (xs_ph && (rc = xs_launch(l, false, hl, hp, phc[1], sp_))) return fail(rc);
         for (int nv = 0; nv < 2; ++nv)
-          if ((rc = timed(phc[nv], l, 4 + nv, sp_))) return fail(rc);
+          if ((rc = (xs_ph && nv) ? timed_xs(phc[1], l, 5, false, hl, hp, sp_) : timed(phc[nv], l, 4 + nv, sp_))) return fail(rc);
       }
     }
     if (two) join();

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void conformer_update_kernel(DpBatch b, DpStep
   __shared__ double s_R[3][3], s_t[3];
   __shared__ float s_Rf[3][3], s_c[3], s_trp[3];
   __shared__ double s_red[256 * 9];
-  __shared__ int s_flag;
+  __shared__ int s_flag, s_sbad;
   __shared__ int s_uv[MAXT];
   __shared__ uint8_t s_mask[TMASK_CAP];
   const int p = blockIdx.x, tid = threadIdx.x;
@@ -289,8 +289,16 @@ __global__ __launch_bounds__(256) void conformer_update_kernel(DpBatch b, DpStep
   for (int i = tid; i < N * 3; i += 256) s_pos[i] = b.pos[(size_t)l0 * 3 + i];
   for (int i = tid; i < T; i += 256) s_theta[i] = sp.tor_c1 * tor[t0 + i] + (z_tor ? sp.tor_c2 * z_tor[t0 + i] : 0.f);
   stage_torsions(b, p, l0, N, t0, T, s_uv, s_mask);
-  if (tid == 0) s_flag = 0;
+  if (tid == 0) {
+    s_flag = 0;
+    // a non-finite SCORE (status bit 2): not a failure of this update - the score model left the arithmetic it was run in
+    int bad = 0;
+    for (int c = 0; c < 3; ++c) bad |= (!isfinite(tr[p * 3 + c]) || !isfinite(rot[p * 3 + c])) ? 1 : 0;
+    s_sbad = bad;
+  }
   __syncthreads();
+  for (int i = tid; i < T; i += 256)
+    if (!isfinite(tor[t0 + i])) s_sbad = 1;          // (racing writers store the same value)
   if (tid == 0) {
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int i = 0; i < N; ++i) { sx += s_pos[i * 3]; sy += s_pos[i * 3 + 1]; sz += s_pos[i * 3 + 2]; }
@@ -388,7 +396,14 @@ __global__ __launch_bounds__(256) void conformer_update_kernel(DpBatch b, DpStep
     }
   }
   __syncthreads();
-  if (tid == 0 && status && s_flag) status[p] |= s_flag;     // sticky across the steps of a run; the caller zeroes it
+  // sticky across the steps of a run (the caller zeroes it); the FIRST cause is kept: bit 2 = the scores of this step were non-finite while the pose was
+  // still fine (with the two-limb fp16 kernels: a value beyond fp16's range - run the batch again with DpWork.node_f16 = 0, edge_bf16x6 = 0; with the
+  // exact kernels: the model itself diverged), bit 0 = finite scores, but the update produced a non-finite pose (degenerate Kabsch alignment)
+  if (tid == 0 && status) {
+    const int cur = status[p];
+    const int add = s_sbad ? ((cur & 5) == 0 ? 4 : 0) : (s_flag ? 1 : 0);
+    if (add) status[p] = cur | add;
+  }
 }
 
 

@@ -253,6 +253,8 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
                     # fail the unit at once with its own reason instead of re-sampling it `retries` times as a Kabsch failure
                     bad[i] = "ligand graph repeats an ordered atom pair (not representable in the node-side pair tables; status bit 1)"
                     continue
+                if any(x & 4 for x in st) and not exact:
+                    over_range.add(i)                 # status bit 2: non-finite scores out of (possibly) the two-limb fp16 kernels
                 out.append((i, None if any(st) else torch.stack([p["ligand"].pos for p in part[lo:hi]]).numpy()))
             k += 1
             flagged += settle(out, final)
@@ -265,15 +267,25 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
     # complex they bring back flagged is first run again with the SAME noise key on the exact-fp32 kernels - poses are independent and their noise
     # is keyed by (seed, pose uid), so that IS the exact-fp32 result of the original run - and only what is flagged in the reference's own
     # arithmetic too goes on to the fresh-key retries (which stay on the exact kernels).  Only the flagged complexes are re-run, not their batches.
-    limb = getattr(getattr(model, "device_model", None), "precision", None) == "f32" and \
-        (os.environ.get("DIFFPHORE_NODE_F16", "1") != "0" or os.environ.get("DIFFPHORE_EDGE_X6", "1") != "0") and \
-        os.environ.get("DIFFPHORE_EXACT_REPLAY", "1") != "0"
+    # Which units: the ones whose status carries bit 2 (non-finite SCORES while the pose was fine: DpWork.status) from a run that was not exact already;
+    # a degenerate Kabsch alignment (bit 0) fails the same way in any arithmetic and goes straight to the fresh-key retries.
+    replay_ok = getattr(getattr(model, "device_model", None), "precision", None) == "f32" and os.environ.get("DIFFPHORE_EXACT_REPLAY", "1") != "0"
+    over_range: set = set()
     seed0 = int(seed) & 0xFFFFFFFFFFFFFFFF
-    retry = run(batches, seed0, retries <= 0 and not limb)
+    retry = run(batches, seed0, retries <= 0 and not replay_ok)
     per = max(1, max_poses // samples_per_complex)
     cut = lambda units: [units[lo:lo + per] for lo in range(0, len(units), per)]      # noqa: E731
+    limb = replay_ok and bool(over_range)
     if retry and limb:
-        retry = run(cut(retry), seed0, retries <= 0, exact=True)
+        again = [i for i in retry if i in over_range]
+        retry = [i for i in retry if i not in over_range] + run(cut(again), seed0, False, exact=True)
+    if retry and retries <= 0 and replay_ok:
+        # no fresh-key retries were asked for: what is still flagged after the exact replay is a failure
+        for i in retry:
+            bad[i] = "Kabsch alignment failed to converge (every attempt)"
+            done_bad.add(i)
+            deliver(i, None)
+        retry = []
     # retries of the Kabsch-flagged complexes with a fresh noise key each (the pose uids stay: only the seed changes)
     for attempt in range(1, retries + 1):
         if not retry:

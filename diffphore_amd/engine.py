@@ -960,11 +960,12 @@ class Engine:
 
     def launch_of(self, layer: int, conv: int):
         """(first, count, node_side) of the dp_forward launch that carries conv `conv` of interaction layer `layer` (conv numbering of
-        DpWork.prof_conv: 0 lig_conv, 1 phore_to_lig, 2 phore_to_lig_norm, 3 phore_conv, 4 lig_to_phore, 5 lig_to_phore_norm)."""
+        DpWork.prof_conv: 0 lig_conv, 1 phore_to_lig, 2 phore_to_lig_norm, 3 phore_conv, 4 lig_to_phore, 5 lig_to_phore_norm); node_side: 0 = edge-side
+        kernel, 1 = node-side kernel, 2 = a normals conv as its s0-only node-side launch + its listed pairs (DpWork.xn_sparse)."""
         f, n, ns = c_i32(), c_i32(), c_i32()
         _lib.check(self.L.dp_forward_launch_of(C.byref(self.pb.struct), C.byref(self.model.struct), C.byref(self.ws.struct), layer, conv,
                                                C.byref(f), C.byref(n), C.byref(ns)), "dp_forward_launch_of")
-        return f.value, n.value, bool(ns.value)
+        return f.value, n.value, int(ns.value)
 
     def forward(self):
         ws = self.ws

@@ -205,6 +205,14 @@ def _check_status(eng, synced=False):
         raise ValueError("ligand graph lists the same ordered atom pair twice among its bond (or radius) edges for poses "
                          f"{torch.nonzero(status & 2).flatten().tolist()}: not representable by the node-side ligand-ligand conv "
                          "(set DIFFPHORE_CONV_ALGO=edge)")
+    if bool((status & 4).any()):
+        # non-finite SCORES (DpWork.status bit 2).  The reference would hand them to its Kabsch SVD, which raises the text its callers string-match
+        # (inference.py:211); on the two-limb fp16 kernels the cause may be their exponent range, which the reference does not have: say how to leave it
+        poses = torch.nonzero(status & 4).flatten().tolist()
+        hint = (" - this engine runs the two-limb fp16 kernels (fp32-grade inside fp16's range only): run the batch on Engine(exact=True) / "
+                "DIFFPHORE_NODE_F16=0 DIFFPHORE_EDGE_X6=0 (sampling_phore does that by itself unless engine= / write_back=False / keep_update is used)"
+                if eng.limb_kernels() else "")
+        raise RuntimeError(f"linalg.svd: the score model returned non-finite scores for poses {poses}, the alignment failed to converge{hint}")
     if bool((status & 1).any()):
         # the reference raises from torch.linalg.svd and the caller string-matches this text (inference.py:211)
         raise RuntimeError(f"linalg.svd: Kabsch alignment failed to converge for poses {torch.nonzero(status & 1).flatten().tolist()}")
@@ -213,7 +221,7 @@ def _check_status(eng, synced=False):
 def _finish_run(eng, part, done=None, raise_on_status=True):
     """Wait for the batch's loop (`done`: an event recorded behind it; None = the whole launch stream) and write the final state back.
     The downloads run on the copy stream: on the launch stream they would queue behind the NEXT batch's loop.  Returns the per-pose status
-    words (0 = ok, bit 0 = Kabsch / SVD failure, bit 1 = unrepresentable ligand multigraph); with `raise_on_status` a non-zero one raises
+    words (0 = ok, bit 0 = Kabsch / SVD failure, bit 1 = unrepresentable ligand multigraph, bit 2 = non-finite scores); with `raise_on_status` a non-zero one raises
     the exception the reference's callers expect for the WHOLE batch, without it the caller sorts the poses out (library screens)."""
     pb = eng.pb
     if done is not None:
@@ -346,8 +354,8 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
         not (randomize or {}).get("keep_update", False) and os.environ.get("DIFFPHORE_EXACT_REPLAY", "1") != "0"
 
     def replay_exact(item, eng):
-        """A batch of an fp32 model that ran the two-limb fp16 kernels came back with a Kabsch flag (status bit 0 = some pose went non-finite
-        or degenerate).  Those kernels are fp32-grade only inside fp16's exponent range (Engine.limb_kernels), the reference has no such
+        """A batch of an fp32 model that ran the two-limb fp16 kernels came back with status bit 2 (the scores of some pose went non-finite while
+        the pose was fine; a degenerate Kabsch alignment - bit 0 - is not replayed: it fails the same way in any arithmetic).  Those kernels are fp32-grade only inside fp16's exponent range (Engine.limb_kernels), the reference has no such
         limit: run the batch once more on the exact-fp32 kernels - same start state (the host graphs are untouched until write-back), same
         start randomisation, same noise - before anything is reported.  What is still flagged then is flagged in the reference's own
         arithmetic."""
@@ -374,7 +382,7 @@ def _run_parts(parts_iter, model, device, common, t_to_sigma, model_args, no_ran
         nxt = launch(item, False) if item is not None else None      # ... and its loop, queued behind the running one
         if write_back and replayable and eng.limb_kernels():
             done.synchronize()
-            if bool((d2h(eng.ws.t["status"]) & 1).any()):
+            if bool((d2h(eng.ws.t["status"]) & 4).any()):
                 eng, done = replay_exact(cur_item, eng)
         if timing is not None and nxt is None:
             done.synchronize()

@@ -1,6 +1,8 @@
 """Drop-in for `TensorProductScoreModel` (src/models/score_model_phore.py:152-310) backed by the HIP library.
 
-Same constructor keywords (the released configuration only - anything else raises), same `forward(data)` contract:
+Same constructor keywords: every keyword of the reference constructor (:166-180) is either checked against the released configuration the
+kernels are specialised for (`_KW` -> `ModelConfig.check_supported`, `_MUST`), or listed in `_INERT` with the reference lines that show the
+reference itself never reads it in this configuration; anything else is a TypeError.  Same `forward(data)` contract:
 reads the hetero-graph batch fields listed in SURVEY.md 8a, returns `(tr_pred [B,3], rot_pred [B,3], tor_pred [sum T])`
 on the model device, and leaves `node_sigma_emb` / `graph_sigma_emb` on `data` like the reference does (:342,717,744).
 """
@@ -28,11 +30,39 @@ _KW = {"lig_max_radius": "lig_max_radius", "num_conv_layers": "num_conv_layers",
        "in_lig_edge_features": "in_lig_edge_features"}
 
 
+# Constructor keywords of the reference that do not change what forward() computes in the released configuration: accepted with any value and
+# ignored.  Value = where /root/reference/src/models/score_model_phore.py shows it.
+_INERT = {
+    "dynamic_max_cross": ":207 stored, never read (the cross graph is dense, :759-789)",
+    "use_phore_rule": ":223,490 stored, never read",
+    "ex_factor": ":855 only in the `else` of `if self.new` (:799); new = True is checked",
+    "clash_tolerance": ":921 only under `if self.by_radius` (:917); by_radius = False is checked",
+    "trioformer_layer": ":558-560,969-970 only under use_att (:554); use_att = False is checked",
+    "update_by_att": ":176,195,467 passed on, never read",
+    "contrastive_node": ":508 stored, never read",
+    "dist_for_fitscore": ":237 stored, never read", "angle_for_fitscore": ":238,509 stored, never read",
+    "type_for_fitscore": ":239,510 stored, never read", "sigmoid_for_fitscore": ":240 stored, never read",
+    "norm_by_ph": ":236 stored, never read", "readout": ":241 stored, never read", "as_exp": ":242 stored, never read (:197 lands in the encoder's **kwargs)",
+    "confidence_dropout": ":189 passed on, never read", "confidence_no_batchnorm": ":190 passed on, never read",
+    "num_confidence_outputs": ":190 passed on, never read",
+}
+# keywords that must keep the value the kernels are built for (beyond ModelConfig.check_supported)
+_MUST = {"confidence_mode": False, "contrastive_model": None, "num_phoretype": 11}
+
+
 class TensorProductScoreModel:
     def __init__(self, t_to_sigma=None, device="cuda", timestep_emb_func=None, sigma_args=None, precision=None, **kwargs):
         cfg = cfgmod.ModelConfig()
         if "clash_cutoff" in kwargs:
             cfg.clash_cutoff = tuple(float(x) for x in kwargs.pop("clash_cutoff"))
+        unknown = sorted(k for k in kwargs if k not in _KW and k not in _INERT and k not in _MUST)
+        if unknown:
+            raise TypeError(f"TensorProductScoreModel() got unexpected keyword argument(s) {unknown}: not a keyword of the reference constructor "
+                            "(src/models/score_model_phore.py:166-180)")
+        for k, want in _MUST.items():
+            if k in kwargs and kwargs[k] != want and not (want is None and kwargs[k] is None):
+                raise NotImplementedError(f"diffphore_amd implements the released DiffPhore score model only: {k}={kwargs[k]!r} is not supported "
+                                          f"(must be {want!r})")
         for k, v in kwargs.items():
             if k in _KW:
                 setattr(cfg, _KW[k], v)
@@ -200,4 +230,11 @@ def get_model(args, device, t_to_sigma, no_parallel=True, confidence_mode=False,
         phore_direction_transition=g("phore_direction_transition", True), phoretype_match_transition=g("phoretype_match_transition", True),
         new=g("new", True), boarder=g("boarder", False), by_radius=g("by_radius", False),
         clash_cutoff=g("clash_cutoff", [1.0, 2.0, 3.0, 4.0, 5.0]), use_att=g("use_att", False),
-        use_phore_match_feat=g("use_phore_match_feat", False), atom_weight=g("atom_weight", "softmax"), scaler=g("scaler", 1.0))
+        use_phore_match_feat=g("use_phore_match_feat", False), atom_weight=g("atom_weight", "softmax"), scaler=g("scaler", 1.0),
+        # the rest of what the reference's get_model forwards: checked (_MUST) or inert in this configuration (_INERT)
+        dynamic_max_cross=g("dynamic_max_cross", False), confidence_mode=confidence_mode, use_phore_rule=g("phore_rule", True),
+        ex_factor=g("ex_factor", -2.0), clash_tolerance=g("clash_tolerance", 0.4), trioformer_layer=g("trioformer_layer", 1),
+        contrastive_model=contrastive_model, contrastive_node=g("return_node", False), norm_by_ph=g("norm_by_ph", False),
+        dist_for_fitscore=g("dist_for_fitscore", False), angle_for_fitscore=g("angle_for_fitscore", False),
+        type_for_fitscore=g("type_for_fitscore", False), sigmoid_for_fitscore=g("sigmoid_for_fitscore", False), readout=g("readout", "mean"),
+        as_exp=g("as_exp", False))

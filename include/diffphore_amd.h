@@ -393,7 +393,14 @@ typedef struct DpWork {
   float* gpred;                     /* [B,12] */
   int32_t *t_rowptr, *t_rowend, *t_nbr, *t_src;   /* [n_tor], [n_tor], [n_tor*32], [n_tor*32] */
   float *t_emb, *t_sh, *t_hb, *t_q;               /* [n_tor*32,20], [n_tor*32,7], [n_tor,20], [n_tor,40] */
-  int32_t* status;                  /* [B] 0 ok, bit0 Kabsch degenerate / non-finite, bit1 ligand graph with a repeated (bond or radius) edge
+  int32_t* status;                  /* [B] 0 ok; bit 0 (1) the conformer update produced a non-finite pose from FINITE scores (degenerate Kabsch alignment: what
+                                       the reference reports as "linalg.svd ... failed to converge", inference.py:211); bit 2 (4) the SCORES the update was
+                                       handed were non-finite while the pose was still fine (first cause wins, both are sticky): with the two-limb fp16
+                                       kernels (node_f16 / edge_bf16x6, the defaults) this is how a feature, hidden activation or intermediate beyond
+                                       fp16's range surfaces (precondition of DP_PREC_F16X3: |T| 2^5 < 65504, i.e. node-side intermediates below ~2047,
+                                       hidden activations and features below 65504) - the caller re-runs the batch from its start state with node_f16 = 0,
+                                       edge_bf16x6 = 0 (tests/c_host/dp_host_forward.c, sampling._run_parts); with the exact kernels the model itself
+                                       diverged; bit1 ligand graph with a repeated (bond or radius) edge
                                        between the same ordered atom pair (not representable in the pair tables of the node-side lig-lig
                                        conv; only raised when that conv runs: pass DpBatch.llp_ptr = NULL for such ligands and the
                                        ligand-ligand convs use the edge-side CSR kernel, which handles multigraphs) */
@@ -453,7 +460,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
 
 /* Which launch of dp_forward carries conv `conv` (0 lig_conv, 1 phore_to_lig, 2 phore_to_lig_norm, 3 phore_conv, 4 lig_to_phore,
  * 5 lig_to_phore_norm) of interaction layer `layer` for this batch / workspace: the launch runs convs [*first, *first + *count) (count > 1:
- * a fused node-side launch, dp_tp_conv_node_fused); *node_side (may be NULL) = 1 when that launch is a node-side kernel.  The same conv
+ * a fused node-side launch, dp_tp_conv_node_fused); *node_side (may be NULL) = 1 when that launch is a node-side kernel, 2 when it is the s0-only
+ * node-side launch of a normals conv whose other paths run over the listed pairs (DpWork.xn_sparse; the bracketing events then span the DP_EDGES_LIST
+ * launch and the s0-only launch).  The same conv
  * numbering as DpWork.prof_conv: the prof_start / prof_stop events bracket exactly this launch.  Pure host logic, no GPU work. */
 int dp_forward_launch_of(const DpBatch* b, const DpWeights* w, const DpWork* k, int32_t layer, int32_t conv, int32_t* first, int32_t* count,
                          int32_t* node_side);

@@ -23,6 +23,12 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for n in names:
         assert hasattr(L, n), f"{n} declared in the header but not exported"
+    assert "dp_list_reduce" in names
+    # ... and nothing else: the C++ launchers between the library's translation units are not part of the ABI (csrc/exports.map)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TtDdBbRrWwVv"}
+    assert exported == names, sorted(exported ^ names)
 
 
 def test_source_hash_ignores_comments_and_layout_but_not_code():

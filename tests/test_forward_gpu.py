@@ -471,9 +471,10 @@ def test_hip_path_matches_reference_model_and_sampler_golden(golden_dir, algo, m
 
 @pytest.mark.parametrize("noise_mode", ["seed", "host"])
 def test_flagged_batch_of_the_limb_kernels_is_replayed_on_exact_fp32(noise_mode, monkeypatch):
-    """The two-limb fp16 kernels an fp32 model runs by default are fp32-grade only inside fp16's exponent range; beyond it a pose goes
-    non-finite and comes back with status bit 0, where the reference (plain fp32) has no such limit.  `_run_parts` therefore replays a
-    flagged batch once on the exact-fp32 kernels - same start state, start randomisation and noise - before anything is reported.  Here
+    """The two-limb fp16 kernels an fp32 model runs by default are fp32-grade only inside fp16's exponent range; beyond it the SCORES of a pose go
+    non-finite and the conformer update raises status bit 2 (DpWork.status), where the reference (plain fp32) has no such limit.  `_run_parts` therefore replays a
+    batch flagged with bit 2 once on the exact-fp32 kernels - same start state, start randomisation and noise - before anything is reported; a pure Kabsch flag
+    (bit 0: finite scores, degenerate alignment) is NOT replayed - it fails the same way in any arithmetic.  Here
     the flag is injected behind the first run's loop (the kernels' own overflow behaviour is tests/test_conv_f16_gpu.py's business): the
     call must not raise, must report one replay, and must return bit for bit what an exact-fp32 run of the same call returns - on-device
     noise (seed) and the reference-order host draws (whose later steps are drawn lazily, behind the first launch) alike.  With the replay
@@ -514,15 +515,24 @@ def test_flagged_batch_of_the_limb_kernels_is_replayed_on_exact_fp32(noise_mode,
         enqueue(eng, *a, **k)
         seen.append(eng.limb_kernels())
         if eng.limb_kernels():
-            eng.ws.t["status"][2:3].bitwise_or_(1)       # behind the loop, on the launch stream: "pose 2 went non-finite"
+            eng.ws.t["status"][2:3].bitwise_or_(flag[0])       # behind the loop, on the launch stream: "pose 2's scores went non-finite"
+    flag = [4]
     monkeypatch.setattr(sampling, "_enqueue_run", flagging)
     timing = {}
     replayed = run(timing)
     assert seen == [True, False] and timing.get("exact_replays") == 1
     for x, y in zip(replayed, exact):
         assert torch.equal(x["ligand"].pos, y["ligand"].pos) and torch.equal(x["ligand"].norm, y["ligand"].norm)
-    monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
+    # a pure Kabsch flag (bit 0) is not replayed: the reference's SVD error, at once
+    flag[0] = 1
+    del seen[:]
+    timing = {}
     with pytest.raises(RuntimeError, match="Kabsch alignment failed to converge for poses \\[2\\]"):
+        run(timing)
+    assert seen == [True] and "exact_replays" not in timing
+    flag[0] = 4
+    monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
+    with pytest.raises(RuntimeError, match="non-finite scores for poses \\[2\\], the alignment failed to converge.*Engine\\(exact=True\\)"):
         run()
 
 
@@ -530,7 +540,7 @@ def test_real_fp16_range_overflow_is_replayed_on_exact_fp32(monkeypatch):
     """The same replay on a REAL range overflow: ligand atom embeddings scaled by 10 push the radial hidden vectors x tensor-product
     operands of the later layers past what two fp16 limbs hold (|T| 2^5 < 65504, dp_conv_node_f16_impl.h) while every fp32 product stays
     finite (scores of magnitude 10^6: a diverged model, but one the reference evaluates).  The limb kernels alone end in the reference's SVD
-    error (status bit 0: non-finite pose); with the replay the call returns what the exact-fp32 kernels return, bit for bit."""
+    error (status bit 2: non-finite scores); with the replay the call returns what the exact-fp32 kernels return, bit for bit."""
     from diffphore_amd import sampling
     from diffphore_amd.diffusion import get_t_schedule, t_to_sigma_fn
     from diffphore_amd.score_model import TensorProductScoreModel
@@ -556,7 +566,7 @@ def test_real_fp16_range_overflow_is_replayed_on_exact_fp32(monkeypatch):
     for k in ("DIFFPHORE_NODE_F16", "DIFFPHORE_EDGE_X6"):
         monkeypatch.delenv(k)
     monkeypatch.setenv("DIFFPHORE_EXACT_REPLAY", "0")
-    with pytest.raises(RuntimeError, match="Kabsch alignment failed to converge"):
+    with pytest.raises(RuntimeError, match="non-finite scores .* failed to converge"):
         run()
     monkeypatch.delenv("DIFFPHORE_EXACT_REPLAY")
     timing = {}

@@ -91,6 +91,60 @@ def test_unsupported_configurations_are_rejected():
     assert [config.layer_numel(l) for l in range(4)] == [600, 1100, 1600, 2200]
 
 
+@pytest.mark.parametrize("key,val", [("lig_max_radius", 6.0), ("phore_max_radius", 4.0), ("cross_max_distance", 30.0), ("center_max_distance", 25.0),
+                                     ("ns", 16), ("num_conv_layers", 3), ("use_att", True), ("by_radius", True), ("atom_weight", "softmax"),
+                                     ("phoretype_match", False), ("multiple", True), ("sh_lmax", 3), ("clash_cutoff", [1.0, 2.0]),
+                                     ("confidence_mode", True), ("contrastive_model", object()), ("num_phoretype", 12)])
+def test_constructor_rejects_every_keyword_that_would_change_the_model(key, val):
+    """a keyword of the reference constructor (src/models/score_model_phore.py:166-180) whose value the kernels are not built for raises - it is
+    never accepted and ignored (cut-offs included: the ligand radius graph uses 5 A inside the kernels)"""
+    from diffphore_amd.score_model import TensorProductScoreModel
+    with pytest.raises(NotImplementedError):
+        TensorProductScoreModel(device="cuda", **{key: val})
+
+
+def test_constructor_keyword_surface():
+    from diffphore_amd import score_model as sm
+    # unknown keywords are a TypeError, as for any Python callable (the reference constructor takes **kwargs only to pass them on, :180)
+    with pytest.raises(TypeError, match="frobnicate"):
+        sm.TensorProductScoreModel(device="cuda", frobnicate=1)
+    # keywords the reference stores or passes on but never reads in this configuration are accepted with any value and change nothing
+    ref = sm.TensorProductScoreModel(device="cuda").cfg
+    for k in sm._INERT:
+        for v in (True, 3, "sum"):
+            assert sm.TensorProductScoreModel(device="cuda", **{k: v}).cfg == ref, k
+    assert {"dynamic_max_cross", "norm_by_ph", "as_exp", "readout"} <= set(sm._INERT)
+    # each entry names the reference lines that prove it; the lines exist where the reference is available (the build container)
+    import os
+    src = "/root/reference/src/models/score_model_phore.py"
+    if os.path.exists(src):
+        text = open(src).read().splitlines()
+        import re
+        for k, proof in sm._INERT.items():
+            lines = [int(x) for x in re.findall(r"(\d{3})", proof.split(" ")[0])]
+            assert lines, (k, proof)
+            assert any(re.search(rf"\b{k}\b", text[n - 1]) for n in lines), (k, proof)
+        # ... and a keyword of the reference signature is in exactly one of the three sets (or handled by name)
+        sig = " ".join(text[165:180])
+        names = set(re.findall(r"(\w+)=", sig)) | {"t_to_sigma", "device", "timestep_emb_func"}
+        handled = set(sm._KW) | set(sm._INERT) | set(sm._MUST) | {"clash_cutoff", "t_to_sigma", "device", "timestep_emb_func"}
+        assert names <= handled, sorted(names - handled)
+    # the get_model mirror forwards everything the reference's get_model forwards (src/utils/utils.py:121-166)
+    args = types.SimpleNamespace(no_torsion=False, num_conv_layers=4, max_radius=5.0, scale_by_sigma=True, sigma_embed_dim=20, ns=20, nv=10,
+                                 distance_embed_dim=20, cross_distance_embed_dim=20, no_batch_norm=False, dropout=0.1, use_second_order_repr=False,
+                                 cross_max_distance=25.0, dynamic_max_cross=True, consider_norm=True, phore_rule=True, auto_phorefp=False, angle_match=True,
+                                 cross_distance_transition=True, phore_direction_transition=True, phoretype_match_transition=True, new=True, ex_factor=-2.0,
+                                 boarder=True, by_radius=False, clash_tolerance=0.4, use_att=False, use_phore_match_feat=True, atom_weight="phore",
+                                 norm_by_ph=True, readout="sum", as_exp=True, scaler=100.0)
+    m = sm.get_model(args, "cuda", None)
+    assert m.cfg == ref
+    with pytest.raises(NotImplementedError):
+        sm.get_model(args, "cuda", None, confidence_mode=True)
+    args.max_radius = 6.0
+    with pytest.raises(NotImplementedError):
+        sm.get_model(args, "cuda", None)
+
+
 def test_step_scalars_follow_the_reference_formulas():
     from diffphore_amd.sampling import _step_params
     cfg = config.ModelConfig()

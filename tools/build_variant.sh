@@ -26,6 +26,6 @@ for f in *.hip; do
   objs="$objs $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../../build_abl/lib$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=exports.map $objs -o ../../build_abl/lib$name.so
 rm -rf ../../build_abl/obj_$name
 echo built build_abl/lib$name.so
