@@ -362,7 +362,7 @@ int dp_pack_conv_weights_node(int32_t kind, const float* fc0_w, const float* fc0
 // Fused node-side launch: convs[0..n) scatter onto the same node groups and their outputs add up (score_model_phore.py:703-710).
 // Allowed sequences: [LLPAIR][P2L][P2L] (any prefix / suffix of it that is not empty) or [L2P][L2P].  convs[0] names out / resid /
 // accumulate; kind, B, slices, scat_ptr, max_scatter and path_split must agree.
-static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream);
+static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream, hipEvent_t before_combine = nullptr);
 
 int dp_tp_conv_node_fused(const DpConvArgs* convs, int32_t n, void* stream) { return fused_launch(convs, n, 0, nullptr, 0, stream); }
 
@@ -374,7 +374,14 @@ int dp_tp_conv_node_fused_split(const DpConvArgs* convs, int32_t n, int32_t n_no
   return fused_launch(convs, n, n_nodes, part, part_floats, stream);
 }
 
-static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream) {
+// (library-internal, dp_dev.h) the conv-split launch whose combine kernel waits for `before_combine` (an event of ANOTHER stream): dp_forward's third
+// stream - the phore-phore conv writes the residual the combine reads while the split launch runs
+int dpn_fused_split_after(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream, void* before_combine) {
+  if (!convs || n < 2 || n_nodes <= 0 || !part || !convs[0].path_split) return DP_E_BADARG;
+  return fused_launch(convs, n, n_nodes, part, part_floats, stream, (hipEvent_t)before_combine);
+}
+
+static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream, hipEvent_t before_combine) {
   if (!convs || n < 1 || n > 3) return DP_E_BADARG;
   dpn::FusedArgs fa;
   memset(&fa, 0, sizeof(fa));
@@ -420,6 +427,7 @@ static int fused_launch(const DpConvArgs* convs, int32_t n, int32_t n_nodes, flo
   c.resid = convs[0].resid; c.resid_stride = convs[0].resid_stride; c.resid_width = convs[0].resid_width;
   for (int i = 0; i < 3; ++i) c.shift[i] = convs[i < n ? i : 0].bn_shift;
   const int total = n_nodes * c.d_out;
+  if (before_combine && hipStreamWaitEvent((hipStream_t)stream, before_combine, 0) != hipSuccess) return (int)hipGetLastError();
   hipLaunchKernelGGL(dpn::conv_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c);
   return (int)hipGetLastError();
 }

@@ -149,13 +149,22 @@ __device__ __forceinline__ void load_x2(const XSrc& xs, int lane_l, int st, f32x
   }
 }
 
-template <int KIND, int MODE, bool HALF, int P>
+// S0 (DpConvArgs.s0_only, as in dp_conv_node_f16_impl.h): the conv's harmonics are e0 on every pair the launch covers - only the paths through the
+// l = 0 component (Z000 / Z101: the operand is the gathered input itself) are evaluated; the path after P that such a launch runs next:
+template <int KIND, bool S0> constexpr int next_path(int p) {
+  for (int i = p + 1; i < Spec<KIND>::NPATH; ++i)
+    if (!(S0 && needs_s_rt(Spec<KIND>::P[i].ztype))) return i;
+  return Spec<KIND>::NPATH;
+}
+template <int KIND, int MODE, bool HALF, bool S0, int P>
 struct StageB {
   static __device__ __forceinline__ void run(__amdgpu_buffer_rsrc_t wrs, const XSrc& xs, int q, int lane, const u32x4 (&hid)[NB],
                                              unsigned tl_base, unsigned dummy_base, const float* sS, f32x4 (&acc)[n_acc4<KIND>()],
                                              f32x2 (&xr)[2][3][4], NProfT& prof_prev) {
     using S = Spec<KIND>;
-    if constexpr (P < S::NPATH) {
+    if constexpr (P < S::NPATH && S0 && needs_s_rt(S::P[P < S::NPATH ? P : 0].ztype)) {
+      StageB<KIND, MODE, HALF, S0, P + 1>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr, prof_prev);
+    } else if constexpr (P < S::NPATH) {
       constexpr PathC pc = S::P[P];
       constexpr int ZT = pc.ztype;
       constexpr bool VEC = d_out_of(ZT) == 3;
@@ -313,7 +322,7 @@ struct StageB {
         // chunk ch + 1's T fragments are read from LDS while chunk ch's MFMAs run; the next supertile's gathered operands are requested
         // at the start (they are consumed when that supertile begins: behind the W2 fragments already in flight, vector-memory returns are in order)
         {
-          constexpr int PN = P + 1;
+          constexpr int PN = next_path<KIND, S0>(P);
           const unsigned rbase = tl_base + (unsigned)(g * 128 + c * 8);          // GEMM-B view: node c, k quad g; the column is an immediate offset
           auto readT = [&](int ch, u32x4 (&tb)[NG]) {
 #pragma unroll
@@ -349,13 +358,13 @@ struct StageB {
         }
         NPROF(3);
       }
-      StageB<KIND, MODE, HALF, P + 1>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr, prof_prev);
+      StageB<KIND, MODE, HALF, S0, P + 1>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, sS, acc, xr, prof_prev);
     }
   }
 };
 
 // one pass (32 edge slots per node; HALF: 16) of one conv: stage the SH factors, GEMM1 -> hid (bf16 A fragments), then the path stages
-template <int KIND, int MODE, bool HALF>
+template <int KIND, int MODE, bool HALF, bool S0>
 __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_rsrc_t xrs, __amdgpu_buffer_rsrc_t ers, __amdgpu_buffer_rsrc_t wrs, const Grp& grp, const Wg& r, int et, int tid,
                                           float* s_T, float* s_S, const float* s_inv, f32x4 (&acc)[n_acc4<KIND>()], NProfT& prof_prev) {
   const int lane = tid & 63, q = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -394,6 +403,8 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_r
   }
   // ---- stage the SH-derived factors of the pass (fp32) and, in the pair mode, the pass's pair -> edge-slot entries ----------------
   constexpr int SLOTS = HALF ? 16 : 32;
+  static_assert(!(S0 && MODE == LL), "s0-only is a mode of the dense cross convs");
+  if constexpr (!S0) {            // (s0-only: no path reads the factors)
 #pragma unroll
   for (int idx = tid; idx < NB * SLOTS; idx += 256) {
     const int nn = idx / SLOTS, el = idx % SLOTS, e = 32 * et + el;
@@ -420,6 +431,7 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_r
     }
 #pragma unroll
     for (int i = 0; i < SCOMP; ++i) s_S[((nn * 2 + (el >> 4)) * SCOMP + i) * 16 + (el & 15)] = v[i];
+  }
   }
   __syncthreads();
   NPROF(0);
@@ -519,11 +531,11 @@ __device__ __forceinline__ void pass_bf16(const DpConvArgs& a, __amdgpu_buffer_r
   const unsigned tl_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(q * TIMG_B);
   const unsigned dummy_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)(s_T) + (unsigned)(4 * TIMG_B);
   NPROF(1);
-  StageB<KIND, MODE, HALF, 0>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0, prof_prev);
+  StageB<KIND, MODE, HALF, S0, 0>::run(wrs, xs, q, lane, hid, tl_base, dummy_base, s_S, acc, xr0, prof_prev);
 }
 
 // every pass of one conv of the (possibly fused) launch
-template <int KIND, int MODE, bool HALFOK>
+template <int KIND, int MODE, bool HALFOK, bool S0 = false>
 __device__ __forceinline__ void conv_bf16(const DpConvArgs& a, const Grp& grp, int tid, float* s_T, float* s_S, float* s_inv,
                                           f32x4 (&acc)[n_acc4<KIND>()], NProfT& prof_prev) {
   const Wg r = wg_of<MODE>(a, grp.pose);
@@ -546,13 +558,14 @@ __device__ __forceinline__ void conv_bf16(const DpConvArgs& a, const Grp& grp, i
     // HALFOK = false: the lean instantiation for launches in which no pose ends on a pass of <= 16 slots (DpConvArgs.no_tail on every conv, as
     // for the other node-side kernels): without the half-pass body the kernel spills less
     if constexpr (HALFOK) {
-      if (r.En - 32 * et <= 16) { pass_bf16<KIND, MODE, true>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev); continue; }
+      if (r.En - 32 * et <= 16) { pass_bf16<KIND, MODE, true, S0>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev); continue; }
     }
-    pass_bf16<KIND, MODE, false>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev);
+    pass_bf16<KIND, MODE, false, S0>(a, xrs, ers, wrs, grp, r, et, tid, s_T, s_S, s_inv, acc, prof_prev);
   }
 }
 
-template <int KIND, bool HAS_LL, int XMODE, bool HALFOK>
+// S0K: every conv of the launch is s0-only (its own instantiation and launch, as for the f16x3 kernel)
+template <int KIND, bool HAS_LL, int XMODE, bool HALFOK, bool S0K = false>
 #ifndef DP_WG_PER_CU
 #define DP_WG_PER_CU 2            // 1 = timing experiment: one wave per SIMD with the whole 512-register file (r5_experiments.md section 7)
 #endif
@@ -588,7 +601,7 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
     const int c_lo = cx_only < 0 ? (HAS_LL ? 1 : 0) : (cx_only < (HAS_LL ? 1 : 0) ? n_conv_all : cx_only);
     const int c_hi = cx_only < 0 ? n_conv_all : (c_lo < n_conv_all ? c_lo + 1 : n_conv_all);
 #pragma unroll 1
-    for (int cx = c_lo; cx < c_hi; ++cx) conv_bf16<KIND, XMODE, HALFOK>(fa.conv[cx], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
+    for (int cx = c_lo; cx < c_hi; ++cx) conv_bf16<KIND, XMODE, HALFOK, S0K>(fa.conv[cx], grp, tid, s_T, s_S, s_inv, acc, prof_prev);
   }
   // ---- sum the four k-partials, BatchNorm shift, residual stream (mean and BatchNorm scale are inside the operands) -----------------
   {
@@ -604,6 +617,19 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
       const int node = grp.n_lo + (live ? n : 0);
       float sh = 0.f;
       for (int k = 0; k < n_conv; ++k) sh += fa.conv[k].bn_shift[live ? ch : 0];
+      if constexpr (S0K) {
+        // the conv's listed pairs (DpConvArgs.list_*: messages of a DP_EDGES_LIST launch): scatter mean over the conv's full degree, their BatchNorm scale
+        for (int k = 0; k < n_conv; ++k) {
+          const DpConvArgs& ck = fa.conv[k];
+          if (ck.list_msg == nullptr || !live) continue;
+          const int k0 = ck.list_rowptr[node], k1 = ck.list_rowptr[node + 1];
+          if (k0 == k1) continue;
+          float sm = 0.f;
+          for (int kk = k0; kk < k1; ++kk) sm += ck.list_msg[(size_t)kk * S::D_OUT + ch];
+          const int deg = wg_of<XMODE>(ck, grp.pose).En;
+          sh += (sm / (float)max(deg, 1)) * ck.list_scale[ch];
+        }
+      }
       eb[it] = sh;
       const float* src = a.accumulate ? a.out + (size_t)node * a.out_stride + (live ? ch : 0)
                                       : (a.resid != nullptr && live && ch < a.resid_width ? a.resid + (size_t)node * a.resid_stride + ch : nullptr);
@@ -629,9 +655,21 @@ __global__ __launch_bounds__(256, DP_WG_PER_CU) void tp_conv_node_bf16_kernel(Fu
 #endif
 }
 
+template <int KIND, bool HALFOK> int launch_bf16_h(const FusedArgs& fa, int xmode, hipStream_t st);
+template <int KIND, bool HALFOK> int launch_bf16_s0(const FusedArgs& fa, int xmode, hipStream_t st, dim3 grid, dim3 block) {
+  if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_P2L, HALFOK, true>), grid, block, 0, st, fa);
+  else hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_L2P, HALFOK, true>), grid, block, 0, st, fa);
+  return (int)hipGetLastError();
+}
 template <int KIND, bool HALFOK> int launch_bf16_h(const FusedArgs& fa, int xmode, hipStream_t st) {
   const DpConvArgs& a = fa.conv[0];
   const dim3 grid((unsigned)(a.B * a.slices * (fa.conv_split ? fa.n_ll + fa.n_x : 1))), block(256);
+  int n_s0 = 0;
+  for (int i = 0; i < fa.n_ll + fa.n_x; ++i) n_s0 += fa.conv[i].s0_only ? 1 : 0;
+  if (n_s0) {                                     // s0-only convs: their own instantiation, never mixed with full convs in one launch
+    if (fa.n_ll || n_s0 != fa.n_x) return DP_E_UNSUPPORTED;
+    return launch_bf16_s0<KIND, HALFOK>(fa, xmode, st, grid, block);
+  }
   if (fa.n_ll) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, true, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
   else if (xmode == DP_EDGES_P2L) hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_P2L, HALFOK>), grid, block, 0, st, fa);
   else hipLaunchKernelGGL((tp_conv_node_bf16_kernel<KIND, false, DP_EDGES_L2P, HALFOK>), grid, block, 0, st, fa);

@@ -241,6 +241,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 struct Term { int xcomp; int scomp; float sign; };
 template <int ZT> constexpr int n_terms() { return ZT == Z000 || ZT == Z101 || ZT == Z011 ? 1 : (ZT == Z111 ? 2 : 3); }
 template <int ZT> constexpr bool needs_s() { return !(ZT == Z000 || ZT == Z101); }
+constexpr bool needs_s_rt(int zt) { return !(zt == Z000 || zt == Z101); }
 template <int ZT> __device__ __forceinline__ Term term_of(int t, int m) {
   // xcomp: offset inside the in-channel's d_in components; scomp: row of s_S
   if constexpr (ZT == Z000) return Term{0, 0, 1.f};

@@ -745,6 +745,9 @@ static bool plan_node_ll(const DpBatch* b, const DpWeights* w, const DpWork* k) 
          k->ll_pair_bond != nullptr && b->max_nl <= (k->ll_node_max_atoms > 0 ? k->ll_node_max_atoms : DP_NODE_LL_MAX_ATOMS);
 }
 
+// dp_conv_node.hip (library-internal): the conv-split launch whose combine kernel first waits for an event of another stream
+extern "C" int dpn_fused_split_after(const DpConvArgs* convs, int32_t n, int32_t n_nodes, float* part, int64_t part_floats, void* stream, void* before_combine);
+
 // which node-side launches run the two-limb fp16 kernel, and whether the normals convs split into an s0-only launch + their listed pairs
 struct F16Plan { bool f16_ok, f16_lig, f16_ph, xs_lig, xs_ph; };
 static F16Plan plan_f16(const DpBatch* b, const DpWeights* w, const DpWork* k) {
@@ -773,8 +776,20 @@ static F16Plan plan_f16(const DpBatch* b, const DpWeights* w, const DpWork* k) {
 #else
   const bool xs_have = b->xs_src && b->xs_nbr && b->xs_feat && b->xs_rowptr && b->xt_src && b->xt_nbr && b->xt_feat && b->xt_rowptr && b->n_xs >= 0 &&
                        k->xs_msg != nullptr && w->p2l_norm_conv[0].w2x && w->p2l_norm_conv[0].bn_scale_x && w->l2p_norm_conv[0].w2x && w->l2p_norm_conv[0].bn_scale_x;
-  const bool xs_want = k->xn_sparse == 1 || (k->xn_sparse == 0 && (long long)b->n_xs * 4 <= (long long)b->n_x);
-  p.xs_lig = p.f16_lig && xs_have && xs_want; p.xs_ph = p.f16_ph && xs_have && xs_want;
+  // ... and the launches fill the chip: a batch small enough for the conv split (<= DP_F16_CSPLIT_MAX_WG workgroups per fused launch) is bound by the
+  // LATENCY of its chain of launches, which the split makes two launches longer per side and layer (ms per step, 30 atoms / 32 nodes, graph + second
+  // stream, dense vs split: 40 poses 0.65 / 0.77, 96: 0.99 / 1.00, 128: 1.17 / 1.13, 256: 1.87 / 1.70, 512: 3.50 / 3.09 - profiles/r6_batch_sweep.csv)
+  const bool short_list = (long long)b->n_xs * 4 <= (long long)b->n_x;
+  auto big = [&](int max_nodes) { return k->path_split != 0 || !node_f16_conv_split_auto(b->B, (max_nodes + nb_ - 1) / nb_); };
+  p.xs_lig = p.f16_lig && xs_have && (k->xn_sparse == 1 || (k->xn_sparse == 0 && short_list && big(b->max_nl)));
+  p.xs_ph = p.f16_ph && xs_have && (k->xn_sparse == 1 || (k->xn_sparse == 0 && short_list && big(b->max_np)));
+  // a DP_PREC_BF16 model: the same split on its node-side kernels (their s0-only instantiation; the listed pairs run the two-limb fp16 list kernel,
+  // 3 % of the pairs at more than the model's precision), under that kernel's small-batch rule (conv split while B x groups <= 256)
+  if (node_side && w->precision == DP_PREC_BF16 && k->x_emb_bf != nullptr && xs_have) {
+    auto big_bf = [&](int max_nodes) { return k->path_split == 2 || (k->path_split == 0 && !node_path_split_auto(b->B, (max_nodes + nb_ - 1) / nb_, false)); };
+    p.xs_lig = k->xn_sparse == 1 || (k->xn_sparse == 0 && short_list && big_bf(b->max_nl));
+    p.xs_ph = k->xn_sparse == 1 || (k->xn_sparse == 0 && short_list && big_bf(b->max_np));
+  }
 #endif
   return p;
 }
@@ -951,7 +966,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     hipStream_t sp_ = two ? aux : st;           // stream of the phore-side convs
     if (two) fork();
     // timing hook around the launch that contains conv `which` (a fused launch answers for each of its convs)
-    auto timed_fused = [&](const DpConvArgs* cs, int n, int which_lo, int which_hi, hipStream_t s_) -> int {
+    auto timed_fused = [&](const DpConvArgs* cs, int n, int which_lo, int which_hi, hipStream_t s_, void* before_combine = nullptr) -> int {
       const bool prof = k->prof_start && k->prof_stop && k->prof_layer == l && k->prof_conv >= which_lo && k->prof_conv <= which_hi;
       if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
       if (ev_all(l, which_lo, 0)) note(hipEventRecord(ev_all(l, which_lo, 0), s_));
@@ -961,7 +976,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       const int n_nodes = lig_side ? b->n_lig : b->n_ph;
       const int64_t half = DP_CONV_PART_FLOATS / 2;
       const bool csplit = n >= 2 && cs[0].path_split && k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)n * n_nodes * cs[0].out_stride <= half;
-      const int r = csplit ? dp_tp_conv_node_fused_split(cs, n, n_nodes, k->conv_part + (lig_side ? 0 : half), half, s_)
+      if (before_combine && !csplit) note(hipStreamWaitEvent(s_, (hipEvent_t)before_combine, 0));      // (no combine launch: wait in front of the conv)
+      const int r = csplit ? (before_combine ? dpn_fused_split_after(cs, n, n_nodes, k->conv_part + (lig_side ? 0 : half), half, s_, before_combine)
+                                             : dp_tp_conv_node_fused_split(cs, n, n_nodes, k->conv_part + (lig_side ? 0 : half), half, s_))
                            : dp_tp_conv_node_fused(cs, n, s_);
       if (ev_all(l, which_lo, 1)) note(hipEventRecord(ev_all(l, which_lo, 1), s_));
       if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
@@ -1019,6 +1036,17 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       }
     }
     if (l != 3) {   // phore side (:691-700, :708-710) - reads the PRE-update ligand features
+      // third stream (DpWork.aux2_stream): when the ligand->phore launch takes the conv split (a batch that cannot fill the chip: the step is a chain
+      // of short dependent launches), the phore-phore conv runs BESIDE it instead of in front of it: it writes pad(h_p) + its output to pp_tmp, which
+      // the split launch's combine kernel (behind ev_join2) adds to the other convs' parts
+      // ... while the three launches of a layer together leave workgroup slots free (256 CUs x 2): ms per step with / without, 30 atoms / 32 nodes,
+      // graph + streams: 1 pose 0.439 / 0.473, 8: 0.476 / 0.499, 20: 0.570 / 0.535, 40: 0.678 / 0.652 - from ~18 poses on the chip is full of (long)
+      // workgroups and one more concurrent launch only stretches the others
+      const long long wg_layer = (long long)B * slices_x6 + (long long)B * ((b->max_np + nb - 1) / nb) * 2 * 2 + (long long)B * ((b->max_nl + nb - 1) / nb) * 2 * 3;
+      const bool pp_beside = two && k->aux2_stream && k->ev_join2 && k->pp_tmp && node_side && fuse && !xs_ph && f16_ph && f16_csplit(slices_lp) &&
+                             k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)2 * b->n_ph * 100 <= DP_CONV_PART_FLOATS / 2 && wg_layer <= 384;
+      hipStream_t s3 = pp_beside ? (hipStream_t)k->aux2_stream : sp_;
+      if (pp_beside) note(hipStreamWaitEvent(s3, (hipEvent_t)k->ev_fork, 0));        // (the layer's fork event, recorded on the launch stream above)
       {
         DpConvArgs c = a;
         c.mode = DP_EDGES_CSR; c.scat_ptr = b->ph_ptr; c.max_scatter = b->max_np; c.rowptr = b->pp_rowptr; c.rowend = b->pp_rowend; c.nbr = b->pp_dst;
@@ -1026,7 +1054,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
         if (edge_x6 && w->ph_conv[l].w2x && w->ph_conv[l].bn_scale_x) { c.precision = DP_PREC_F16X3; c.w2p = w->ph_conv[l].w2x; c.bn_scale = w->ph_conv[l].bn_scale_x; c.slices = slices_x6; c.phase_split = 0; }
-        if ((rc = timed(c, l, 3, sp_))) return fail(rc);
+        if (pp_beside) { c.out = k->pp_tmp; c.out_stride = 100; }
+        if ((rc = timed(c, l, 3, s3))) return fail(rc);
+        if (pp_beside) note(hipEventRecord((hipEvent_t)k->ev_join2, s3));
       }
       DpConvArgs phc[2];
       for (int nv = 0; nv < 2; ++nv) {
@@ -1043,8 +1073,11 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       }
       }
       if (xs_ph) phc[1].s0_only = 1;
+      if (pp_beside) {      // the combine launch starts from pp_tmp = pad(h_p) + phore-phore output instead of accumulating onto hp2
+        phc[0].accumulate = 0; phc[0].resid = k->pp_tmp; phc[0].resid_stride = 100; phc[0].resid_width = 100;
+      }
       if (node_side && fuse && !xs_ph) {
-        if ((rc = timed_fused(phc, 2, 4, 5, sp_))) return fail(rc);
+        if ((rc = timed_fused(phc, 2, 4, 5, sp_, pp_beside ? k->ev_join2 : nullptr))) return fail(rc);
       } else {
         for (int nv = 0; nv < 2; ++nv)
           if ((rc = (xs_ph && nv) ? timed_xs(phc[1], l, 5, false, hl, hp, sp_) : timed(phc[nv], l, 4 + nv, sp_))) return fail(rc);

@@ -74,6 +74,7 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   w.status = c.take<int32_t>(B);
   w.z_noise = c.take<float>(B * 6 + nt);
   w.conv_part = c.take<float>(DP_CONV_PART_FLOATS);
+  w.pp_tmp = c.take<float>(np * 100);
   w.xs_msg = c.take<float>((size_t)2 * (b->n_xs > 0 ? (size_t)b->n_xs : 0) * 100);
   float* tr_ = c.take<float>(B * 3);
   float* rot_ = c.take<float>(B * 3);
@@ -144,7 +145,7 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
         snprintf(nm, sizeof(nm), "%s.%d.w1n", FAMS[f], l); s.add(nm, dp_conv_w1b_floats(l));
         snprintf(nm, sizeof(nm), "%s.%d.w2n", FAMS[f], l); s.add(nm, dp_conv_w2b_floats(l));
       }
-      if (((f == 1 && l < 3) || f == 0 || f >= 4) && precision == DP_PREC_F32) {     // phore-phore stays edge-side, ligand-ligand goes edge-side for
+      if ((((f == 1 && l < 3) || f == 0 || f >= 4) && precision == DP_PREC_F32) || (f >= 4 && precision == DP_PREC_BF16)) {     // phore-phore stays edge-side, ligand-ligand goes edge-side for
                                                                             // large ligands, the normals convs run their listed pairs edge-side
                                                                             // (DP_EDGES_LIST): the second layer for the 16-bit pipe as well (DpConvW.w2x)
         snprintf(nm, sizeof(nm), "%s.%d.w2x", FAMS[f], l); s.add(nm, dp_conv_w2p_floats(l, DP_PREC_F16X3));

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void conformer_update_kernel(DpBatch b, DpStep
   // exact kernels: the model itself diverged), bit 0 = finite scores, but the update produced a non-finite pose (degenerate Kabsch alignment)
   if (tid == 0 && status) {
     const int cur = status[p];
-    const int add = s_sbad ? ((cur & 5) == 0 ? 4 : 0) : (s_flag ? 1 : 0);
+    const int add = (cur & 5) ? 0 : (s_sbad ? 4 : (s_flag ? 1 : 0));
     if (add) status[p] = cur | add;
   }
 }

@@ -90,7 +90,7 @@ class DpWork(C.Structure):
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("prof_events", VOIDP), ("conv_algo", c_i32)]
                 + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("path_split", c_i32), ("conv_fuse", c_i32), ("node_f16", c_i32),
-                                                                                 ("xs_msg", VOIDP), ("xn_sparse", c_i32)])
+                                                                                 ("aux2_stream", VOIDP), ("ev_join2", VOIDP), ("pp_tmp", VOIDP), ("xs_msg", VOIDP), ("xn_sparse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -220,7 +220,8 @@ class DeviceModel:
                 node_bf = name != "ph_conv" and prec == _lib.PREC_BF16
                 # edge-side in an fp32 model (phore-phore always, ligand-ligand for large ligands): two-limb fp16 second layer as well (w2x, bnx)
                 # ... and the two normals convs: the pairs whose harmonics are not e0 run edge-side as an explicit list (DP_EDGES_LIST)
-                x6 = ((name == "ph_conv" and l < 3) or name in ("lig_conv", "l2p_norm_conv", "p2l_norm_conv")) and prec == _lib.PREC_F32
+                x6 = (((name == "ph_conv" and l < 3) or name in ("lig_conv", "l2p_norm_conv", "p2l_norm_conv")) and prec == _lib.PREC_F32) or \
+                    (name in ("l2p_norm_conv", "p2l_norm_conv") and prec == _lib.PREC_BF16)
                 # node-side in an fp32 model: the fp32-grade two-limb fp16 fragments as well (DP_PREC_F16X3: what those convs run on by default)
                 for part, t in packing.pack_conv(sd, f"{e}{fam}.{l}", l, prec, node_side=node, x6=x6, node_bf16=node_bf, node_f16=node).items():
                     H[f"{name}.{l}.{part}"] = t
@@ -842,6 +843,9 @@ class _HipHandles:
         self.L = L
         self.stream, self.ev_fork, self.ev_join = VOIDP(), VOIDP(), VOIDP()
         _lib.check(L.dp_aux_create(C.byref(self.stream), C.byref(self.ev_fork), C.byref(self.ev_join)), "dp_aux_create")
+        # the third stream (DpWork.aux2_stream / ev_join2: the phore-phore conv of a small batch beside its ligand->phore convs)
+        self.stream2, self._ev_spare, self.ev_join2 = VOIDP(), VOIDP(), VOIDP()
+        _lib.check(L.dp_aux_create(C.byref(self.stream2), C.byref(self._ev_spare), C.byref(self.ev_join2)), "dp_aux_create")
 
     @classmethod
     def for_device(cls, index: int) -> "_HipHandles":
@@ -853,6 +857,7 @@ class _HipHandles:
     def __del__(self):
         try:
             self.L.dp_aux_destroy(self.stream, self.ev_fork, self.ev_join)
+            self.L.dp_aux_destroy(self.stream2, self._ev_spare, self.ev_join2)
         except Exception:      # noqa: BLE001 - interpreter shutdown
             pass
 
@@ -933,6 +938,8 @@ class Engine:
             self._handles = _HipHandles.for_device(dev.index if dev.index is not None else torch.cuda.current_device())
             w = self.ws.struct
             w.aux_stream, w.ev_fork, w.ev_join = self._handles.stream, self._handles.ev_fork, self._handles.ev_join
+            if os.environ.get("DIFFPHORE_THIRD_STREAM", "1") != "0":
+                w.aux2_stream, w.ev_join2 = self._handles.stream2, self._handles.ev_join2
         self.ws.struct.aux_mode = int(aux_mode)
 
     def __del__(self):

@@ -437,6 +437,12 @@ typedef struct DpWork {
   int32_t node_f16;                 /* 1 = the node-side convs of an fp32 model use DpConvW.w1h / w2h when present and the launch is not path-split:
                                        DP_PREC_F16X3, fp32-grade two-limb fp16 operands on the 16-bit matrix pipe (the default dp_work_bind sets);
                                        0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+  /* optional THIRD stream + one more event (both or none; created with dp_aux_create like the second): small batches whose pharmacophore-side launch takes
+   * the conv split then run the layer's phore-phore conv on it, beside the ligand->phore convs instead of in front of them - it writes pad(h_p) + its
+   * output to pp_tmp, which the combine launch of the conv split adds up with the other convs' parts.  A latency-bound step's longest chain per layer
+   * (phore-phore conv -> ligand->phore convs -> combine) becomes max(...) -> combine: 40 poses 0.65 -> ... ms per step.  Needs aux_stream. */
+  void *aux2_stream, *ev_join2;
+  float* pp_tmp;                    /* [n_ph, 100] */
   float* xs_msg;                    /* [2, n_xs, 100] per-edge messages of the listed pairs of the two normals convs of a layer (DP_EDGES_LIST; the two
                                        sides of a layer may run on two streams: one half each) */
   int32_t xn_sparse;                /* the two normals convs of a layer (phore_to_lig_norm / lig_to_phore_norm): 0 = library's choice - when they run on the
