@@ -100,6 +100,8 @@ def _declare(L):
     L.dp_pack_conv_weights.restype = C.c_int
     L.dp_list_reduce.argtypes = [VOIDP, VOIDP, c_i32, VOIDP, VOIDP, c_i32, VOIDP, VOIDP, c_i32, VOIDP]
     L.dp_list_reduce.restype = C.c_int
+    L.dp_list_finish.argtypes = [VOIDP, VOIDP, VOIDP, c_i32, c_i32, VOIDP, VOIDP, VOIDP, c_i32, c_i32, VOIDP, c_i32, c_i32, VOIDP]
+    L.dp_list_finish.restype = C.c_int
     L.dp_tp_conv_node.argtypes = [C.POINTER(DpConvArgs), VOIDP]
     L.dp_tp_conv_node_fused.argtypes = [C.POINTER(DpConvArgs), c_i32, VOIDP]
     L.dp_tp_conv_node_fused.restype = C.c_int

@@ -32,11 +32,38 @@ __global__ __launch_bounds__(256) void list_reduce_kernel(const float* __restric
     out[(size_t)n * out_stride + c] += (s * inv) * bn_scale[c];
   }
 }
+// finishes a DP_EDGES_LIST launch that carried a WHOLE conv (every edge of every node listed, grouped by scatter node): scatter mean over the node's
+// own edges, BatchNorm affine, residual / accumulate - what conv_epilogue does for the CSR kernel.  One thread per (node, channel).
+__global__ __launch_bounds__(256) void list_finish_kernel(const float* __restrict__ msg, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
+                                                          int n_nodes, int d_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                                                          const float* __restrict__ resid, int resid_stride, int resid_width, float* __restrict__ out,
+                                                          int out_stride, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_nodes * d_out) return;
+  const int n = i / d_out, c = i - n * d_out;
+  const int k0 = rowptr[n], k1 = rowend[n];
+  float s = 0.f;
+  for (int k = k0; k < k1; ++k) s += msg[(size_t)k * d_out + c];
+  float v = s / (float)(k1 - k0 > 1 ? k1 - k0 : 1);
+  v = v * bn_scale[c] + bn_shift[c];
+  float* o = out + (size_t)n * out_stride + c;
+  if (accumulate) *o += v;
+  else *o = v + ((resid != nullptr && c < resid_width) ? resid[(size_t)n * resid_stride + c] : 0.f);
+}
 }  // namespace dp
 
 extern "C" {
 
 int dp_abi_version(void) { return DP_ABI_VERSION; }
+
+int dp_list_finish(const float* msg, const int32_t* rowptr, const int32_t* rowend, int32_t n_nodes, int32_t d_out, const float* bn_scale, const float* bn_shift,
+                   const float* resid, int32_t resid_stride, int32_t resid_width, float* out, int32_t out_stride, int32_t accumulate, void* stream) {
+  if (!msg || !rowptr || !rowend || n_nodes <= 0 || d_out <= 0 || !bn_scale || !bn_shift || !out || out_stride < d_out) return DP_E_BADARG;
+  const long long total = (long long)n_nodes * d_out;
+  hipLaunchKernelGGL(dp::list_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, msg, rowptr, rowend, n_nodes, d_out, bn_scale,
+                     bn_shift, resid, resid_stride, resid_width, out, out_stride, accumulate);
+  return (int)hipGetLastError();
+}
 
 int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int32_t* scat_ptr, const int32_t* deg_ptr, int32_t d_out,
                    const float* bn_scale, float* out, int32_t out_stride, void* stream) {
@@ -113,10 +140,10 @@ int dp_resolve_conv_algo(int32_t algo, int32_t precision, int32_t B) {
 int dp_tp_conv(const DpConvArgs* a, void* stream) {
   if (a && a->algo == DP_ALGO_NODE) return dp_tp_conv_node(a, stream);
   if (a && a->mode == DP_EDGES_LIST) {           // explicit edge list -> per-edge messages (kinds 0-3, DP_PREC_F16X3; finished by dp_list_reduce)
-    if (a->n_list < 0 || (a->n_list > 0 && (!a->nbr || !a->edge_scat || !a->feat_idx || !a->msg_out)) || !a->gather_tab || !a->attr1_tab || !a->attr2_tab ||
+    if (a->n_list < 0 || (a->n_list > 0 && (!a->nbr || !a->edge_scat || !a->msg_out)) || !a->gather_tab || !a->attr1_tab || !a->attr2_tab ||
         !a->edge_emb || !a->edge_sh || !a->w1p || !a->w2p)
       return DP_E_BADARG;
-    if (a->kind < 0 || a->kind > 3 || !a->sh0_zero) return DP_E_UNSUPPORTED;      // (the list kernel skips the tiles of the l = 0 paths)
+    if (a->kind < 0 || a->kind > 3) return DP_E_UNSUPPORTED;
     hipStream_t st_ = (hipStream_t)stream;
     switch (a->kind) {
       case 0: return dp_conv_launch_k0(*a, st_);

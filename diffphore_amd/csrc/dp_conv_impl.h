@@ -359,7 +359,7 @@ __device__ __forceinline__ EdgeRef decode_edge(const DpConvArgs& a, const WgRang
     e.a2 = a.attr_swap ? sg : e.gather;
   } else if (a.mode == DP_EDGES_LIST) {
     const int kk = valid ? k : r.k_begin;
-    e.feat = a.feat_idx[kk];
+    e.feat = a.feat_idx ? a.feat_idx[kk] : kk;
     e.gather = a.nbr[kk];
     const int sabs = a.edge_scat[kk];
     e.scat_local = valid ? 0 : -1;
@@ -916,8 +916,8 @@ struct OperandPipe {
 // Stage TILE of the split-bf16 pipeline.  The packed weights stream L2 -> LDS through a RING-deep ring filled by LDS-DMA
 // RING-1 tiles ahead (an L2 round trip under load is ~2k cycles, longer than one bf16 tile), so a tile costs:
 //   issue DMA(tile+RING-1) | ds_read operands | 12 or 24 bf16 MFMAs | VALU contraction | counted vmcnt | s_barrier.
-// a tile whose 16 weight rows all belong to paths through the l = 0 harmonic (Z000 / Z101): a DP_EDGES_LIST launch reads that component as 0
-// (DpConvArgs.sh0_zero, required), so the tile's products are multiplied by zero - its MFMAs and contraction are skipped (the ring still carries it)
+// a tile whose 16 weight rows all belong to paths through the l = 0 harmonic (Z000 / Z101): a DP_EDGES_LIST launch with DpConvArgs.sh0_zero reads
+// that component as 0, so the tile's products are multiplied by zero - its MFMAs and contraction are skipped (SKIPL0; the ring still carries it)
 template <int KIND, int TILE> constexpr bool tile_l0_only() {
   for (int r = 0; r < 16; ++r) {
     const Triple t = triple_at<KIND>(TILE * 16 + r);
@@ -929,7 +929,7 @@ template <int KIND, int TILE> constexpr bool tile_l0_only() {
 }
 
 // EMIT (DP_EDGES_LIST): the staged messages are written to `emit` (the wave's first row of msg_out; emit_rows rows exist) instead of being summed
-template <int KIND, int NS, int TILE, bool FULL = false, bool F16 = false, bool EMIT = false>
+template <int KIND, int NS, int TILE, bool FULL = false, bool F16 = false, bool EMIT = false, bool SKIPL0 = false>
 struct StageB {
   static __device__ __forceinline__ void run(gptrq w2p, int wave, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
                                              const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
@@ -969,7 +969,7 @@ struct StageB {
         dma_tile<KIND, NS>(src, s_w + ((TILE + R - 1) % R) * NQ, wave, lane);
       }
       const unsigned lds_w = (unsigned)(__UINTPTR_TYPE__)(lptrq)s_w + lane * 16;   // LDS byte address of this lane's quad
-      if constexpr (!(EMIT && tile_l0_only<KIND, TILE>())) {
+      if constexpr (!(SKIPL0 && tile_l0_only<KIND, TILE>())) {
       f32x16 D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if DP_ABLATE == 2
       for (int r_ = 0; r_ < 16; ++r_) D[r_] = hb.v[0][0][0] == (__bf16)123.f ? 1.f : 0.5f;
@@ -1011,7 +1011,7 @@ struct StageB {
         __builtin_amdgcn_s_barrier();
       }
       __builtin_amdgcn_sched_barrier(0);
-      StageB<KIND, NS, TILE + 1, FULL, F16, EMIT>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local, emit, emit_rows);
+      StageB<KIND, NS, TILE + 1, FULL, F16, EMIT, SKIPL0>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local, emit, emit_rows);
     } else {
       constexpr int PHL = n_tiles_phase<KIND>(1) > 0 ? 1 : 0;
       PROF_MARK(5);
@@ -1133,7 +1133,7 @@ struct StageP {
 #define DP_PIPE_NS1 1      // 0: the one-product kernel on StageB like the split kernels (A/B builds)
 #endif
 
-template <int KIND, int NS, bool FULL = false, bool F16 = false, bool EMIT = false>
+template <int KIND, int NS, bool FULL = false, bool F16 = false, bool EMIT = false, bool SKIPL0 = false>
 __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArgs a) {
   using S = Spec<KIND>;
   using G = Geo<KIND>;
@@ -1196,8 +1196,8 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
         StageP<KIND, 0, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local, D0);
     } else if constexpr (EMIT) {
       const int k0 = kc + wave * 32, left = r.k_end - k0;
-      StageB<KIND, NS, 0, FULL, F16, true>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local,
-                                                a.msg_out + (size_t)k0 * S::D_OUT, left < 0 ? 0 : (left > 32 ? 32 : left));
+      StageB<KIND, NS, 0, FULL, F16, true, SKIPL0>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local,
+                                                        a.msg_out + (size_t)k0 * S::D_OUT, left < 0 ? 0 : (left > 32 ? 32 : left));
     } else {
       StageB<KIND, NS, 0, FULL, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local);
     }
@@ -1214,7 +1214,10 @@ template <int KIND> int launch(const DpConvArgs& a_in, hipStream_t st) {
     if constexpr (KIND <= 3) {
       if (a.precision != DP_PREC_F16X3) return DP_E_UNSUPPORTED;
       if (a.n_list <= 0) return DP_OK;
-      hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2, false, true, true>), dim3((unsigned)((a.n_list + CHUNK_B - 1) / CHUNK_B)), dim3(WAVES_B * 64), 0, st, a);
+      const dim3 grid_l((unsigned)((a.n_list + CHUNK_B - 1) / CHUNK_B));
+      // sh0_zero: the tiles whose rows all belong to l = 0 paths multiply by a zero and are skipped (their own instantiation)
+      if (a.sh0_zero) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2, false, true, true, true>), grid_l, dim3(WAVES_B * 64), 0, st, a);
+      else hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2, false, true, true, false>), grid_l, dim3(WAVES_B * 64), 0, st, a);
       return (int)hipGetLastError();
     } else {
       return DP_E_UNSUPPORTED;

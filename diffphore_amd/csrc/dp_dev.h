@@ -85,3 +85,19 @@ __device__ __forceinline__ void mlp_tail20(const DpMlp& m, const float* h, float
 }
 
 }  // namespace dp
+
+// Whether the phore-phore convs of a batch run as ONE DP_EDGES_LIST launch over all its edges (+ dp_list_finish) instead of the CSR launch with its
+// workgroups per (pose, slice): the CSR kernel works in 128-edge chunks per workgroup, and a small pharmacophore leaves them mostly empty (configs[1]:
+// 150 edges per pose = 2 chunks, 59 % full; a 40-pose call: 8 slices of 19 edges).  The list packs the batch's edges into full chunks.  Estimated from
+// the batch's averages (host arithmetic; dp_work_bind sizes DpWork.pp_msg by it, dp_forward takes the list when that array is there).
+static inline bool dp_pp_as_list(const DpBatch* b) {
+  if (b->n_pp <= 0 || b->B <= 0) return false;
+  const int mx = b->max_nl > b->max_np ? b->max_nl : b->max_np;
+  int slices = 1;
+  while ((mx + slices - 1) / slices > 32) ++slices;                 // (dp_conv_max_nodes of the split-bf16 kernels, as dp_forward deals the slices)
+  while (b->B * slices < 512 && slices < 8) ++slices;
+  const double per_slice = (double)b->n_pp / b->B / slices;
+  const double chunks = (double)b->B * slices * (double)(long long)((per_slice + 127.0) / 128.0);
+  return (double)b->n_pp < 0.7 * chunks * 128.0;
+}
+

@@ -890,7 +890,14 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
 #endif
   // the listed pairs of one normals conv: their messages through the edge-side kernel BEFORE the conv's s0-only launch, whose epilogue folds them in
   // (scatter mean over the full degree, BatchNorm scale: DpConvArgs.list_*)
-  auto xs_launch = [&](int l_, bool lig_side, const float* hl_, const float* hp_, DpConvArgs& s0conv, hipStream_t s_) -> int {
+  auto xs_bind = [&](int l_, bool lig_side, DpConvArgs& s0conv) {
+    if (!xs_list || b->n_xs <= 0) return;
+    const DpConvW& cw = lig_side ? w->p2l_norm_conv[l_] : w->l2p_norm_conv[l_];
+    s0conv.list_msg = k->xs_msg + (lig_side ? (size_t)0 : (size_t)b->n_xs * 100);
+    s0conv.list_rowptr = lig_side ? b->xs_rowptr : b->xt_rowptr;
+    s0conv.list_scale = cw.bn_scale_x;
+  };
+  auto xs_launch = [&](int l_, bool lig_side, const float* hl_, const float* hp_, hipStream_t s_) -> int {
     if (!xs_list || b->n_xs <= 0) return DP_OK;
     const DpConvW& cw = lig_side ? w->p2l_norm_conv[l_] : w->l2p_norm_conv[l_];
     float* msg = k->xs_msg + (lig_side ? (size_t)0 : (size_t)b->n_xs * 100);
@@ -905,9 +912,12 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.gather_stride = c.attr1_stride = c.attr2_stride = 100;
     c.edge_emb = k->x_emb; c.edge_sh = k->x_nsh; c.sh_stride = 9;
     c.w1p = cw.w1p; c.w2p = cw.w2x;
-    s0conv.list_msg = msg; s0conv.list_rowptr = lig_side ? b->xs_rowptr : b->xt_rowptr; s0conv.list_scale = cw.bn_scale_x;
     return dp_tp_conv(&c, s_);
   };
+  // With a third stream (DpWork.aux2_stream + ev_join2 / ev_x2) the list launches of a layer - small grids, a chunk's latency each - run there from
+  // the start of the layer, beside the layer's big launches, instead of in front of their s0-only launch on its stream
+  const bool xs_async = aux != nullptr && k->aux2_stream && k->ev_join2 && k->ev_x2 && xs_list && b->n_xs > 0;
+  bool xs_early[2] = {false, false};
   auto node_path_split = [&](int B_, int slices_) {
     return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(B_, slices_, f16_ok)));
   };
@@ -943,7 +953,10 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     const bool prof = k->prof_start && k->prof_stop && k->prof_layer == layer && k->prof_conv == which;
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
     if (ev_all(layer, which, 0)) note(hipEventRecord(ev_all(layer, which, 0), s_));
-    int r = xs_launch(layer, lig_side, hl_, hp_, c, s_);
+    int r = DP_OK;
+    xs_bind(layer, lig_side, c);
+    if (xs_early[lig_side ? 0 : 1]) note(hipStreamWaitEvent(s_, (hipEvent_t)(lig_side ? k->ev_join2 : k->ev_x2), 0));      // its list launch ran on the third stream
+    else r = xs_launch(layer, lig_side, hl_, hp_, s_);
     if (!r) r = dp_tp_conv(&c, s_);
     if (ev_all(layer, which, 1)) note(hipEventRecord(ev_all(layer, which, 1), s_));
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
@@ -965,6 +978,22 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     const bool two = aux != nullptr && l != 3 && k->aux_mode != 1;
     hipStream_t sp_ = two ? aux : st;           // stream of the phore-side convs
     if (two) fork();
+    xs_early[0] = xs_early[1] = false;
+    if (xs_async && (xs_lig || (xs_ph && l != 3))) {
+      hipStream_t s3x = (hipStream_t)k->aux2_stream;
+      if (!two) note(hipEventRecord((hipEvent_t)k->ev_fork, st));      // (layer 3 / single-side layers: the layer's inputs are complete on st here)
+      note(hipStreamWaitEvent(s3x, (hipEvent_t)k->ev_fork, 0));
+      if (xs_lig) {
+        if ((rc = xs_launch(l, true, hl, hp, s3x))) return fail(rc);
+        note(hipEventRecord((hipEvent_t)k->ev_join2, s3x));
+        xs_early[0] = true;
+      }
+      if (xs_ph && l != 3) {
+        if ((rc = xs_launch(l, false, hl, hp, s3x))) return fail(rc);
+        note(hipEventRecord((hipEvent_t)k->ev_x2, s3x));
+        xs_early[1] = true;
+      }
+    }
     // timing hook around the launch that contains conv `which` (a fused launch answers for each of its convs)
     auto timed_fused = [&](const DpConvArgs* cs, int n, int which_lo, int which_hi, hipStream_t s_, void* before_combine = nullptr) -> int {
       const bool prof = k->prof_start && k->prof_stop && k->prof_layer == l && k->prof_conv >= which_lo && k->prof_conv <= which_hi;
@@ -1043,7 +1072,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       // graph + streams: 1 pose 0.439 / 0.473, 8: 0.476 / 0.499, 20: 0.570 / 0.535, 40: 0.678 / 0.652 - from ~18 poses on the chip is full of (long)
       // workgroups and one more concurrent launch only stretches the others
       const long long wg_layer = (long long)B * slices_x6 + (long long)B * ((b->max_np + nb - 1) / nb) * 2 * 2 + (long long)B * ((b->max_nl + nb - 1) / nb) * 2 * 3;
-      const bool pp_beside = two && k->aux2_stream && k->ev_join2 && k->pp_tmp && node_side && fuse && !xs_ph && f16_ph && f16_csplit(slices_lp) &&
+      const bool pp_beside = two && k->aux2_stream && k->ev_join2 && k->pp_tmp && node_side && fuse && !xs_ph && !xs_lig && f16_ph && f16_csplit(slices_lp) &&
                              k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)2 * b->n_ph * 100 <= DP_CONV_PART_FLOATS / 2 && wg_layer <= 384;
       hipStream_t s3 = pp_beside ? (hipStream_t)k->aux2_stream : sp_;
       if (pp_beside) note(hipStreamWaitEvent(s3, (hipEvent_t)k->ev_fork, 0));        // (the layer's fork event, recorded on the launch stream above)
@@ -1053,9 +1082,23 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         c.edge_scat = b->pp_src; c.gather_tab = hp; c.attr1_tab = hp; c.attr2_tab = hp; c.edge_emb = k->pp_emb; c.edge_sh = k->pp_sh;
         c.w1p = w->ph_conv[l].w1p; c.w2p = w->ph_conv[l].w2p; c.bn_scale = w->ph_conv[l].bn_scale; c.bn_shift = w->ph_conv[l].bn_shift;
         c.out = hp2; c.accumulate = 0; c.resid = hp; c.resid_width = din;
-        if (edge_x6 && w->ph_conv[l].w2x && w->ph_conv[l].bn_scale_x) { c.precision = DP_PREC_F16X3; c.w2p = w->ph_conv[l].w2x; c.bn_scale = w->ph_conv[l].bn_scale_x; c.slices = slices_x6; c.phase_split = 0; }
+        const bool x6 = edge_x6 && w->ph_conv[l].w2x && w->ph_conv[l].bn_scale_x;
+        if (x6) { c.precision = DP_PREC_F16X3; c.w2p = w->ph_conv[l].w2x; c.bn_scale = w->ph_conv[l].bn_scale_x; c.slices = slices_x6; c.phase_split = 0; }
         if (pp_beside) { c.out = k->pp_tmp; c.out_stride = 100; }
-        if ((rc = timed(c, l, 3, s3))) return fail(rc);
+        if (x6 && k->pp_msg != nullptr && dp_pp_as_list(b)) {
+          // small pharmacophores: the batch's phore-phore edges as ONE list in full 128-edge chunks (dp_pp_as_list), then mean / BatchNorm / residual
+          DpConvArgs cl = c;
+          cl.mode = DP_EDGES_LIST; cl.n_list = b->n_pp; cl.sh0_zero = 0; cl.msg_out = k->pp_msg; cl.feat_idx = nullptr;
+          const bool prof = k->prof_start && k->prof_stop && k->prof_layer == l && k->prof_conv == 3;
+          if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s3));
+          if (ev_all(l, 3, 0)) note(hipEventRecord(ev_all(l, 3, 0), s3));
+          rc = dp_tp_conv(&cl, s3);
+          if (!rc) rc = dp_list_finish(k->pp_msg, b->pp_rowptr, b->pp_rowend, b->n_ph, D[l + 1], c.bn_scale, c.bn_shift, c.resid, c.resid_stride, c.resid_width,
+                                       c.out, c.out_stride, 0, s3);
+          if (ev_all(l, 3, 1)) note(hipEventRecord(ev_all(l, 3, 1), s3));
+          if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s3));
+          if (rc) return fail(rc);
+        } else if ((rc = timed(c, l, 3, s3))) return fail(rc);
         if (pp_beside) note(hipEventRecord((hipEvent_t)k->ev_join2, s3));
       }
       DpConvArgs phc[2];

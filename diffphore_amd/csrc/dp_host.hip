@@ -75,6 +75,7 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   w.z_noise = c.take<float>(B * 6 + nt);
   w.conv_part = c.take<float>(DP_CONV_PART_FLOATS);
   w.pp_tmp = c.take<float>(np * 100);
+  w.pp_msg = dp_pp_as_list(b) ? c.take<float>(npp * 100) : nullptr;
   w.xs_msg = c.take<float>((size_t)2 * (b->n_xs > 0 ? (size_t)b->n_xs : 0) * 100);
   float* tr_ = c.take<float>(B * 3);
   float* rot_ = c.take<float>(B * 3);

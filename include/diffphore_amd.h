@@ -161,13 +161,14 @@ typedef struct DpConvArgs {
                                 wherever the pharmacophore type does not agree with the atom's fingerprint (:874-894 - r = 0 there), and the few
                                 pairs that do agree (DpBatch.xs_*) are added by an edge-side launch over exactly those pairs (DP_EDGES_LIST) */
   /* DP_EDGES_LIST (edge-side kernel at DP_PREC_F16X3 only): an explicit list of n_list edges anywhere in the batch - edge k scatters onto node
-   * edge_scat[k], gathers node nbr[k], reads row feat_idx[k] of edge_emb / edge_sh; attr_swap as for DP_EDGES_CSR.  The launch writes the edges'
-   * MESSAGES msg_out[k][D_out] (no mean, no BatchNorm: dp_list_reduce finishes the conv) - 128 edges per workgroup whatever nodes they belong to */
+   * edge_scat[k], gathers node nbr[k], reads row feat_idx[k] (NULL: row k) of edge_emb / edge_sh; attr_swap as for DP_EDGES_CSR.  The launch writes
+   * the edges' MESSAGES msg_out[k][D_out] (no mean, no BatchNorm: dp_list_reduce / dp_list_finish / DpConvArgs.list_* finish the conv) - 128 edges
+   * per workgroup whatever nodes (and poses) they belong to: no partly filled chunk per pose */
   const int32_t* feat_idx;
   float* msg_out;
   int32_t n_list;
-  int32_t sh0_zero;          /* DP_EDGES_LIST: must be 1 = component 0 of every edge_sh row is read as 0: the tensor-product paths through the l = 0 harmonic
-                                are NOT part of a list launch (that part of the conv is the s0_only launch) */
+  int32_t sh0_zero;          /* DP_EDGES_LIST: 1 = component 0 of every edge_sh row is read as 0: the tensor-product paths through the l = 0 harmonic are
+                                not part of this launch (that part of the conv is an s0_only launch); 0 = the whole conv */
   /* s0_only convs: the messages of the conv's listed pairs (a DP_EDGES_LIST launch that ran before this one), folded in by this launch's epilogue
    * instead of a dp_list_reduce launch: out[n][c] also gets list_scale[c] * sum(list_msg[k][c], k = list_rowptr[n] .. list_rowptr[n + 1]) / degree.
    * All three or none. */
@@ -185,6 +186,12 @@ int dp_tp_conv(const DpConvArgs* args, void* stream);
  * bn_scale: what the messages' weights were packed with (DpConvW.bn_scale_x for DP_PREC_F16X3).  Deterministic (one thread per node and channel). */
 int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int32_t* scat_ptr, const int32_t* deg_ptr, int32_t d_out,
                    const float* bn_scale, float* out, int32_t out_stride, void* stream);
+/* Finishes a DP_EDGES_LIST launch that carried a WHOLE conv (sh0_zero = 0, every edge listed, grouped by scatter node: edges rowptr[n] .. rowend[n] of
+ * node n): out[n][c] = base + bn_scale[c] * mean of msg[k][c] over the node's edges + bn_shift[c], base = out[n][c] (accumulate) or resid[n][c] for
+ * c < resid_width or 0 - the epilogue of the CSR kernel, for convs whose poses have too few edges to fill 128-edge chunks of their own
+ * (dp_forward: the phore-phore convs of small pharmacophores). */
+int dp_list_finish(const float* msg, const int32_t* rowptr, const int32_t* rowend, int32_t n_nodes, int32_t d_out, const float* bn_scale, const float* bn_shift,
+                   const float* resid, int32_t resid_stride, int32_t resid_width, float* out, int32_t out_stride, int32_t accumulate, void* stream);
 /* the node-side kernel directly (dp_tp_conv dispatches here when args->algo == DP_ALGO_NODE) */
 int dp_tp_conv_node(const DpConvArgs* args, void* stream);
 int dp_conv_node_max_nodes(void);
@@ -442,7 +449,13 @@ typedef struct DpWork {
    * output to pp_tmp, which the combine launch of the conv split adds up with the other convs' parts.  A latency-bound step's longest chain per layer
    * (phore-phore conv -> ligand->phore convs -> combine) becomes max(...) -> combine: 40 poses 0.65 -> ... ms per step.  Needs aux_stream. */
   void *aux2_stream, *ev_join2;
+  void* ev_x2;                      /* one more event for the third stream (optional, A/B runs: measured slower on a full chip): with it the DP_EDGES_LIST launches
+                                       of a layer's normals convs run on aux2_stream from the start of the layer (beside the big launches) instead of in
+                                       front of their s0-only launches */
   float* pp_tmp;                    /* [n_ph, 100] */
+  float* pp_msg;                    /* [n_pp, 100] per-edge messages of a phore-phore conv that runs as one DP_EDGES_LIST launch over the whole batch's edges +
+                                       dp_list_finish (dp_forward: when the poses' own edge lists would leave their 128-edge chunks less than 70 % full -
+                                       small pharmacophores - and the two-limb fp16 edge-side weights are there), or NULL (dp_work_bind: not needed) */
   float* xs_msg;                    /* [2, n_xs, 100] per-edge messages of the listed pairs of the two normals convs of a layer (DP_EDGES_LIST; the two
                                        sides of a layer may run on two streams: one half each) */
   int32_t xn_sparse;                /* the two normals convs of a layer (phore_to_lig_norm / lig_to_phore_norm): 0 = library's choice - when they run on the

@@ -454,6 +454,36 @@ def test_list_launch_rejects_what_it_does_not_cover():
     for k_, v in dict(msg_out=msg, edge_scat=lst["edge_scat"], nbr=lst["nbr"], feat_idx=lst["feat_idx"], gather_tab=base["gather_tab"], attr1_tab=base["attr1_tab"],
                       attr2_tab=base["attr2_tab"], edge_emb=base["edge_emb"], edge_sh=base["edge_sh"], w1p=base["w1p"], w2p=lst["w2x"]).items():
         setattr(a, k_, v.data_ptr())
-    assert _lib.lib().dp_tp_conv(C.byref(a), None) == -2          # sh0_zero = 0: the list kernel does not evaluate the l = 0 paths
-    a.sh0_zero, a.kind = 1, 5
+    a.kind = 5
     assert _lib.lib().dp_tp_conv(C.byref(a), None) == -2          # layer convs only
+    a.kind, a.precision = 1, _lib.PREC_F32
+    assert _lib.lib().dp_tp_conv(C.byref(a), None) == -2          # the two-limb fp16 form only
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_whole_conv_as_one_list_launch(kind):
+    """DP_EDGES_LIST with sh0_zero = 0 + dp_list_finish: a WHOLE conv (every edge listed, grouped by scatter node, rows of the edge tables = list
+    positions) - what dp_forward does with the phore-phore convs of small pharmacophores, whose poses cannot fill 128-edge chunks of their own.
+    Against the fp64 oracle at the edge-side kernels' tolerance."""
+    NL, NP = [7, 30, 13, 1, 40, 17], [32, 5, 79, 33, 17, 48]
+    base, ref, resid, dims, n_out, lst = _sparse_sh_case(kind, "p2l", 3100 + kind, NL, NP, 1.1)       # density > 1: every pair is listed
+    E = base["edge_sh"].shape[0]
+    assert lst["n_list"] == E
+    keep = []
+    msg = torch.full((E, dims["d_out"]), float("nan")).cuda()
+    larg = dict(kind=kind, mode=_lib.EDGES_LIST, B=len(NL), slices=1, precision=_lib.PREC_F16X3, max_scatter=1, n_list=E, sh0_zero=0, msg_out=msg,
+                edge_scat=lst["edge_scat"], nbr=lst["nbr"], feat_idx=None, attr_swap=0, gather_tab=base["gather_tab"], gather_stride=dims["d_in"],
+                attr1_tab=base["attr1_tab"], attr1_stride=dims["d_in"], attr2_tab=base["attr2_tab"], attr2_stride=dims["d_in"], edge_emb=base["edge_emb"],
+                edge_sh=base["edge_sh"], sh_stride=9, w1p=base["w1p"], w2p=lst["w2x"])
+    _run(larg, keep)
+    out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
+    rp = lst["rowptr"]
+    _lib.check(_lib.lib().dp_list_finish(msg.data_ptr(), rp.data_ptr(), rp[1:].contiguous().data_ptr(), n_out, dims["d_out"], lst["bnx"].data_ptr(),
+                                         base["bn_shift"].data_ptr(), base["resid"].data_ptr(), dims["d_in"], dims["d_in"], out.data_ptr(), dims["d_out"], 0,
+                                         torch.cuda.current_stream().cuda_stream), "dp_list_finish")
+    torch.cuda.synchronize()
+    want = ref.clone()
+    want[:, :dims["d_in"]] += resid.double()
+    err = (out.cpu().double() - want).abs().max().item() / ref.abs().max().item()
+    print(f"kind {kind}: whole conv as a list launch vs fp64 oracle {err:.2e}")
+    assert err < TOL, err
