@@ -334,6 +334,8 @@ __global__ __launch_bounds__(256) void lig_edges_kernel(DpBatch b, DpWeights w, 
     const int n_rows = E - e0 < 256 ? E - e0 : 256;
     const int o = base + (live ? e0 + tid : E - 1);
     const size_t o0 = (size_t)(base + e0);
+    // (a thread past the last edge re-reads slot E - 1 while that slot's own thread rewrites it below with the type bits stripped: either value
+    //  gives a valid (src, dst) - only `bt` may differ - and such a thread stores nothing: a benign race)
     const int packed = k.ll_src[o];
     const int bt = (packed >> 28) & 7, src = packed & 0x0fffffff, dst = k.ll_nbr[o];
     if (live) {
@@ -731,6 +733,8 @@ int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream) {
 //    f16x3 launches beyond): 1 pose 0.570 -> 0.468, 8: 0.622 -> 0.490, 20: 0.698 -> 0.527, 40: 0.697 -> 0.651, 64: 0.838 -> 0.793, 96: 1.036 -> 0.991,
 //    128 (512 workgroups per fused launch): 1.11 either way.  The two sides of a layer run side by side: the gain is large while BOTH split
 //    launches fit the chip at once (<= 25 poses of this shape) and small beyond.
+// (f16_avail: only reached by builds with DP_F16_CSPLIT_MAX_WG <= 0 - the shipped library gives an fp32 model's small batches the f16x3 conv split
+//  instead and never takes the fp32 path split by itself; the bf16 model calls this with f16_avail = false)
 static int node_path_split_auto(int B, int slices, bool f16_avail) { return (long long)B * slices <= (f16_avail ? 48 : 256) ? 1 : 0; }
 #ifndef DP_F16_CSPLIT_MAX_WG
 #define DP_F16_CSPLIT_MAX_WG 384

@@ -68,11 +68,18 @@ enum DpPrecision {
   DP_PREC_F16X3 = 6     /* fp32-GRADE on the 16-bit pipe.  Node-side kernel (dp_conv_node_f16_impl.h): every operand of the three GEMMs as TWO fp16 limbs
                            (hi = rne16(v), lo = rne16(v - hi): 22 significand bits; exact power-of-two scales map the operands into fp16's
                            range), cross products hi*hi + hi*lo + lo*hi (+ lo*lo in the second contraction) on v_mfma_f32_16x16x32_f16, fp32
-                           accumulate.  Held to the same tolerances as DP_PREC_F32.  Precondition: |features|, |edge embedding| < 65504 (beyond: non-finite -> status bit 0; the Python host replays such a batch on DP_PREC_F32).
+                           accumulate.  Held to the same tolerances as DP_PREC_F32.  PRECONDITIONS (what "inside fp16's range" means here):
+                           the node-side intermediate T = sum over a node's edges of hidden x tensor-product operand, divided by the degree,
+                           carries up to 2^5: |T| < ~2047; gathered features, SH factors, edge embeddings and hidden activations < 65504; the
+                           packed second layer is scaled by ONE power of two per conv (max |W2 x bn_scale| -> (1024, 2048]), so a weight more
+                           than 2^25 below the conv's largest keeps less than 11 + 11 bits (accuracy is relative to that maximum, as the
+                           tests' tolerance is).  Beyond the range: non-finite scores -> DpWork.status bit 2 (the caller replays the batch with
+                           node_f16 = 0, edge_bf16x6 = 0: tests/c_host/dp_host_forward.c, sampling._run_parts).
                            Edge-side kernel (dp_conv.hip, round 5): the radial contraction W2 hid with both operands as two fp16 limbs, 3 cross
                            products on v_mfma_f32_32x32x16_f16 (weights from dp_pack_conv_weights(kind, DP_PREC_F16X3): W2 * 2^w, w in a trailing
-                           quad; the caller passes bn_scale * 2^-w).  Not a model precision: dp_forward uses it for the convs of a DP_PREC_F32
-                           model (DpWork.node_f16 for the node-side launches, DpWork.edge_bf16x6 for the convs that stay edge-side). */
+                           quad; the caller passes bn_scale * 2^-w); hidden activations are converted unscaled (< 65504).  Not a model precision:
+                           dp_forward uses it for the convs of a DP_PREC_F32 model (DpWork.node_f16 for the node-side launches, DpWork.edge_bf16x6
+                           for the convs that stay edge-side and for the DP_EDGES_LIST launches). */
 };
 
 /* formulation of the fused conv: per-edge radial GEMM, or node-side contraction (dense cross edge sets; DP_PREC_F32 or DP_PREC_BF16) */

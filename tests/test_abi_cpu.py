@@ -44,7 +44,7 @@ def test_source_hash_ignores_comments_and_layout_but_not_code():
 
 def test_committed_traffic_records_match_the_kernel_sources():
     """bench.py quotes `roofline.traffic` only from a PMC record taken on the SAME kernel sources (profiles/conv_hbm_traffic.json, keyed by
-    build.source_hash()): a kernel edit - even a comment - without a new tools/gpu_round5_final3.sh run would make the driver's bench line say
+    build.source_hash()): a kernel edit without a new tools/gpu_evidence.sh run would make the driver's bench line say
     traffic: null.  Records for the headline workload (config 2, f32) and the bf16 workload (config 5)."""
     import json
     import os
@@ -52,7 +52,7 @@ def test_committed_traffic_records_match_the_kernel_sources():
     recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "conv_hbm_traffic.json")))
     h = build.source_hash()
     mine = {(r["config"], r["precision"]) for r in recs if r["source_hash"] == h}
-    assert (2, "f32") in mine and (5, "bf16") in mine, f"no PMC traffic record for kernel sources {h}: re-run tools/gpu_round5_final3.sh and commit profiles/"
+    assert (2, "f32") in mine and (5, "bf16") in mine, f"no PMC traffic record for kernel sources {h}: re-run tools/gpu_evidence.sh and commit profiles/"
 
 
 def test_build_identity_and_ablation_builds_are_refused(monkeypatch):

@@ -35,12 +35,26 @@ for k in range(4):
         SLOTS[f"tp_conv_node_f16_kernel<{k}, true, 1, {h}>"] = [LIG3]
         SLOTS[f"tp_conv_node_f16_kernel<{k}, false, 1, {h}>"] = [LIG2]
         SLOTS[f"tp_conv_node_f16_kernel<{k}, false, 2, {h}>"] = [PH2]
+# round 6: the 16-bit node-side kernels carry a fifth template argument (S0K: the s0-only instantiation of a normals conv, its own launch) and the
+# normals convs of a big batch run as that launch + a DP_EDGES_LIST launch over their listed pairs (tp_conv_bf16_kernel<KIND, 2, false, true, EMIT =
+# true, SKIPL0 = true>); the phore-phore convs of small pharmacophores as a list launch over the whole batch's edges (SKIPL0 = false)
+LIG2L, LIGN0, PHN0, PH1 = "lig-lig + phore->lig", "phore->lig(norm), l = 0 part", "lig->phore(norm), l = 0 part", "lig->phore"
+for k in range(4):
+    for fam in ("tp_conv_node_f16_kernel", "tp_conv_node_bf16_kernel"):
+        for h in ("true", "false"):
+            SLOTS[f"{fam}<{k}, true, 1, {h}, false>"] = [LIG3]            # re-labelled below when the batch took the split
+            SLOTS[f"{fam}<{k}, false, 1, {h}, false>"] = [LIG2]
+            SLOTS[f"{fam}<{k}, false, 2, {h}, false>"] = [PH2]
+            SLOTS[f"{fam}<{k}, false, 1, {h}, true>"] = [LIGN0]
+            SLOTS[f"{fam}<{k}, false, 2, {h}, true>"] = [PHN0]
+    SLOTS[f"tp_conv_bf16_kernel<{k}, 2, false, true, true, true>"] = ["normals convs: listed pairs (both sides)"]
+    SLOTS[f"tp_conv_bf16_kernel<{k}, 2, false, true, true, false>"] = ["phore-phore (list launch)"]
 SLOTS["tp_conv_kernel<4>"] = ["centre (final_conv)"]
 SLOTS["tp_conv_kernel<5>"] = ["torsion bonds (tor_bond_conv)"]
 # SURVEY.md 8d per edge-conv (edge-side count): 2*(n_attr*hid + hid*numel) + 2*sum_paths mul_in*mul_out*(2 l_out + 1); kinds 4 / 5 = the
 # centre head (fc 40->40->200, out 2x1o+2x1e) and the torsion head (fc 60->60->1600, scalar outputs)
 FLOPS = {0: 79200 + 2000, 1: 139200 + 4200, 2: 199200 + 6400, 3: 271200 + 8400, 4: 19200 + 1200, 5: 199200 + 3200}
-EDGE_SET = {LIG3: ("ll", "x", "x"), LIG2: ("x", "x"), PH2: ("x", "x"), "lig-lig": "ll", "phore-phore": "pp", "phore->lig": "x", "phore->lig(norm)": "x", "lig->phore": "x", "lig->phore(norm)": "x",
+EDGE_SET = {LIG3: ("ll", "x", "x"), LIG2: ("x", "x"), PH2: ("x", "x"), "lig-lig + phore->lig": ("ll", "x"), "lig->phore": ("x",), "phore-phore (list launch)": "pp", "lig-lig": "ll", "phore-phore": "pp", "phore->lig": "x", "phore->lig(norm)": "x", "lig->phore": "x", "lig->phore(norm)": "x",
             "centre (final_conv)": "center", "torsion bonds (tor_bond_conv)": "tor"}
 
 
@@ -53,12 +67,18 @@ def slot_names(kernels_seen):
     """edge-side layer kernels: all six slots when the node-side kernel is absent, only phore-phore (and lig-lig when that ran
     edge-side) otherwise; in an fp32 model those edge-side convs run as tp_conv_bf16_kernel<KIND, 3, false> (bf16x6)"""
     s = dict(SLOTS)
+    split = any(k.startswith(("tp_conv_node_f16_kernel<", "tp_conv_node_bf16_kernel<")) and k.endswith(", true>") for k in kernels_seen)
+    if split:                                        # the fused launches carry one conv less each
+        for k in list(s):
+            if k.startswith(("tp_conv_node_f16_kernel<", "tp_conv_node_bf16_kernel<")) and k.endswith(", false>") and k.count(",") == 4:
+                s[k] = [{LIG3: LIG2L, LIG2: "phore->lig", PH2: PH1}[s[k][0]]]
     node = any("tp_conv_node" in k for k in kernels_seen)
     node_ll = any("tp_conv_node" in k and ", true, " in k.split("<")[1][:12] for k in kernels_seen)
     x6 = any(k.startswith("tp_conv_bf16_kernel<") and k.endswith(", 3, false>") for k in kernels_seen)
     x1 = any(k.startswith("tp_conv_bf16_kernel<") and k.endswith(", 1, false>") for k in kernels_seen)      # precision="bf16": one-product edge-side kernel
     for k in range(4):
         names = [f"tp_conv_kernel<{k}>"] + ([f"tp_conv_bf16_kernel<{k}, 3, false>"] if node and x6 else []) + ([f"tp_conv_bf16_kernel<{k}, 1, false>"] if node and x1 else [])
+        names += [n_ for n_ in (f"tp_conv_bf16_kernel<{k}, 2, false, true, false, false>", f"tp_conv_bf16_kernel<{k}, 1, false, false, false, false>") if n_ in kernels_seen]
         for n in names:
             if not node:
                 s[n] = EDGE_ALL if k < 3 else EDGE_ALL[:3]
@@ -144,7 +164,7 @@ def main():
                     fa, wa = sum(f) / len(f), sum(w) / len(w)
                     res.append(f"{k},{sname},{len(f)},{fa:.1f},{wa:.1f},{2 * fa / 1024:.2f},{wa / 1024:.2f}")
                     if (k.startswith("tp_conv_node_kernel<3, true, 1, ")) or (k == "tp_conv_kernel<3>" and sname == "phore->lig") or \
-                            k.startswith("tp_conv_node_bf16_kernel<3, true, 1") or k.startswith("tp_conv_node_f16_kernel<3, true, 1, "):      # bench.py PROF_LAYER = 3
+                            (k.startswith(("tp_conv_node_bf16_kernel<3, true, 1", "tp_conv_node_f16_kernel<3, true, 1, ")) and not k.endswith(", true>")):      # bench.py PROF_LAYER = 3
                         rec = int((2 * fa + wa) * 1024)
         open(f"{a.prefix}_conv_hbm_traffic.csv", "w").write("\n".join(res) + "\n")
         if rec is not None and bench is not None:
