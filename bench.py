@@ -446,7 +446,9 @@ def main():
         m = TensorProductScoreModel(device=dev, precision=precision)
         m.load_state_dict(sd)
         gl = [g.sample_copy() for g in graphs]
-        sampling_phore(gl[:8], m, 2, sched, sched, sched, dev, t2s, margs, batch_size=20)     # warm-up
+        # warm-up on the WHOLE pose list, two steps: a 512-pose batch launches kernels an 8-pose one never does (fused launches instead of the conv split,
+        # the s0-only / list kernels of the normals convs) and the runtime loads a kernel's code at its first launch (~10 ms, seen as 75 instead of 62 ms of loop)
+        sampling_phore([g.sample_copy() for g in graphs], m, 2, sched, sched, sched, dev, t2s, margs, batch_size=20)
         torch.cuda.synchronize()
         import gc
         gc.collect()             # a generation-2 collection inside the 0.14 s timed call would be a third of it (seen: 20 -> 110 ms host stage)
