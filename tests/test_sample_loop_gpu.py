@@ -22,7 +22,7 @@ def _args():
 
 
 def _run(gs, noise, S, monkeypatch, **env):
-    for k in ("DIFFPHORE_WHOLE_LOOP", "DIFFPHORE_GRAPH", "DIFFPHORE_TWO_STREAMS", "DIFFPHORE_CONV_ALGO"):
+    for k in ("DIFFPHORE_WHOLE_LOOP", "DIFFPHORE_GRAPH", "DIFFPHORE_TWO_STREAMS", "DIFFPHORE_CONV_ALGO", "DIFFPHORE_XN_SPARSE", "DIFFPHORE_PATH_SPLIT", "DIFFPHORE_PP_LIST"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -34,14 +34,21 @@ def _run(gs, noise, S, monkeypatch, **env):
     return torch.cat([g["ligand"].pos for g in out]).numpy(), torch.cat([g["ligand"].norm for g in out]).numpy()
 
 
-@pytest.mark.parametrize("algo", ["edge", "node"])
+@pytest.mark.parametrize("algo", ["edge", "node", "node-large"])
 def test_whole_loop_graph_and_two_streams_are_bit_identical_to_per_step(monkeypatch, algo):
+    """`node-large`: the forms a batch that fills the chip takes (round 6) forced onto this small one - fused launches instead of the conv split, the
+    normals convs as s0-only launch + listed pairs, the phore-phore convs as one list launch (already this batch's choice) - through the same drivers"""
+    large = dict(DIFFPHORE_XN_SPARSE="1", DIFFPHORE_PATH_SPLIT="0") if algo == "node-large" else {}
+    algo = "node" if algo == "node-large" else algo
+
+    def run(gs, noise, S, monkeypatch, **env):        # every arm of this case carries the same switches
+        return _run(gs, noise, S, monkeypatch, **dict(large, **env))
     gs = synthetic.synthetic_pairs(91, 7, (8, 30), (0, 6), (5, 34))
     S = 5
     gen = torch.Generator().manual_seed(3)
     nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
     noise = dict(tr=torch.randn(S, len(gs), 3, generator=gen), rot=torch.randn(S, len(gs), 3, generator=gen), tor=torch.randn(S, nT, generator=gen))
-    base = _run(gs, noise, S, monkeypatch, DIFFPHORE_WHOLE_LOOP="0", DIFFPHORE_TWO_STREAMS="0", DIFFPHORE_CONV_ALGO=algo)
+    base = run(gs, noise, S, monkeypatch, DIFFPHORE_WHOLE_LOOP="0", DIFFPHORE_TWO_STREAMS="0", DIFFPHORE_CONV_ALGO=algo)
     assert np.all(np.isfinite(base[0]))
     variants = {
         "dp_sample eager": dict(DIFFPHORE_GRAPH="0", DIFFPHORE_TWO_STREAMS="0"),
@@ -50,7 +57,7 @@ def test_whole_loop_graph_and_two_streams_are_bit_identical_to_per_step(monkeypa
         "two streams, graph": dict(DIFFPHORE_GRAPH="1", DIFFPHORE_TWO_STREAMS="1"),
     }
     for name, env in variants.items():
-        got = _run(gs, noise, S, monkeypatch, DIFFPHORE_CONV_ALGO=algo, **env)
+        got = run(gs, noise, S, monkeypatch, DIFFPHORE_CONV_ALGO=algo, **env)
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), name
 
 
