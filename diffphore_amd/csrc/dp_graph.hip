@@ -918,9 +918,13 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.w1p = cw.w1p; c.w2p = cw.w2x;
     return dp_tp_conv(&c, s_);
   };
-  // With a third stream (DpWork.aux2_stream + ev_join2 / ev_x2) the list launches of a layer - small grids, a chunk's latency each - run there from
-  // the start of the layer, beside the layer's big launches, instead of in front of their s0-only launch on its stream
-  const bool xs_async = aux != nullptr && k->aux2_stream && k->ev_join2 && k->ev_x2 && xs_list && b->n_xs > 0;
+  // Where the list launches of a layer run (DpWork.xs_place).  They are small grids (one chunk's latency each, ~120 workgroups): in front of their s0-only
+  // launch they sit on that stream's chain; CROSSED, each opens the OTHER side's stream at the start of the layer (the ligand side's list launch on the
+  // pharmacophore side's stream and vice versa; layer 3, which has no pharmacophore side, uses the idle second stream) - its consumer waits for an event
+  // that has long fired.  2 = both on the third stream (measured slower: one more concurrent launch on a full chip).
+  const bool xs_ev = k->ev_join2 && k->ev_x2 && xs_list && b->n_xs > 0 && aux != nullptr;
+  const int xs_place = (!xs_ev || k->xs_place == 0) ? 3 : (k->xs_place == 2 && !k->aux2_stream ? 3 : k->xs_place);
+  const bool xs_async = xs_place == 2;
   bool xs_early[2] = {false, false};
   auto node_path_split = [&](int B_, int slices_) {
     return k->path_split == 1 ? 1 : (k->path_split == 2 ? 0 : ((f16_ok && DP_F16_CSPLIT_MAX_WG > 0) ? 0 : node_path_split_auto(B_, slices_, f16_ok)));
@@ -983,18 +987,20 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     hipStream_t sp_ = two ? aux : st;           // stream of the phore-side convs
     if (two) fork();
     xs_early[0] = xs_early[1] = false;
-    if (xs_async && (xs_lig || (xs_ph && l != 3))) {
-      hipStream_t s3x = (hipStream_t)k->aux2_stream;
-      if (!two) note(hipEventRecord((hipEvent_t)k->ev_fork, st));      // (layer 3 / single-side layers: the layer's inputs are complete on st here)
-      note(hipStreamWaitEvent(s3x, (hipEvent_t)k->ev_fork, 0));
+    if ((xs_async || xs_place == 1) && (xs_lig || (xs_ph && l != 3))) {
+      // the layer's inputs are complete on st here (ev_fork: recorded by fork() when the layer has two sides)
+      if (!two) note(hipEventRecord((hipEvent_t)k->ev_fork, st));
+      hipStream_t s_lig = xs_async ? (hipStream_t)k->aux2_stream : aux;       // crossed: the ligand side's list on the second stream ...
+      hipStream_t s_ph = xs_async ? (hipStream_t)k->aux2_stream : st;         // ... the pharmacophore side's on the launch stream
+      if (xs_async || !two) note(hipStreamWaitEvent(s_lig, (hipEvent_t)k->ev_fork, 0));      // (with two sides the second stream has waited in fork())
       if (xs_lig) {
-        if ((rc = xs_launch(l, true, hl, hp, s3x))) return fail(rc);
-        note(hipEventRecord((hipEvent_t)k->ev_join2, s3x));
+        if ((rc = xs_launch(l, true, hl, hp, s_lig))) return fail(rc);
+        note(hipEventRecord((hipEvent_t)k->ev_join2, s_lig));
         xs_early[0] = true;
       }
       if (xs_ph && l != 3) {
-        if ((rc = xs_launch(l, false, hl, hp, s3x))) return fail(rc);
-        note(hipEventRecord((hipEvent_t)k->ev_x2, s3x));
+        if ((rc = xs_launch(l, false, hl, hp, s_ph))) return fail(rc);
+        note(hipEventRecord((hipEvent_t)k->ev_x2, s_ph));
         xs_early[1] = true;
       }
     }
@@ -1097,6 +1103,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
           if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s3));
           if (ev_all(l, 3, 0)) note(hipEventRecord(ev_all(l, 3, 0), s3));
           rc = dp_tp_conv(&cl, s3);
+          // (its mean / BatchNorm affine as a launch of its own: folded into the epilogue of the layer's s0-only lig_to_phore_norm launch - one launch
+          //  and one pass over hp2 less - the step was 3 % SLOWER, 164.4 k vs 169.3 k: the dependent loads stand at the end of a short kernel)
           if (!rc) rc = dp_list_finish(k->pp_msg, b->pp_rowptr, b->pp_rowend, b->n_ph, D[l + 1], c.bn_scale, c.bn_shift, c.resid, c.resid_stride, c.resid_width,
                                        c.out, c.out_stride, 0, s3);
           if (ev_all(l, 3, 1)) note(hipEventRecord(ev_all(l, 3, 1), s3));

@@ -90,7 +90,7 @@ class DpWork(C.Structure):
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("prof_events", VOIDP), ("conv_algo", c_i32)]
                 + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("path_split", c_i32), ("conv_fuse", c_i32), ("node_f16", c_i32),
-                                                                                 ("aux2_stream", VOIDP), ("ev_join2", VOIDP), ("ev_x2", VOIDP), ("pp_tmp", VOIDP), ("pp_msg", VOIDP), ("xs_msg", VOIDP), ("xn_sparse", c_i32)])
+                                                                                 ("aux2_stream", VOIDP), ("ev_join2", VOIDP), ("ev_x2", VOIDP), ("pp_tmp", VOIDP), ("pp_msg", VOIDP), ("xs_msg", VOIDP), ("xs_place", c_i32), ("xn_sparse", c_i32)])
 
 
 class DpStepParams(C.Structure):
@@ -941,11 +941,12 @@ class Engine:
             w = self.ws.struct
             w.aux_stream, w.ev_fork, w.ev_join = self._handles.stream, self._handles.ev_fork, self._handles.ev_join
             if os.environ.get("DIFFPHORE_THIRD_STREAM", "1") != "0":
-                w.aux2_stream, w.ev_join2 = self._handles.stream2, self._handles.ev_join2
-                if os.environ.get("DIFFPHORE_XS_ASYNC", "0") == "1":
-                    # A/B switch (off: measured 165.8k vs 169.7k pose-steps/s at configs[1] - the list launches beside the big launches stretch them by
-                    # more than their own latency, profiles/r6_experiments.md): the normals convs' list launches on the third stream
-                    w.ev_x2 = self._handles._ev_spare
+                w.aux2_stream, w.ev_join2, w.ev_x2 = self._handles.stream2, self._handles.ev_join2, self._handles._ev_spare
+            place = os.environ.get("DIFFPHORE_XS_PLACE", "auto")
+            if place not in ("auto", "crossed", "third", "front"):
+                raise ValueError(f"DIFFPHORE_XS_PLACE must be auto, crossed, third or front (got {place!r})")
+            # where the list launches of a layer's normals convs run (DpWork.xs_place; profiles/r6_experiments.md: front > third stream > crossed)
+            w.xs_place = {"auto": 0, "crossed": 1, "third": 2, "front": 3}[place]
         self.ws.struct.aux_mode = int(aux_mode)
 
     def __del__(self):

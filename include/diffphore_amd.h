@@ -456,15 +456,19 @@ typedef struct DpWork {
    * output to pp_tmp, which the combine launch of the conv split adds up with the other convs' parts.  A latency-bound step's longest chain per layer
    * (phore-phore conv -> ligand->phore convs -> combine) becomes max(...) -> combine: 40 poses 0.65 -> ... ms per step.  Needs aux_stream. */
   void *aux2_stream, *ev_join2;
-  void* ev_x2;                      /* one more event for the third stream (optional, A/B runs: measured slower on a full chip): with it the DP_EDGES_LIST launches
-                                       of a layer's normals convs run on aux2_stream from the start of the layer (beside the big launches) instead of in
-                                       front of their s0-only launches */
+  void* ev_x2;                      /* one more event (optional; with ev_join2 it lets the list launches of a layer's normals convs run somewhere else than in front
+                                       of their s0-only launch, see xs_place) */
   float* pp_tmp;                    /* [n_ph, 100] */
   float* pp_msg;                    /* [n_pp, 100] per-edge messages of a phore-phore conv that runs as one DP_EDGES_LIST launch over the whole batch's edges +
                                        dp_list_finish (dp_forward: when the poses' own edge lists would leave their 128-edge chunks less than 70 % full -
                                        small pharmacophores - and the two-limb fp16 edge-side weights are there), or NULL (dp_work_bind: not needed) */
   float* xs_msg;                    /* [2, n_xs, 100] per-edge messages of the listed pairs of the two normals convs of a layer (DP_EDGES_LIST; the two
                                        sides of a layer may run on two streams: one half each) */
+  int32_t xs_place;                 /* where the DP_EDGES_LIST launches of a layer's two normals convs run (small grids, one chunk's latency each): 0 = library's
+                                       choice (3: measured - a small launch beside the big ones stretches them by more than its own latency); 1 = CROSSED: each side's list launch opens the OTHER
+                                       side's stream at the start of the layer - far from its consumer, beside the big launches of its own side, and off the
+                                       chain that ends in that consumer; 2 = both on aux2_stream from the start of the layer (measured slower on a full chip);
+                                       3 = in front of their s0-only launch on its stream */
   int32_t xn_sparse;                /* the two normals convs of a layer (phore_to_lig_norm / lig_to_phore_norm): 0 = library's choice - when they run on the
                                        f16x3 node-side kernel, the batch carries the pair lists (DpBatch.xs_*) and at most a quarter of the cross pairs is
                                        listed, each is evaluated as its l = 0 part on every pair (DpConvArgs.s0_only, its own node-side launch) + the
