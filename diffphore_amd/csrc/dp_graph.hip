@@ -923,7 +923,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   // pharmacophore side's stream and vice versa; layer 3, which has no pharmacophore side, uses the idle second stream) - its consumer waits for an event
   // that has long fired.  2 = both on the third stream (measured slower: one more concurrent launch on a full chip).
   const bool xs_ev = k->ev_join2 && k->ev_x2 && xs_list && b->n_xs > 0 && aux != nullptr;
-  const int xs_place = (!xs_ev || k->xs_place == 0) ? 3 : (k->xs_place == 2 && !k->aux2_stream ? 3 : k->xs_place);
+  const int xs_place = (!xs_ev || k->xs_place == 0 || k->xs_place == 4) ? 3 : (k->xs_place == 2 && !k->aux2_stream ? 3 : k->xs_place);
   const bool xs_async = xs_place == 2;
   bool xs_early[2] = {false, false};
   auto node_path_split = [&](int B_, int slices_) {
@@ -962,10 +962,19 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s_));
     if (ev_all(layer, which, 0)) note(hipEventRecord(ev_all(layer, which, 0), s_));
     int r = DP_OK;
-    xs_bind(layer, lig_side, c);
-    if (xs_early[lig_side ? 0 : 1]) note(hipStreamWaitEvent(s_, (hipEvent_t)(lig_side ? k->ev_join2 : k->ev_x2), 0));      // its list launch ran on the third stream
+    // the messages reach the output through a dp_list_reduce launch behind the s0-only launch (library's choice: 171.1 k vs 169.9 k pose-steps/s folded into
+    // that launch's epilogue, DpConvArgs.list_*, xs_place = 3: the fold's dependent loads stand at the end of a short kernel)
+    const bool own_reduce = k->xs_place != 3 && xs_list && b->n_xs > 0;
+    if (!own_reduce) xs_bind(layer, lig_side, c);
+    if (xs_early[lig_side ? 0 : 1]) note(hipStreamWaitEvent(s_, (hipEvent_t)(lig_side ? k->ev_join2 : k->ev_x2), 0));      // its list launch ran elsewhere
     else r = xs_launch(layer, lig_side, hl_, hp_, s_);
     if (!r) r = dp_tp_conv(&c, s_);
+    if (!r && own_reduce) {
+      static const int DOUT_[4] = {50, 80, 100, 100};
+      const DpConvW& cw = lig_side ? w->p2l_norm_conv[layer] : w->l2p_norm_conv[layer];
+      r = dp_list_reduce(k->xs_msg + (lig_side ? (size_t)0 : (size_t)b->n_xs * 100), lig_side ? b->xs_rowptr : b->xt_rowptr, B, lig_side ? b->lig_ptr : b->ph_ptr,
+                         lig_side ? b->ph_ptr : b->lig_ptr, DOUT_[layer], cw.bn_scale_x, c.out, 100, s_);
+    }
     if (ev_all(layer, which, 1)) note(hipEventRecord(ev_all(layer, which, 1), s_));
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
     return r;

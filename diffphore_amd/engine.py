@@ -943,10 +943,10 @@ class Engine:
             if os.environ.get("DIFFPHORE_THIRD_STREAM", "1") != "0":
                 w.aux2_stream, w.ev_join2, w.ev_x2 = self._handles.stream2, self._handles.ev_join2, self._handles._ev_spare
             place = os.environ.get("DIFFPHORE_XS_PLACE", "auto")
-            if place not in ("auto", "crossed", "third", "front"):
+            if place not in ("auto", "crossed", "third", "front", "front-reduce"):
                 raise ValueError(f"DIFFPHORE_XS_PLACE must be auto, crossed, third or front (got {place!r})")
             # where the list launches of a layer's normals convs run (DpWork.xs_place; profiles/r6_experiments.md: front > third stream > crossed)
-            w.xs_place = {"auto": 0, "crossed": 1, "third": 2, "front": 3}[place]
+            w.xs_place = {"auto": 0, "crossed": 1, "third": 2, "front": 3, "front-reduce": 4}[place]
         self.ws.struct.aux_mode = int(aux_mode)
 
     def __del__(self):

@@ -464,11 +464,12 @@ typedef struct DpWork {
                                        small pharmacophores - and the two-limb fp16 edge-side weights are there), or NULL (dp_work_bind: not needed) */
   float* xs_msg;                    /* [2, n_xs, 100] per-edge messages of the listed pairs of the two normals convs of a layer (DP_EDGES_LIST; the two
                                        sides of a layer may run on two streams: one half each) */
-  int32_t xs_place;                 /* where the DP_EDGES_LIST launches of a layer's two normals convs run (small grids, one chunk's latency each): 0 = library's
-                                       choice (3: measured - a small launch beside the big ones stretches them by more than its own latency); 1 = CROSSED: each side's list launch opens the OTHER
-                                       side's stream at the start of the layer - far from its consumer, beside the big launches of its own side, and off the
-                                       chain that ends in that consumer; 2 = both on aux2_stream from the start of the layer (measured slower on a full chip);
-                                       3 = in front of their s0-only launch on its stream */
+  int32_t xs_place;                 /* the DP_EDGES_LIST launches of a layer's two normals convs (small grids, one chunk's latency each) and how their messages
+                                       reach the output: 0 = library's choice (4); 4 = list launch in front of its s0-only launch on that launch's stream,
+                                       dp_list_reduce launch behind it; 3 = the same, messages folded into the s0-only launch's epilogue (DpConvArgs.list_*:
+                                       one launch less, measured 0.7 % slower at 512 poses); 1 = CROSSED: each side's list launch opens the OTHER side's
+                                       stream at the start of the layer (needs aux_stream, ev_join2, ev_x2; measured 2.6 % slower: a small launch beside
+                                       the big ones stretches them); 2 = both on aux2_stream from the start of the layer (1.6 % slower).  1 / 2 fold. */
   int32_t xn_sparse;                /* the two normals convs of a layer (phore_to_lig_norm / lig_to_phore_norm): 0 = library's choice - when they run on the
                                        f16x3 node-side kernel, the batch carries the pair lists (DpBatch.xs_*) and at most a quarter of the cross pairs is
                                        listed, each is evaluated as its l = 0 part on every pair (DpConvArgs.s0_only, its own node-side launch) + the
