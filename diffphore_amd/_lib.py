@@ -98,7 +98,7 @@ def _declare(L):
     L.dp_conv_dims.restype = C.c_int
     L.dp_pack_conv_weights.argtypes = [c_i32, c_i32, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP, VOIDP]
     L.dp_pack_conv_weights.restype = C.c_int
-    L.dp_list_reduce.argtypes = [VOIDP, VOIDP, c_i32, VOIDP, VOIDP, c_i32, VOIDP, VOIDP, c_i32, VOIDP]
+    L.dp_list_reduce.argtypes = [VOIDP, VOIDP, c_i32, VOIDP, c_i32, VOIDP, c_i32, VOIDP, VOIDP, c_i32, VOIDP]
     L.dp_list_reduce.restype = C.c_int
     L.dp_list_finish.argtypes = [VOIDP, VOIDP, VOIDP, c_i32, c_i32, VOIDP, VOIDP, VOIDP, c_i32, c_i32, VOIDP, c_i32, c_i32, VOIDP]
     L.dp_list_finish.restype = C.c_int

@@ -13,25 +13,24 @@ int dp_conv_launch_k5(const DpConvArgs& a, hipStream_t st) { return dp::launch<5
 
 namespace dp {
 // finishes a DP_EDGES_LIST conv: the scatter MEAN over the node's FULL degree (the listed edges are a subset of a dense conv's edges: the degree
-// is the pose's number of gather nodes), the BatchNorm scale, and the sum onto `out`.  One workgroup per pose; a node's messages are added in list
-// order by one thread per channel: deterministic.
+// is the pose's number of gather nodes), the BatchNorm scale, and the sum onto `out`.  blockIdx.x = pose, blockIdx.y = a block of 256 (node, channel)
+// items of it; a node's messages are added in list order by one thread per channel: deterministic.
 __global__ __launch_bounds__(256) void list_reduce_kernel(const float* __restrict__ msg, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ scat_ptr,
                                                           const int32_t* __restrict__ deg_ptr, int d_out, const float* __restrict__ bn_scale,
                                                           float* __restrict__ out, int out_stride) {
   const int p = blockIdx.x;
   const int n0 = scat_ptr[p], n1 = scat_ptr[p + 1];
-  if (rowptr[n0] == rowptr[n1]) return;             // no listed edge in this pose
+  const int i = blockIdx.y * 256 + threadIdx.x;
+  if (i >= (n1 - n0) * d_out) return;
+  const int n = n0 + i / d_out, c = i % d_out;
+  const int k0 = rowptr[n], k1 = rowptr[n + 1];
+  if (k0 == k1) return;
   const int deg = deg_ptr[p + 1] - deg_ptr[p];
-  const float inv = 1.f / (float)(deg > 1 ? deg : 1);
-  for (int i = threadIdx.x; i < (n1 - n0) * d_out; i += 256) {
-    const int n = n0 + i / d_out, c = i % d_out;
-    const int k0 = rowptr[n], k1 = rowptr[n + 1];
-    if (k0 == k1) continue;
-    float s = 0.f;
-    for (int k = k0; k < k1; ++k) s += msg[(size_t)k * d_out + c];
-    out[(size_t)n * out_stride + c] += (s * inv) * bn_scale[c];
-  }
+  float s = 0.f;
+  for (int k = k0; k < k1; ++k) s += msg[(size_t)k * d_out + c];
+  out[(size_t)n * out_stride + c] += (s / (float)(deg > 1 ? deg : 1)) * bn_scale[c];
 }
+
 // finishes a DP_EDGES_LIST launch that carried a WHOLE conv (every edge of every node listed, grouped by scatter node): scatter mean over the node's
 // own edges, BatchNorm affine, residual / accumulate - what conv_epilogue does for the CSR kernel.  One thread per (node, channel).
 __global__ __launch_bounds__(256) void list_finish_kernel(const float* __restrict__ msg, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
@@ -65,10 +64,11 @@ int dp_list_finish(const float* msg, const int32_t* rowptr, const int32_t* rowen
   return (int)hipGetLastError();
 }
 
-int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int32_t* scat_ptr, const int32_t* deg_ptr, int32_t d_out,
+int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int32_t* scat_ptr, int32_t max_scatter, const int32_t* deg_ptr, int32_t d_out,
                    const float* bn_scale, float* out, int32_t out_stride, void* stream) {
-  if (!msg || !rowptr || B <= 0 || !scat_ptr || !deg_ptr || d_out <= 0 || !bn_scale || !out || out_stride < d_out) return DP_E_BADARG;
-  hipLaunchKernelGGL(dp::list_reduce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, msg, rowptr, scat_ptr, deg_ptr, d_out, bn_scale, out, out_stride);
+  if (!msg || !rowptr || B <= 0 || !scat_ptr || max_scatter <= 0 || !deg_ptr || d_out <= 0 || !bn_scale || !out || out_stride < d_out) return DP_E_BADARG;
+  const unsigned blocks = (unsigned)((max_scatter * d_out + 255) / 256);
+  hipLaunchKernelGGL(dp::list_reduce_kernel, dim3((unsigned)B, blocks), dim3(256), 0, (hipStream_t)stream, msg, rowptr, scat_ptr, deg_ptr, d_out, bn_scale, out, out_stride);
   return (int)hipGetLastError();
 }
 

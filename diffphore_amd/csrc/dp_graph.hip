@@ -973,7 +973,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       static const int DOUT_[4] = {50, 80, 100, 100};
       const DpConvW& cw = lig_side ? w->p2l_norm_conv[layer] : w->l2p_norm_conv[layer];
       r = dp_list_reduce(k->xs_msg + (lig_side ? (size_t)0 : (size_t)b->n_xs * 100), lig_side ? b->xs_rowptr : b->xt_rowptr, B, lig_side ? b->lig_ptr : b->ph_ptr,
-                         lig_side ? b->ph_ptr : b->lig_ptr, DOUT_[layer], cw.bn_scale_x, c.out, 100, s_);
+                         lig_side ? b->max_nl : b->max_np, lig_side ? b->ph_ptr : b->lig_ptr, DOUT_[layer], cw.bn_scale_x, c.out, 100, s_);
     }
     if (ev_all(layer, which, 1)) note(hipEventRecord(ev_all(layer, which, 1), s_));
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));

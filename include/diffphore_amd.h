@@ -188,10 +188,10 @@ typedef struct DpConvArgs {
  * Replaces TensorProductConvLayer.forward, score_model_phore.py:134-149. */
 int dp_tp_conv(const DpConvArgs* args, void* stream);
 /* Finishes a DP_EDGES_LIST launch: out[n][c] += bn_scale[c] * (sum of msg[k][c] over the listed edges k of node n, rowptr[n] .. rowptr[n + 1], in list
- * order) / max(deg, 1), deg = deg_ptr[p + 1] - deg_ptr[p] of the node's pose p (nodes scat_ptr[p] .. scat_ptr[p + 1]): the scatter MEAN of
+ * order) / max(deg, 1), deg = deg_ptr[p + 1] - deg_ptr[p] of the node's pose p (nodes scat_ptr[p] .. scat_ptr[p + 1], at most max_scatter of them): the scatter MEAN of
  * TensorProductConvLayer.forward (score_model_phore.py:141) runs over ALL edges of the dense conv the list is a part of, then BatchNorm's scale.
  * bn_scale: what the messages' weights were packed with (DpConvW.bn_scale_x for DP_PREC_F16X3).  Deterministic (one thread per node and channel). */
-int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int32_t* scat_ptr, const int32_t* deg_ptr, int32_t d_out,
+int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int32_t* scat_ptr, int32_t max_scatter, const int32_t* deg_ptr, int32_t d_out,
                    const float* bn_scale, float* out, int32_t out_stride, void* stream);
 /* Finishes a DP_EDGES_LIST launch that carried a WHOLE conv (sh0_zero = 0, every edge listed, grouped by scatter node: edges rowptr[n] .. rowend[n] of
  * node n): out[n][c] = base + bn_scale[c] * mean of msg[k][c] over the node's edges + bn_shift[c], base = out[n][c] (accumulate) or resid[n][c] for

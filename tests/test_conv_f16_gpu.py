@@ -418,7 +418,7 @@ def test_s0_only_launch_plus_listed_pairs_equals_the_dense_conv(kind, mode, fold
     _run(s0, keep)
     if not fold:
         deg_ptr = base["ph_ptr"] if mode == "p2l" else base["lig_ptr"]
-        _lib.check(_lib.lib().dp_list_reduce(msg.data_ptr(), lst["rowptr"].data_ptr(), len(NL), base["scat_ptr"].data_ptr(), deg_ptr.data_ptr(), dims["d_out"],
+        _lib.check(_lib.lib().dp_list_reduce(msg.data_ptr(), lst["rowptr"].data_ptr(), len(NL), base["scat_ptr"].data_ptr(), max(NL if mode == "p2l" else NP), deg_ptr.data_ptr(), dims["d_out"],
                                              lst["bnx"].data_ptr(), out.data_ptr(), dims["d_out"], st), "dp_list_reduce")
         torch.cuda.synchronize()
     got = out.cpu().double()
