@@ -152,9 +152,11 @@ def screen(n_units: int, load_unit, model, args, *, costs: Sequence[int] = None,
         * isolates failures per complex, as the reference's loop does with its try / except and SVD retries (src/inference.py:200-219): a
           `load_unit` exception, a complex over the kernel limits or a sample whose Kabsch alignment fails never ends the run.  A
           Kabsch-flagged complex is re-sampled up to `retries` times with a fresh noise key (the reference re-draws and retries up to five
-          times; a complex that the two-limb fp16 kernels of an fp32 model bring back flagged is first run again with the SAME key on the
-          exact-fp32 kernels - see below - so what reaches the fresh-key retries is flagged in the reference's arithmetic too); what still fails is reported as `on_result(i, None)` (or a None entry of the returned list) and, when the caller passes
-          a list as `failed`, appended to it as (i, reason).
+          times; a complex whose status carries bit 2 - non-finite SCORES, which with the two-limb fp16 kernels of an fp32 model can mean a value
+          beyond fp16's range - is first run again with the SAME key on the exact-fp32 kernels, see below, so what reaches the fresh-key
+          retries is flagged in the reference's arithmetic too; a degenerate Kabsch alignment, bit 0, goes straight to the retries); what still fails
+          is reported as `on_result(i, None)` (or a None entry of the returned list) and, when the caller passes a list as `failed`, appended to
+          it as (i, reason).
 
     Returns (indices owned by this rank in processing order - heaviest first when `costs` is given -, list of pose arrays or None).  Peak host memory: two device batches of
     pose objects, whatever the library size."""
