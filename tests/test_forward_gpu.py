@@ -117,6 +117,29 @@ def test_edge_side_convs_on_the_bf16_pipe_vs_exact_fp32(algo, monkeypatch):
     assert not all(torch.equal(a, b) for a, b in zip(res["1"], res["0"]))        # the switch really selects another kernel
 
 
+def test_normals_convs_split_without_any_listed_pair(monkeypatch):
+    """no atom carries a pharmacophore fingerprint bit: every pair's normals harmonics are e0, the lists are empty (n_xs = 0) and the forced split is
+    the s0-only launches alone - still the oracle's scores"""
+    from diffphore_amd.score_model import TensorProductScoreModel
+    from oracle import sampler as osampler
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", "node")
+    monkeypatch.setenv("DIFFPHORE_XN_SPARSE", "1")
+    gs = _mixed_graphs()
+    for g in gs:
+        g["ligand"].phorefp = torch.zeros_like(g["ligand"].phorefp)
+    sd, om = _model()
+    batch = Batch.from_data_list(gs)
+    osampler.set_time_phore(batch, 0.4, 0.4, 0.4, batch.num_graphs)
+    tr_o, rot_o, tor_o = om(batch)
+    m = TensorProductScoreModel(device="cuda").load_state_dict(sd)
+    tr, rot, tor = m(batch)
+    torch.cuda.synchronize()
+    eng = m._engine
+    assert int(eng.pb.struct.n_xs) == 0 and eng.launch_of(1, 2)[2] == 2 and eng.launch_of(1, 5)[2] == 2
+    errs = dict(h_l4=_rel(eng.ws.t["h_l0"][:, :100], om.debug["h_l4"]), tr=_rel(tr, tr_o), rot=_rel(rot, rot_o), tor=_rel(tor, tor_o))
+    assert all(v < 1e-5 for v in errs.values()), errs
+
+
 @pytest.mark.parametrize("dense_fp", [False, True])
 def test_normals_convs_as_l0_part_plus_listed_pairs(dense_fp, monkeypatch):
     """The two normals convs of a layer (phore_to_lig_norm / lig_to_phore_norm) as their l = 0 part on every pair + the other paths on the listed
