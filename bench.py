@@ -313,7 +313,7 @@ def main():
                 t_idx = i % S_total
                 if t_idx == 0:
                     reset()
-                pb.t.copy_(self.T_dev[t_idx].expand(B, 3))
+                pb.set_time_row(self.T_dev[t_idx])
                 w = eng.ws.struct
                 if prof_idx is None:
                     w.prof_start, w.prof_stop = None, None

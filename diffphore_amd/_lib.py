@@ -13,7 +13,7 @@ c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
-DP_ABI_VERSION = 11
+DP_ABI_VERSION = 12
 
 CONV_L0, CONV_L1, CONV_L2, CONV_L3, CONV_FINAL, CONV_TOR = range(6)
 PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 2, 3
@@ -100,7 +100,7 @@ def _declare(L):
     L.dp_pack_conv_weights.restype = C.c_int
     L.dp_list_reduce.argtypes = [VOIDP, VOIDP, c_i32, VOIDP, c_i32, VOIDP, c_i32, VOIDP, VOIDP, c_i32, VOIDP]
     L.dp_list_reduce.restype = C.c_int
-    L.dp_list_finish.argtypes = [VOIDP, VOIDP, VOIDP, c_i32, c_i32, VOIDP, VOIDP, VOIDP, c_i32, c_i32, VOIDP, c_i32, c_i32, VOIDP]
+    L.dp_list_finish.argtypes = [VOIDP, VOIDP, VOIDP, c_i32, c_i32, VOIDP, VOIDP, VOIDP, c_i32, c_i32, VOIDP, c_i32, c_i32, c_i32, VOIDP]
     L.dp_list_finish.restype = C.c_int
     L.dp_tp_conv_node.argtypes = [C.POINTER(DpConvArgs), VOIDP]
     L.dp_tp_conv_node_fused.argtypes = [C.POINTER(DpConvArgs), c_i32, VOIDP]

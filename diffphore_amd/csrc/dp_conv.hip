@@ -32,15 +32,17 @@ __global__ __launch_bounds__(256) void list_reduce_kernel(const float* __restric
 }
 
 // finishes a DP_EDGES_LIST launch that carried a WHOLE conv (every edge of every node listed, grouped by scatter node): scatter mean over the node's
-// own edges, BatchNorm affine, residual / accumulate - what conv_epilogue does for the CSR kernel.  One thread per (node, channel).
+// own edges, BatchNorm affine, residual / accumulate - what conv_epilogue does for the CSR kernel.  One thread per (node, channel).  The edge rows of
+// the first pose's nodes start at 0 (rowptr is global), so "node n mod bcast_nodes" addresses them directly.
 __global__ __launch_bounds__(256) void list_finish_kernel(const float* __restrict__ msg, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
                                                           int n_nodes, int d_out, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
                                                           const float* __restrict__ resid, int resid_stride, int resid_width, float* __restrict__ out,
-                                                          int out_stride, int accumulate) {
+                                                          int out_stride, int accumulate, int bcast_nodes) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_nodes * d_out) return;
   const int n = i / d_out, c = i - n * d_out;
-  const int k0 = rowptr[n], k1 = rowend[n];
+  const int nm = bcast_nodes > 0 ? n % bcast_nodes : n;      // (one pharmacophore's conv for every pose that carries it: DpBatch.ph_shared)
+  const int k0 = rowptr[nm], k1 = rowend[nm];
   float s = 0.f;
   for (int k = k0; k < k1; ++k) s += msg[(size_t)k * d_out + c];
   float v = s / (float)(k1 - k0 > 1 ? k1 - k0 : 1);
@@ -56,11 +58,12 @@ extern "C" {
 int dp_abi_version(void) { return DP_ABI_VERSION; }
 
 int dp_list_finish(const float* msg, const int32_t* rowptr, const int32_t* rowend, int32_t n_nodes, int32_t d_out, const float* bn_scale, const float* bn_shift,
-                   const float* resid, int32_t resid_stride, int32_t resid_width, float* out, int32_t out_stride, int32_t accumulate, void* stream) {
-  if (!msg || !rowptr || !rowend || n_nodes <= 0 || d_out <= 0 || !bn_scale || !bn_shift || !out || out_stride < d_out) return DP_E_BADARG;
+                   const float* resid, int32_t resid_stride, int32_t resid_width, float* out, int32_t out_stride, int32_t accumulate, int32_t bcast_nodes,
+                   void* stream) {
+  if (!msg || !rowptr || !rowend || n_nodes <= 0 || d_out <= 0 || !bn_scale || !bn_shift || !out || out_stride < d_out || bcast_nodes < 0) return DP_E_BADARG;
   const long long total = (long long)n_nodes * d_out;
   hipLaunchKernelGGL(dp::list_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, msg, rowptr, rowend, n_nodes, d_out, bn_scale,
-                     bn_shift, resid, resid_stride, resid_width, out, out_stride, accumulate);
+                     bn_shift, resid, resid_stride, resid_width, out, out_stride, accumulate, bcast_nodes);
   return (int)hipGetLastError();
 }
 

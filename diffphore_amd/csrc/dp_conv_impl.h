@@ -929,7 +929,11 @@ template <int KIND, int TILE> constexpr bool tile_l0_only() {
 }
 
 // EMIT (DP_EDGES_LIST): the staged messages are written to `emit` (the wave's first row of msg_out; emit_rows rows exist) instead of being summed
-template <int KIND, int NS, int TILE, bool FULL = false, bool F16 = false, bool EMIT = false, bool SKIPL0 = false>
+// PH (EMIT only): -1 = every tile; 0 / 1 = this workgroup runs the tiles of accumulation phase 0 / 1 only (DpConvArgs.phase_split of a list launch:
+// two workgroups per 128-edge chunk, each emits its phase's output channels - the phases share nothing but the operands)
+template <int KIND, int PH> constexpr int tile_begin() { return PH == 1 ? n_tiles_phase<KIND>(0) : 0; }
+template <int KIND, int PH> constexpr int tile_end() { return PH == 0 ? n_tiles_phase<KIND>(0) : Geo<KIND>::NT; }
+template <int KIND, int NS, int TILE, bool FULL = false, bool F16 = false, bool EMIT = false, bool SKIPL0 = false, int PH = -1>
 struct StageB {
   static __device__ __forceinline__ void run(gptrq w2p, int wave, int lane, vu4* s_w, const HidB<KIND, NS>& hb,
                                              const float (&xr)[Spec<KIND>::D_IN / 2], const float (&sh)[Spec<KIND>::SH_DIM],
@@ -939,8 +943,10 @@ struct StageB {
     constexpr int NT0 = n_tiles_phase<KIND>(0);
     constexpr int NQ = TILE_QUADS<KIND, NS>;
     constexpr int R = RING<NS>;
-    if constexpr (TILE < G::NT) {
-      if constexpr (TILE == NT0 && NT0 > 0) {      // phase boundary: scalar outputs done -> stage, reduce, restart accumulators
+    constexpr int TE = tile_end<KIND, PH>();
+    static_assert(PH < 0 || EMIT, "the phase split exists for list launches only");
+    if constexpr (TILE < TE) {
+      if constexpr (TILE == NT0 && NT0 > 0 && PH < 0) {      // phase boundary: scalar outputs done -> stage, reduce, restart accumulators
         PROF_MARK(3);
         stage_phase<KIND, 0, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(0) / 2>{});
         const auto chan0 = [](int c) { return kChanLut<KIND, 0>.v[c]; };
@@ -959,7 +965,7 @@ struct StageB {
         for (int i = 0; i < NACC<KIND>; ++i) acc[i] = 0.f;
         PROF_MARK(4);
       }
-      if constexpr (TILE + R - 1 < G::NT) {        // slot (TILE-1)%R was released by the barrier that ended stage TILE-1
+      if constexpr (TILE + R - 1 < TE) {        // slot (TILE-1)%R was released by the barrier that ended stage TILE-1
 #if DP_ABLATE == 5
         gptrq src = w2p;                                        // every tile from the same 8-12 KB: L1/L2-hot source
 #else
@@ -1003,17 +1009,17 @@ struct StageB {
       contract_tile<KIND, TILE>(D, xr, sh, M, acc, std::make_integer_sequence<int, 16>{});
 #endif
       }
-      if constexpr (TILE + 1 < G::NT) {
+      if constexpr (TILE + 1 < TE) {
         // tile TILE+1 must have landed; tiles TILE+2 .. min(TILE+R-1, NT-1) may stay in flight across the barrier
-        constexpr int last = (TILE + R - 1 < G::NT - 1) ? (TILE + R - 1) : (G::NT - 1);
+        constexpr int last = (TILE + R - 1 < TE - 1) ? (TILE + R - 1) : (TE - 1);
         wait_vmcnt<(last - (TILE + 1)) * PIECES<KIND, NS>>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's ds_reads of the slot about to be recycled are done
         __builtin_amdgcn_s_barrier();
       }
       __builtin_amdgcn_sched_barrier(0);
-      StageB<KIND, NS, TILE + 1, FULL, F16, EMIT, SKIPL0>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local, emit, emit_rows);
+      StageB<KIND, NS, TILE + 1, FULL, F16, EMIT, SKIPL0, PH>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, scat_local, emit, emit_rows);
     } else {
-      constexpr int PHL = n_tiles_phase<KIND>(1) > 0 ? 1 : 0;
+      constexpr int PHL = PH == 0 ? 0 : (n_tiles_phase<KIND>(1) > 0 ? 1 : 0);
       PROF_MARK(5);
       if constexpr (PHL == 1 && n_tiles_phase<KIND>(1) < 2 && n_tiles_phase<KIND>(0) > 0) __syncthreads();   // wave 0 may still be merging phase 0
       stage_phase<KIND, PHL, 0>(acc, row, half, std::make_integer_sequence<int, n_acc_phase<KIND>(PHL) / 2>{});
@@ -1133,7 +1139,7 @@ struct StageP {
 #define DP_PIPE_NS1 1      // 0: the one-product kernel on StageB like the split kernels (A/B builds)
 #endif
 
-template <int KIND, int NS, bool FULL = false, bool F16 = false, bool EMIT = false, bool SKIPL0 = false>
+template <int KIND, int NS, bool FULL = false, bool F16 = false, bool EMIT = false, bool SKIPL0 = false, bool PSPLIT = false>
 __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArgs a) {
   using S = Spec<KIND>;
   using G = Geo<KIND>;
@@ -1146,12 +1152,15 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
   __shared__ int s_pnode[WAVES_B];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ecol = lane & 31, half = lane >> 5;
-  const WgRange r = wg_range(a);
+  static_assert(!PSPLIT || (EMIT && NS == 2), "phase split: list launches of the two-limb kernels");
+  const WgRange r = wg_range(a, PSPLIT ? (int)(blockIdx.x >> 1) : -1);
   if (r.n_loc <= 0) return;
   for (int i = tid; i < r.n_loc * S::D_OUT; i += WAVES_B * 64) s_acc[i] = 0.f;
   gptrq w2p = (gptrq)a.w2p;
 
   PROF_MARK(-1);
+  auto chunks = [&]<int PH>() {
+  constexpr int TB = tile_begin<KIND, PH>(), TE = tile_end<KIND, PH>();
   for (int kc = r.k_begin; kc < r.k_end; kc += CHUNK_B) {
     const EdgeRef e = decode_edge(a, r, kc + wave * 32 + ecol);
     float xr[S::D_IN / 2], sh[S::SH_DIM], M[9];
@@ -1168,9 +1177,9 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
     __syncthreads();                              // previous chunk: partial sums merged, s_msg rows and the ring are free
     PROF_MARK(1);
     constexpr bool PIPED = NS == 1 && DP_PIPE_NS1 != 0 && DP_ABLATE == 0;     // StageP: tile t+1's MFMAs under tile t's contraction
-    constexpr int NPRO = (R - (PIPED ? 0 : 1) < G::NT) ? (R - (PIPED ? 0 : 1)) : G::NT;
+    constexpr int NPRO = (R - (PIPED ? 0 : 1) < TE - TB) ? (R - (PIPED ? 0 : 1)) : TE - TB;
 #pragma unroll
-    for (int t = 0; t < NPRO; ++t) dma_tile<KIND, NS>(w2p + (size_t)t * NQ, s_w + t * NQ, wave, lane);
+    for (int t = 0; t < NPRO; ++t) dma_tile<KIND, NS>(w2p + (size_t)(TB + t) * NQ, s_w + ((TB + t) % R) * NQ, wave, lane);
     float* row = s_msg + (size_t)(wave * 32 + ecol) * MSG_LD_B<KIND>;
     float acc[NACC<KIND>];
 #pragma unroll
@@ -1196,11 +1205,18 @@ __global__ __launch_bounds__(WAVES_B * 64, 2) void tp_conv_bf16_kernel(DpConvArg
         StageP<KIND, 0, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local, D0);
     } else if constexpr (EMIT) {
       const int k0 = kc + wave * 32, left = r.k_end - k0;
-      StageB<KIND, NS, 0, FULL, F16, true, SKIPL0>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local,
-                                                        a.msg_out + (size_t)k0 * S::D_OUT, left < 0 ? 0 : (left > 32 ? 32 : left));
+      StageB<KIND, NS, TB, FULL, F16, true, SKIPL0, PH>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local,
+                                                             a.msg_out + (size_t)k0 * S::D_OUT, left < 0 ? 0 : (left > 32 ? 32 : left));
     } else {
       StageB<KIND, NS, 0, FULL, F16>::run(w2p, wave, lane, s_w, hb, xr, sh, M, acc, row, half, s_msg, s_pnode, s_acc, e.scat_local);
     }
+  }
+  };
+  if constexpr (PSPLIT) {
+    if (blockIdx.x & 1) chunks.template operator()<1>();
+    else chunks.template operator()<0>();
+  } else {
+    chunks.template operator()<-1>();
   }
   if constexpr (EMIT) return;
   __syncthreads();
@@ -1215,6 +1231,12 @@ template <int KIND> int launch(const DpConvArgs& a_in, hipStream_t st) {
       if (a.precision != DP_PREC_F16X3) return DP_E_UNSUPPORTED;
       if (a.n_list <= 0) return DP_OK;
       const dim3 grid_l((unsigned)((a.n_list + CHUNK_B - 1) / CHUNK_B));
+      // phase_split (whole convs only): two workgroups per chunk, the tiles of one accumulation phase each - half the latency of a launch that cannot
+      // fill the chip anyway (a small batch's phore-phore conv sits on the critical path of its layer)
+      if (a.phase_split && !a.sh0_zero && n_tiles_phase<KIND>(0) > 0 && n_tiles_phase<KIND>(1) > 0) {
+        hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2, false, true, true, false, true>), dim3(grid_l.x * 2), dim3(WAVES_B * 64), 0, st, a);
+        return (int)hipGetLastError();
+      }
       // sh0_zero: the tiles whose rows all belong to l = 0 paths multiply by a zero and are skipped (their own instantiation)
       if (a.sh0_zero) hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2, false, true, true, true>), grid_l, dim3(WAVES_B * 64), 0, st, a);
       else hipLaunchKernelGGL((tp_conv_bf16_kernel<KIND, 2, false, true, true, false>), grid_l, dim3(WAVES_B * 64), 0, st, a);

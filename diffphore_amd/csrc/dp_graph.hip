@@ -30,34 +30,48 @@ constexpr int LIG_DIMS[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 
 // time parameters per pose: sinusoidal sigma embedding, sigmas, SO(3)/torus score norms
 //   diffusion_utils.py:16-20,82-93 ; so3.py:92-96 ; torus.py:82-86 ; score_model_phore.py:333,352,376
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void time_params_kernel(int B, const float* __restrict__ t, DpWeights w, float* __restrict__ tp) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// 32 lanes per pose, one output each (the 20 double-precision sin / cos of the embedding had been one thread's serial chain at the very start of a step)
+// t_row (DpWork.t_row): one row of times for every pose - read instead of t[p], and written there (lanes 24..26)
+__global__ __launch_bounds__(256) void time_params_kernel(int B, float* __restrict__ t, const float* __restrict__ t_row, DpWeights w, float* __restrict__ tp) {
+  const int p = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
   if (p >= B) return;
-  const float t_tr = t[p * 3 + 0], t_rot = t[p * 3 + 1], t_tor = t[p * 3 + 2];
+  const float* ts = t_row ? t_row : t + (size_t)p * 3;
+  const float t_tr = ts[0], t_rot = ts[1], t_tor = ts[2];
+  if (t_row && j >= 24 && j < 27) t[(size_t)p * 3 + (j - 24)] = ts[j - 24];
   float* o = tp + (size_t)p * TP_STRIDE;
-  const float st = __fmul_rn(w.emb_scale, t_tr);                 // embedding_scale * x      (float32)
-#pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    const float arg = __fmul_rn(st, w.emb_freq[k]);              // timesteps[:,None] * emb[None,:]
-    o[k] = (float)sin((double)arg);
-    o[10 + k] = (float)cos((double)arg);
-  }
-  const float s_tr = powf(w.tr_smin, 1.f - t_tr) * powf(w.tr_smax, t_tr);
-  const float s_rot = powf(w.rot_smin, 1.f - t_rot) * powf(w.rot_smax, t_rot);
-  const float s_tor = powf(w.tor_smin, 1.f - t_tor) * powf(w.tor_smax, t_tor);
-  o[20] = s_tr; o[21] = s_rot; o[22] = s_tor;
-  {  // so3.score_norm: nearest index on a log10 grid of 1000 eps in [0.01, 2]
+  if (j < 20) {
+    const float st = __fmul_rn(w.emb_scale, t_tr);                 // embedding_scale * x      (float32)
+    const float arg = __fmul_rn(st, w.emb_freq[j < 10 ? j : j - 10]);      // timesteps[:,None] * emb[None,:]
+    o[j] = j < 10 ? (float)sin((double)arg) : (float)cos((double)arg);
+  } else if (j == 20) {
+    o[20] = powf(w.tr_smin, 1.f - t_tr) * powf(w.tr_smax, t_tr);
+  } else if (j == 21) {
+    const float s_rot = powf(w.rot_smin, 1.f - t_rot) * powf(w.rot_smax, t_rot);
+    o[21] = s_rot;
+    // so3.score_norm: nearest index on a log10 grid of 1000 eps in [0.01, 2]
     const double x = (log10((double)s_rot) - log10(0.01)) / (log10(2.0) - log10(0.01)) * 1000.0;
     int idx = (int)rint(x);
     idx = idx < 0 ? 0 : (idx > 999 ? 999 : idx);
     o[23] = w.so3_table[idx];
-  }
-  {  // torus.score_norm: index on a log grid of 5001 sigma/pi in [3e-3, 2]; clip BEFORE round (torus.py:85)
+  } else if (j == 22) {
+    const float s_tor = powf(w.tor_smin, 1.f - t_tor) * powf(w.tor_smax, t_tor);
+    o[22] = s_tor;
+    // torus.score_norm: index on a log grid of 5001 sigma/pi in [3e-3, 2]; clip BEFORE round (torus.py:85)
     double x = (log((double)s_tor / M_PI) - log(3e-3)) / (log(2.0) - log(3e-3)) * 5000.0;
     x = x < 0.0 ? 0.0 : (x > 5000.0 ? 5000.0 : x);
     const int idx = (int)rint(x);
     o[24] = sqrtf(w.torus_table[idx]);
   }
+}
+
+// the time parameters of one row of times (DpWork.t_row), computed before (DpWork.tp_row), for every pose; the times themselves into DpBatch.t
+__global__ __launch_bounds__(256) void tp_bcast_kernel(int B, float* __restrict__ t, const float* __restrict__ t_row, const float* __restrict__ tp_row,
+                                                       float* __restrict__ tp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * TP_STRIDE) return;
+  const int p = i / TP_STRIDE, j = i - p * TP_STRIDE;
+  if (j < 25) tp[i] = tp_row[j];
+  else if (j < 28) t[(size_t)p * 3 + (j - 25)] = t_row[j - 25];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -572,37 +586,41 @@ __global__ __launch_bounds__(256) void center_edges_kernel(DpBatch b, DpWeights 
 }
 
 // tr / rot heads (get_trtheta_score :340-352)
-__global__ void trrot_head_kernel(int B, DpWeights w, DpWork k, float* __restrict__ tr, float* __restrict__ rot) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per pose: lanes 0..19 hold the hidden units of the translation head, lanes 32..51 those of the rotation head; lanes 0 / 32 add them up in
+// the reference's order (the same arithmetic as one thread per pose, a 20th of its dependent chain)
+__global__ __launch_bounds__(256) void trrot_head_kernel(int B, DpWeights w, DpWork k, float* __restrict__ tr, float* __restrict__ rot) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, hsel = lane >> 5, o = lane & 31;
   if (p >= B) return;
   const float* g = k.gpred + (size_t)p * 12;
   const float* tp = k.tparams + (size_t)p * TP_STRIDE;
-  float v[2][3];
-  for (int c = 0; c < 3; ++c) { v[0][c] = g[c] + g[6 + c]; v[1][c] = g[3 + c] + g[9 + c]; }
-  for (int hsel = 0; hsel < 2; ++hsel) {
-    const DpMlp& m = hsel == 0 ? w.tr_final : w.rot_final;
-    const float nrm = sqrtf(v[hsel][0] * v[hsel][0] + v[hsel][1] * v[hsel][1] + v[hsel][2] * v[hsel][2]);
-    float out = m.b3[0];
-    for (int o = 0; o < NS; ++o) {
-      float s = fmaf(m.w0[o * 21], nrm, m.b0[o]);
-      for (int i = 0; i < NS; ++i) s = fmaf(m.w0[o * 21 + 1 + i], tp[i], s);
-      out = fmaf(m.w3[o], fmaxf(s, 0.f), out);
-    }
-    const float scale = hsel == 0 ? 1.f / tp[20] : tp[23];
+  float v[3];
+  for (int c = 0; c < 3; ++c) v[c] = hsel == 0 ? g[c] + g[6 + c] : g[3 + c] + g[9 + c];
+  const DpMlp& m = hsel == 0 ? w.tr_final : w.rot_final;
+  const float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  float r = 0.f;
+  if (o < NS) {
+    float s = fmaf(m.w0[o * 21], nrm, m.b0[o]);
+    for (int i = 0; i < NS; ++i) s = fmaf(m.w0[o * 21 + 1 + i], tp[i], s);
+    r = fmaxf(s, 0.f);
+  }
+  float out = m.b3[0];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) out = fmaf(m.w3[j], __shfl(r, (lane & 32) + j, 64), out);
+  if (o == 0) {
     float* dst = (hsel == 0 ? tr : rot) + (size_t)p * 3;
     for (int c = 0; c < 3; ++c) {
-      float x = v[hsel][c] / nrm * out;
+      float x = v[c] / nrm * out;
       x = hsel == 0 ? x / tp[20] : x * tp[23];
       dst[c] = x;
     }
-    (void)scale;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // torsion graph (build_bond_conv_graph :409-437, FullTensorProduct(sh, 2e) :276,365-366, edge attrs :368-369)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tor_graph_kernel(DpBatch b, DpWeights w, DpWork k, const float* __restrict__ h_l) {
+// Geometry only (positions of this step): dp_forward runs it beside the last interaction layer, whose output only tor_hb_kernel below needs.
+__global__ __launch_bounds__(256) void tor_graph_kernel(DpBatch b, DpWeights w, DpWork k) {
   __shared__ float s_pos[MAXN_L * 3];
   const int p = blockIdx.x, tid = threadIdx.x;
   const int l0 = b.lig_ptr[p], N = b.lig_ptr[p + 1] - l0;
@@ -629,10 +647,6 @@ __global__ __launch_bounds__(256) void tor_graph_kernel(DpBatch b, DpWeights w, 
     k.t_rowptr[t0 + q] = slot0;
     k.t_rowend[t0 + q] = slot0 + cnt;
     for (int c = cnt; c < TOR_SLOTS; ++c) { k.t_nbr[slot0 + c] = l0; k.t_src[slot0 + c] = -1; }
-    // (h_l[u] + h_l[v])[:20]
-    const float* hu = h_l + (size_t)(l0 + u) * 100;
-    const float* hv = h_l + (size_t)(l0 + v) * 100;
-    for (int c = 0; c < NS; ++c) k.t_hb[(size_t)(t0 + q) * NS + c] = hu[c] + hv[c];
   }
   __syncthreads();
   for (int e = tid; e < T * TOR_SLOTS; e += 256) {
@@ -680,22 +694,38 @@ __global__ __launch_bounds__(256) void tor_graph_kernel(DpBatch b, DpWeights w, 
   }
 }
 
+// the bonds' node attribute of the torsion conv: (h_l[u] + h_l[v])[:20] of the final node features (:368)
+__global__ __launch_bounds__(256) void tor_hb_kernel(DpBatch b, DpWork k, const float* __restrict__ h_l) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.n_tor * NS) return;
+  const int q = i / NS, c = i - q * NS;
+  k.t_hb[i] = h_l[(size_t)b.tor_u[q] * 100 + c] + h_l[(size_t)b.tor_v[q] * 100 + c];
+}
+
 // tor_final_layer: Linear(40,20,no bias), Tanh, Linear(20,1,no bias); * sqrt(torus.score_norm(sigma))  (:286-291,372-377)
-__global__ void tor_head_kernel(DpBatch b, DpWeights w, DpWork k, float* __restrict__ tor) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= b.n_tor) return;
-  // pose of this bond: binary search in tor_ptr
-  int lo = 0, hi = b.B;
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.tor_ptr[mid] <= q) lo = mid; else hi = mid; }
-  const float* x = k.t_q + (size_t)q * 40;
-  float out = 0.f;
-  for (int o = 0; o < NS; ++o) {
-    const kptr w0 = K(w.tor_w0), w3 = K(w.tor_w3);
+// 32 lanes per bond: lane o < 20 holds hidden unit o (its 40-term dot product in the reference's order, tanh), lane 0 adds the 20 terms up in order -
+// the same arithmetic as one thread per bond, a 20th of its dependent chain (the launch ends the torsion side of a step: 24 -> 8 us at 320 bonds)
+__global__ __launch_bounds__(256) void tor_head_kernel(DpBatch b, DpWeights w, DpWork k, float* __restrict__ tor) {
+  const int q = blockIdx.x * 8 + (threadIdx.x >> 5), o = threadIdx.x & 31;
+  const bool live = q < b.n_tor;
+  float t = 0.f;
+  if (live && o < NS) {
+    const float* x = k.t_q + (size_t)q * 40;
+    const float* w0 = w.tor_w0 + o * 40;
     float s = 0.f;
-    for (int i = 0; i < 40; ++i) s = fmaf(w0[o * 40 + i], x[i], s);
-    out = fmaf(w3[o], tanhf(s), out);
+#pragma unroll
+    for (int i = 0; i < 40; ++i) s = fmaf(w0[i], x[i], s);
+    t = tanhf(s);
   }
-  tor[q] = out * k.tparams[(size_t)lo * TP_STRIDE + 24];
+  float out = 0.f;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) out = fmaf(w.tor_w3[j], __shfl(t, (threadIdx.x & 32) + j, 64), out);
+  if (live && o == 0) {
+    // pose of this bond: binary search in tor_ptr
+    int lo = 0, hi = b.B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.tor_ptr[mid] <= q) lo = mid; else hi = mid; }
+    tor[q] = out * k.tparams[(size_t)lo * TP_STRIDE + 24];
+  }
 }
 
 }  // namespace dp
@@ -711,6 +741,13 @@ static int dp_check_batch(const DpBatch* b) {
   if (!b || b->B <= 0) return DP_E_BADARG;
   if (b->max_nl > dp::MAXN_L || b->max_np > dp::MAXN_P || b->max_t > dp::MAXT) return DP_E_TOOLARGE;
   return DP_OK;
+}
+
+// library-internal (dp_sample): the time parameters of S rows of times [S,3] into table [S,32] - time_params_kernel with a schedule's rows as its "poses"
+int dpg_time_table(const float* t, int32_t S, const DpWeights* w, float* table, void* stream) {
+  if (!t || S <= 0 || !w || !table) return DP_E_BADARG;
+  hipLaunchKernelGGL(dp::time_params_kernel, dim3((S + 7) / 8), dim3(256), 0, (hipStream_t)stream, S, const_cast<float*>(t), (const float*)nullptr, *w, table);
+  return (int)hipGetLastError();
 }
 
 int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream) {
@@ -738,6 +775,12 @@ int dp_prepare(const DpBatch* b, const DpWeights* w, DpWork* k, void* stream) {
 static int node_path_split_auto(int B, int slices, bool f16_avail) { return (long long)B * slices <= (f16_avail ? 48 : 256) ? 1 : 0; }
 #ifndef DP_F16_CSPLIT_MAX_WG
 #define DP_F16_CSPLIT_MAX_WG 384
+#endif
+#ifndef DP_PP_PSPLIT_MAX_CHUNKS
+#define DP_PP_PSPLIT_MAX_CHUNKS 64   // phore-phore conv as a list of at most this many 128-edge chunks: phase split (DpConvArgs.phase_split of a list launch)
+#endif
+#ifndef DP_PP_BESIDE_MAX_WG
+#define DP_PP_BESIDE_MAX_WG 640      // third stream for the phore-phore conv while the layer's launches together have at most this many workgroups
 #endif
 static int node_f16_conv_split_auto(int B, int slices16) { return (long long)B * slices16 * 2 <= DP_F16_CSPLIT_MAX_WG ? 1 : 0; }
 // which formulation the convs of a forward take (shared by dp_forward and dp_forward_launch_of)
@@ -845,7 +888,10 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   // error exit: never leave the aux stream forked (eager: later work on `st` must stay ordered after it; capture: an unjoined stream
   // turns the caller's hipStreamEndCapture into an error that masks `rc`)
   auto fail = [&](int rc_) { if (aux_forked) join(); return rc_; };
-  hipLaunchKernelGGL(dp::time_params_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, b->t, *w, k->tparams);
+  if (k->t_row && k->tp_row)
+    hipLaunchKernelGGL(dp::tp_bcast_kernel, dim3((B * dp::TP_STRIDE + 255) / 256), dim3(256), 0, st, B, const_cast<float*>(b->t), k->t_row, k->tp_row, k->tparams);
+  else
+    hipLaunchKernelGGL(dp::time_params_kernel, dim3((B + 7) / 8), dim3(256), 0, st, B, const_cast<float*>(b->t), k->t_row, *w, k->tparams);
   // the three graph / embedding kernels only share their inputs (positions, time parameters): the ligand radius graph runs on the second
   // stream beside the node embeddings and the cross edges (each is one workgroup per pose and latency-bound on its own)
   if (aux) fork();
@@ -979,6 +1025,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
     return r;
   };
+  const bool heads_early = aux != nullptr && k->aux_mode != 1;
   for (int l = 0; l < 4; ++l) {
     const float* hl = k->h_l[cur];
     const float* hp = k->h_p[cur];
@@ -995,6 +1042,13 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     const bool two = aux != nullptr && l != 3 && k->aux_mode != 1;
     hipStream_t sp_ = two ? aux : st;           // stream of the phore-side convs
     if (two) fork();
+    // the last layer has no pharmacophore side: the second stream builds the graphs of the two score heads meanwhile - centre edges and torsion-bond
+    // neighbourhoods are functions of this step's positions and times only (35 us off the tail of a step, at any batch size)
+    if (heads_early && l == 3) {
+      fork();
+      hipLaunchKernelGGL(dp::center_edges_kernel, dim3(B), dim3(256), 0, aux, *b, *w, *k);
+      if (b->n_tor > 0) hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, aux, *b, *w, *k);
+    }
     xs_early[0] = xs_early[1] = false;
     if ((xs_async || xs_place == 1) && (xs_lig || (xs_ph && l != 3))) {
       // the layer's inputs are complete on st here (ev_fork: recorded by fork() when the layer has two sides)
@@ -1090,9 +1144,11 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       // ... while the three launches of a layer together leave workgroup slots free (256 CUs x 2): ms per step with / without, 30 atoms / 32 nodes,
       // graph + streams: 1 pose 0.439 / 0.473, 8: 0.476 / 0.499, 20: 0.570 / 0.535, 40: 0.678 / 0.652 - from ~18 poses on the chip is full of (long)
       // workgroups and one more concurrent launch only stretches the others
-      const long long wg_layer = (long long)B * slices_x6 + (long long)B * ((b->max_np + nb - 1) / nb) * 2 * 2 + (long long)B * ((b->max_nl + nb - 1) / nb) * 2 * 3;
+      const bool pp_list_ = edge_x6 && w->ph_conv[l].w2x && w->ph_conv[l].bn_scale_x && k->pp_msg != nullptr && dp_pp_as_list(b);
+      const long long wg_pp = pp_list_ ? (b->n_pp + 127) / 128 : (long long)B * slices_x6;
+      const long long wg_layer = wg_pp + (long long)B * ((b->max_np + nb - 1) / nb) * 2 * 2 + (long long)B * ((b->max_nl + nb - 1) / nb) * 2 * 3;
       const bool pp_beside = two && k->aux2_stream && k->ev_join2 && k->pp_tmp && node_side && fuse && !xs_ph && !xs_lig && f16_ph && f16_csplit(slices_lp) &&
-                             k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)2 * b->n_ph * 100 <= DP_CONV_PART_FLOATS / 2 && wg_layer <= 384;
+                             k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)2 * b->n_ph * 100 <= DP_CONV_PART_FLOATS / 2 && wg_layer <= DP_PP_BESIDE_MAX_WG;
       hipStream_t s3 = pp_beside ? (hipStream_t)k->aux2_stream : sp_;
       if (pp_beside) note(hipStreamWaitEvent(s3, (hipEvent_t)k->ev_fork, 0));        // (the layer's fork event, recorded on the launch stream above)
       {
@@ -1104,10 +1160,17 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         const bool x6 = edge_x6 && w->ph_conv[l].w2x && w->ph_conv[l].bn_scale_x;
         if (x6) { c.precision = DP_PREC_F16X3; c.w2p = w->ph_conv[l].w2x; c.bn_scale = w->ph_conv[l].bn_scale_x; c.slices = slices_x6; c.phase_split = 0; }
         if (pp_beside) { c.out = k->pp_tmp; c.out_stride = 100; }
-        if (x6 && k->pp_msg != nullptr && dp_pp_as_list(b)) {
+        // one pharmacophore for the whole batch at one diffusion time (DpBatch.ph_shared, DpWork.t_uniform): the layer-0 conv reads h_p^0 (type / feature
+        // embeddings + the time embedding), e_pp and sh_pp only (:691-693 at l = 0) - the same numbers for every pose.  Pose 0's edges go through the list
+        // kernel, dp_list_finish hands node j's mean to node j of every pose (the residual pad(h_p) is read per pose: equal too, no special case).
+        const bool ph_once = l == 0 && b->ph_shared != 0 && (k->t_uniform != 0 || k->t_row != nullptr) && k->ph_share != 2 && B > 1 && x6 && k->pp_msg != nullptr &&
+                             b->n_pp % B == 0 && b->n_ph % B == 0;
+        if (x6 && k->pp_msg != nullptr && (ph_once || dp_pp_as_list(b))) {
           // small pharmacophores: the batch's phore-phore edges as ONE list in full 128-edge chunks (dp_pp_as_list), then mean / BatchNorm / residual
           DpConvArgs cl = c;
-          cl.mode = DP_EDGES_LIST; cl.n_list = b->n_pp; cl.sh0_zero = 0; cl.msg_out = k->pp_msg; cl.feat_idx = nullptr;
+          cl.mode = DP_EDGES_LIST; cl.n_list = ph_once ? b->n_pp / B : b->n_pp; cl.sh0_zero = 0; cl.msg_out = k->pp_msg; cl.feat_idx = nullptr;
+          // a list that cannot fill the chip: two workgroups per chunk, one accumulation phase each (the launch heads the pharmacophore side's chain)
+          cl.phase_split = (cl.n_list + 127) / 128 <= DP_PP_PSPLIT_MAX_CHUNKS ? 1 : 0;
           const bool prof = k->prof_start && k->prof_stop && k->prof_layer == l && k->prof_conv == 3;
           if (prof) note(hipEventRecord((hipEvent_t)k->prof_start, s3));
           if (ev_all(l, 3, 0)) note(hipEventRecord(ev_all(l, 3, 0), s3));
@@ -1115,7 +1178,7 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
           // (its mean / BatchNorm affine as a launch of its own: folded into the epilogue of the layer's s0-only lig_to_phore_norm launch - one launch
           //  and one pass over hp2 less - the step was 3 % SLOWER, 164.4 k vs 169.3 k: the dependent loads stand at the end of a short kernel)
           if (!rc) rc = dp_list_finish(k->pp_msg, b->pp_rowptr, b->pp_rowend, b->n_ph, D[l + 1], c.bn_scale, c.bn_shift, c.resid, c.resid_stride, c.resid_width,
-                                       c.out, c.out_stride, 0, s3);
+                                       c.out, c.out_stride, 0, ph_once ? b->n_ph / B : 0, s3);
           if (ev_all(l, 3, 1)) note(hipEventRecord(ev_all(l, 3, 1), s3));
           if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s3));
           if (rc) return fail(rc);
@@ -1147,14 +1210,14 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
           if ((rc = (xs_ph && nv) ? timed_xs(phc[1], l, 5, false, hl, hp, sp_) : timed(phc[nv], l, 4 + nv, sp_))) return fail(rc);
       }
     }
-    if (two) join();
+    if (two || (heads_early && l == 3)) join();
     cur ^= 1;
   }
   const float* hl = k->h_l[cur];
   // translation / rotation head on the launch stream, torsion head beside it when a second stream was given
   const bool tor_aux = aux != nullptr && b->n_tor > 0 && k->aux_mode != 1;
   if (tor_aux) fork();
-  hipLaunchKernelGGL(dp::center_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  if (!heads_early) hipLaunchKernelGGL(dp::center_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
   {
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
@@ -1165,11 +1228,12 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.out = k->gpred; c.out_stride = 12;
     if ((rc = dp_tp_conv(&c, st))) return fail(rc);
   }
-  hipLaunchKernelGGL(dp::trrot_head_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, *w, *k, tr, rot);
+  hipLaunchKernelGGL(dp::trrot_head_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, *w, *k, tr, rot);
   // torsion head
   if (b->n_tor > 0) {
     hipStream_t s2 = tor_aux ? aux : st;
-    hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, s2, *b, *w, *k, hl);
+    if (!heads_early) hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, s2, *b, *w, *k);
+    hipLaunchKernelGGL(dp::tor_hb_kernel, dim3((b->n_tor * dp::NS + 255) / 256), dim3(256), 0, s2, *b, *k, hl);
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
     c.kind = DP_CONV_TOR; c.mode = DP_EDGES_CSR; c.B = B; c.scat_ptr = b->tor_ptr; c.precision = prec_edge; c.max_scatter = b->max_t > 0 ? b->max_t : 1;
@@ -1184,9 +1248,12 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       c.precision = DP_PREC_F16X3; c.w2p = w->tor_conv.w2x; c.bn_scale = w->tor_conv.bn_scale_x;
       c.slices = 1;
       while ((b->max_t + c.slices - 1) / c.slices > dp_conv_max_nodes(DP_PREC_BF16X6)) ++c.slices;
+      // a batch that cannot fill the chip: fewer torsion bonds per workgroup (a bond has up to 32 edge slots; one 128-edge chunk per workgroup instead
+      // of one after the other - the launch sits on the step's critical path between tor_graph and tor_head)
+      while (B * c.slices < 512 && c.slices < 8 && c.slices < b->max_t) ++c.slices;
     }
     if ((rc = dp_tp_conv(&c, s2))) return fail(rc);
-    hipLaunchKernelGGL(dp::tor_head_kernel, dim3((b->n_tor + 63) / 64), dim3(64), 0, s2, *b, *w, *k, tor);
+    hipLaunchKernelGGL(dp::tor_head_kernel, dim3((b->n_tor + 7) / 8), dim3(256), 0, s2, *b, *w, *k, tor);
     if (tor_aux) join();
   }
   return ev_rc ? ev_rc : (int)hipGetLastError();

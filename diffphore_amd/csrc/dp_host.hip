@@ -74,8 +74,10 @@ static size_t carve(const DpBatch* b, void* base, DpWork* k, float** tr, float**
   w.status = c.take<int32_t>(B);
   w.z_noise = c.take<float>(B * 6 + nt);
   w.conv_part = c.take<float>(DP_CONV_PART_FLOATS);
+  w.tp_table = c.take<float>((size_t)DP_TP_TABLE_STEPS * dp::TP_STRIDE);
   w.pp_tmp = c.take<float>(np * 100);
-  w.pp_msg = dp_pp_as_list(b) ? c.take<float>(npp * 100) : nullptr;
+  // (a batch on one pharmacophore, DpBatch.ph_shared: room for one pose's edges is enough for the layer-0 conv that runs once)
+  w.pp_msg = dp_pp_as_list(b) ? c.take<float>(npp * 100) : (b->ph_shared && B > 0 ? c.take<float>((npp / B + 1) * 100) : nullptr);
   w.xs_msg = c.take<float>((size_t)2 * (b->n_xs > 0 ? (size_t)b->n_xs : 0) * 100);
   float* tr_ = c.take<float>(B * 3);
   float* rot_ = c.take<float>(B * 3);
@@ -170,11 +172,6 @@ static int list_segments(int precision, DpSegment* out, int cap, int64_t* total)
   s.add("emb_freq", 10);
   if (total) *total = s.off;
   return s.n;
-}
-
-__global__ void set_time_kernel(int B, const float* __restrict__ t3, float* __restrict__ t) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B * 3) t[i] = t3[i % 3];
 }
 
 }  // namespace dph
@@ -340,13 +337,22 @@ int dp_pack_bn(int32_t kind, const float* running_mean, const float* running_var
 // ---------------------------------------------------------------------------------------------------------------------------
 // whole reverse-diffusion loop
 // ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int dpg_time_table(const float* t, int32_t S, const DpWeights* w, float* table, void* stream);      // dp_graph.hip
 int dp_sample(const DpBatch* b, const DpWeights* w, DpWork* k, const DpSchedule* s, float* tr, float* rot, float* tor, void* stream) {
   if (!b || !w || !k || !s || s->steps <= 0 || !s->sp || !s->t || !tr || !rot) return DP_E_BADARG;
   if (s->noise_mode != DP_NOISE_TABLES && s->noise_mode != DP_NOISE_SEED) return DP_E_BADARG;
-  hipStream_t st = (hipStream_t)stream;
+  DpWork ku = *k;
+  ku.t_uniform = 1;                 // every pose gets the step's times (set_time_phore, sampling.py:218) ...
+  // the schedule is known: the time parameters of all its steps in one launch, a step then only hands its row to the poses
+  const bool tabled = k->tp_table != nullptr && s->steps <= DP_TP_TABLE_STEPS;
+  if (tabled) {
+    const int rt = dpg_time_table(s->t, s->steps, w, k->tp_table, stream);
+    if (rt) return rt;
+  }
   for (int i = 0; i < s->steps; ++i) {
     const DpStepParams& sp = s->sp[i];
-    hipLaunchKernelGGL(dph::set_time_kernel, dim3((b->B * 3 + 255) / 256), dim3(256), 0, st, b->B, s->t + 3 * i, const_cast<float*>(b->t));
+    ku.t_row = s->t + 3 * i;        // ... by the first kernel of dp_forward (DpWork.t_row) instead of a launch of its own
+    ku.tp_row = tabled ? k->tp_table + (size_t)i * dp::TP_STRIDE : nullptr;
     // a noise table is consumed only where its coefficient is non-zero (ODE, no_random, no_final_step_noise: sampling.py:226-244)
     const float *z_tr, *z_rot, *z_tor;
     if (s->noise_mode == DP_NOISE_SEED) {
@@ -362,7 +368,7 @@ int dp_sample(const DpBatch* b, const DpWeights* w, DpWork* k, const DpSchedule*
       z_rot = (s->z_rot && sp.rot_c2 != 0.f) ? s->z_rot + (size_t)i * b->B * 3 : nullptr;
       z_tor = (s->z_tor && sp.tor_c2 != 0.f && !sp.no_torsion) ? s->z_tor + (size_t)i * b->n_tor : nullptr;
     }
-    const int rc = dp_sample_step(b, w, k, &sp, tr, rot, tor, z_tr, z_rot, z_tor, stream);
+    const int rc = dp_sample_step(b, w, &ku, &sp, tr, rot, tor, z_tr, z_rot, z_tor, stream);
     if (rc) return rc;
   }
   return (int)hipGetLastError();

@@ -19,7 +19,19 @@ namespace dpk {
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct Sizes { int64_t n_lig, n_ph, n_bond, n_tor, n_pp, n_x, ll_cap, n_llp, n_mask, n_xs; int32_t max_nl, max_np, max_t; };
+struct Sizes { int64_t n_lig, n_ph, n_bond, n_tor, n_pp, n_x, ll_cap, n_llp, n_mask, n_xs; int32_t max_nl, max_np, max_t, ph_shared; };
+
+// the pharmacophore of view b is the one of view a: same nodes (features, positions, normals, types) and the same edges in the same order
+static bool same_phore(const DpGraphView& a, const DpGraphView& b) {
+  if (&a == &b) return true;
+  if (a.n_phore != b.n_phore || a.n_pp != b.n_pp) return false;
+  if (!a.ph_x || !b.ph_x || !a.ph_pos || !b.ph_pos || !a.ph_norm || !b.ph_norm || !a.ph_type || !b.ph_type) return false;
+  if (a.n_pp > 0 && (!a.pp_index || !b.pp_index)) return false;
+  const size_t np = (size_t)a.n_phore;
+  auto eq = [](const void* x, const void* y, size_t bytes) { return x == y || memcmp(x, y, bytes) == 0; };
+  return eq(a.ph_x, b.ph_x, np * 5 * 4) && eq(a.ph_pos, b.ph_pos, np * 3 * 4) && eq(a.ph_norm, b.ph_norm, np * 3 * 4) && eq(a.ph_type, b.ph_type, np * 11 * 4) &&
+         (a.n_pp == 0 || eq(a.pp_index, b.pp_index, (size_t)a.n_pp * 2 * 8));
+}
 
 constexpr int EX_TYPE = 10;      // the exclusion-sphere column of the one-hot `phoretype` (process_pharmacophore.py:28-38: the last of 11)
 // type of pharmacophore node j: the first column that is exactly 1 (dp_pack_fill validates the one-hot), -1 if none
@@ -45,6 +57,7 @@ static int sizes_of(int32_t n, const DpPoseRef* poses, Sizes* s) {
   memset(s, 0, sizeof(*s));
   const DpGraphView* last = nullptr;               // the samples of one complex share a view and follow each other: counted once
   int64_t last_xs = 0;
+  bool shared = n > 1;                             // DpBatch.ph_shared: every pose carries pose 0's pharmacophore (byte comparison; -0.0 vs 0.0 counts as different)
   for (int i = 0; i < n; ++i) {
     const DpGraphView* v = poses[i].view;
     if (!v || !poses[i].pos || !poses[i].norm) return DP_E_BADARG;
@@ -57,12 +70,14 @@ static int sizes_of(int32_t n, const DpPoseRef* poses, Sizes* s) {
     if (v != last) {
       if (!v->phorefp || !v->ph_type) return DP_E_BADARG;
       last = v; last_xs = count_xs(*v);
+      if (shared && i > 0) shared = same_phore(*poses[0].view, *v);
     }
     s->n_xs += last_xs;
     s->max_nl = std::max<int32_t>(s->max_nl, (int32_t)nl); s->max_np = std::max<int32_t>(s->max_np, (int32_t)np);
     s->max_t = std::max<int32_t>(s->max_t, (int32_t)nt);
   }
   if (std::max(s->n_x, s->ll_cap) * 20 >= ((int64_t)1 << 31)) return DP_E_TOOLARGE;      // int32 indexing of the per-edge arrays
+  s->ph_shared = shared ? 1 : 0;
   return DP_OK;
 }
 
@@ -103,6 +118,7 @@ int dp_pack_query(int32_t n, const DpPoseRef* poses, DpBatch* totals, DpPackLayo
   totals->n_pp = (int32_t)s.n_pp; totals->n_x = (int32_t)s.n_x; totals->ll_cap = (int32_t)s.ll_cap; totals->n_llp = (int32_t)s.n_llp;
   totals->max_nl = s.max_nl; totals->max_np = s.max_np; totals->max_t = s.max_t;
   totals->n_xs = (int32_t)s.n_xs;
+  totals->ph_shared = s.ph_shared;
   memset(layout, 0, sizeof(*layout));
   dpk::layout_of(n, s, layout);
   return DP_OK;

@@ -37,7 +37,7 @@ class DpBatch(C.Structure):
                                         "mask_rotate", "phorefp", "norm_angle1", "norm_angle2", "ph_pos", "ph_norm", "ph_x",
                                         "ph_scalar", "ph_type", "pp_src", "pp_dst", "pp_rowptr", "pp_rowend", "pos", "norm",
                                         "t")]
-                + [("n_xs", c_i32)] + [(n, VOIDP) for n in _XS_ARRAYS])
+                + [("n_xs", c_i32)] + [(n, VOIDP) for n in _XS_ARRAYS] + [("ph_shared", c_i32)])
 
 
 class DpGraphView(C.Structure):
@@ -90,7 +90,8 @@ class DpWork(C.Structure):
                                         "t_hb", "t_q", "status", "prof_start", "prof_stop")]
                 + [("prof_layer", c_i32), ("prof_conv", c_i32), ("prof_events", VOIDP), ("conv_algo", c_i32)]
                 + [(n, VOIDP) for n in ("aux_stream", "ev_fork", "ev_join")] + [("aux_mode", c_i32), ("ll_node_max_atoms", c_i32), ("edge_bf16x6", c_i32), ("conv_part", VOIDP), ("z_noise", VOIDP), ("path_split", c_i32), ("conv_fuse", c_i32), ("node_f16", c_i32),
-                                                                                 ("aux2_stream", VOIDP), ("ev_join2", VOIDP), ("ev_x2", VOIDP), ("pp_tmp", VOIDP), ("pp_msg", VOIDP), ("xs_msg", VOIDP), ("xs_place", c_i32), ("xn_sparse", c_i32)])
+                                                                                 ("aux2_stream", VOIDP), ("ev_join2", VOIDP), ("ev_x2", VOIDP), ("pp_tmp", VOIDP), ("pp_msg", VOIDP), ("xs_msg", VOIDP), ("xs_place", c_i32), ("xn_sparse", c_i32),
+                                                                                 ("t_uniform", c_i32), ("ph_share", c_i32), ("t_row", VOIDP), ("tp_table", VOIDP), ("tp_row", VOIDP)])
 
 
 class DpStepParams(C.Structure):
@@ -693,6 +694,17 @@ class PackedBatch:
             cnt = np.bincount(src, minlength=n_nodes)
             H[pre + "_rowptr"] = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
         self._n_xs = int(H["xs_src"].size)
+        # DpBatch.ph_shared: every pose carries pose 0's pharmacophore (byte comparison, as dp_pack_query does it)
+        def same_phore(i):
+            if P[i] is P[0] and graphs[i]["phore", "phore"] is graphs[0]["phore", "phore"]:
+                return True
+            if npn[i] != npn[0] or npp[i] != npp[0]:
+                return False
+            pairs = [(P[i].x, P[0].x, np.float32), (P[i].pos, P[0].pos, np.float32), (P[i].norm, P[0].norm, np.float32),
+                     (P[i].phoretype, P[0].phoretype, np.float32),
+                     (graphs[i]["phore", "phore"].edge_index, graphs[0]["phore", "phore"].edge_index, np.int64)]
+            return all(a is b_ or np.ascontiguousarray(A(a), dtype=dt).tobytes() == np.ascontiguousarray(A(b_), dtype=dt).tobytes() for a, b_, dt in pairs)
+        self._ph_shared = int(B > 1 and all(same_phore(i) for i in range(1, B)))
         for k_ in ("xs_src", "xs_nbr", "xs_feat", "xt_src", "xt_nbr", "xt_feat"):
             if H[k_].size == 0:
                 H[k_] = np.zeros(1, dtype=np.int32)
@@ -766,6 +778,7 @@ class PackedBatch:
         s.n_pp, s.n_x, s.ll_cap = int(self.pp_ptr[-1]), int(self.x_ptr[-1]), int(self.ll_ptr[-1])
         s.n_llp = int(self.llp_ptr[-1]) if self.ll_pairs_ok else 0
         s.n_xs = self._n_xs
+        s.ph_shared = self._ph_shared
         s.max_nl, s.max_np, s.max_t = int(nl.max()), int(npn.max()), int(nt.max())
         # hints for the node-side convs: no pose ends on a pass of <= 16 edge slots -> the lean kernel instantiation (DpConvArgs.no_tail)
         tail = lambda v: bool((((v - 1) % 32) < 16).any())                     # noqa: E731  (v mod 32 in 1..16)
@@ -786,7 +799,20 @@ class PackedBatch:
         """Scalars (one t for the whole batch, sampling.py:218) or per-pose tensors [B]."""
         tt = torch.stack([torch.as_tensor(x, dtype=torch.float32).expand(self.B) if not torch.is_tensor(x) or x.dim() == 0
                           else x.float() for x in (t_tr, t_rot, t_tor)], 1)
+        # one time for every pose (known without looking at device data): DpWork.t_uniform of the forwards that follow
+        # (a per-pose HOST tensor is looked at: set_time_phore hands forward(data) B copies of one value; a device tensor is not - no sync here)
+        def uniform(x):
+            if not torch.is_tensor(x) or x.dim() == 0:
+                return True
+            return x.device.type == "cpu" and x.numel() > 0 and bool((x == x.reshape(-1)[0]).all())
+        self.t_uniform = all(uniform(x) for x in (t_tr, t_rot, t_tor))
         self.t.copy_(tt.to(self.device))
+
+    def set_time_row(self, row: torch.Tensor):
+        """The sampling loop's set_time_phore (sampling.py:218): one device row (t_tr, t_rot, t_tor) for every pose, no host sync.  (Write the times
+        through set_time / set_time_row only: they keep `t_uniform`, which Engine.forward / sample_step pass on as DpWork.t_uniform.)"""
+        self.t.copy_(row.reshape(1, 3).expand(self.B, 3))
+        self.t_uniform = True
 
 
 class Workspace:
@@ -905,6 +931,8 @@ class Engine:
         self.ws.struct.xn_sparse = {"auto": 0, "1": 1, "0": 2}[xn]
         if os.environ.get("DIFFPHORE_PP_LIST", "1") == "0":
             self.ws.struct.pp_msg = None             # A/B switch: the phore-phore convs on the CSR kernel whatever the fill of its chunks (dp_pp_as_list)
+        if os.environ.get("DIFFPHORE_PH_SHARE", "1") == "0":
+            self.ws.struct.ph_share = 2              # A/B switch: the layer-0 phore-phore conv per pose even when the batch is on one pharmacophore (DpBatch.ph_shared)
         self.ws.struct.ll_node_max_atoms = int(os.environ.get("DIFFPHORE_LL_NODE_MAX_ATOMS", "0"))
         ps = os.environ.get("DIFFPHORE_PATH_SPLIT", "auto")
         if ps not in ("auto", "1", "0"):
@@ -983,6 +1011,7 @@ class Engine:
 
     def forward(self):
         ws = self.ws
+        ws.struct.t_uniform = 1 if getattr(self.pb, "t_uniform", False) else 0
         _lib.check(self.L.dp_forward(C.byref(self.pb.struct), C.byref(self.model.struct), C.byref(ws.struct), ws.tr.data_ptr(),
                                      ws.rot.data_ptr(), ws.tor.data_ptr(), _stream()), "dp_forward")
         return ws.tr, ws.rot, ws.tor[:ws.n_tor]
@@ -1012,6 +1041,7 @@ class Engine:
 
     def sample_step(self, sp: DpStepParams, z_tr=None, z_rot=None, z_tor=None):
         ws = self.ws
+        ws.struct.t_uniform = 1 if getattr(self.pb, "t_uniform", False) else 0
         _lib.check(self.L.dp_sample_step(C.byref(self.pb.struct), C.byref(self.model.struct), C.byref(ws.struct), C.byref(sp),
                                          ws.tr.data_ptr(), ws.rot.data_ptr(), ws.tor.data_ptr(), _lib.ptr(z_tr), _lib.ptr(z_rot),
                                          _lib.ptr(z_tor), _stream()), "dp_sample_step")

@@ -173,7 +173,7 @@ def _enqueue_run(eng, Z, T_all, part, inference_steps, tr_schedule, rot_schedule
         last = t_idx == inference_steps - 1
         zero = no_random or (no_final_step_noise and last)
         sp = sps[t_idx]
-        pb.t.copy_(T_all[t_idx].expand(pb.B, 3))
+        pb.set_time_row(T_all[t_idx])
         z_tr = z_rot = z_tor = None
         if not (ode or zero) and dev_noise is not None:
             seed, uid = dev_noise

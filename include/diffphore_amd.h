@@ -31,7 +31,7 @@ extern "C" {
 #define DP_E_UNSUPPORTED (-2)
 #define DP_E_TOOLARGE (-3)
 
-#define DP_ABI_VERSION 11
+#define DP_ABI_VERSION 12
 
 /* tensor-product conv "kinds": which irreps / path table the kernel is specialised for */
 enum DpConvKind {
@@ -133,8 +133,10 @@ typedef struct DpConvArgs {
   int32_t resid_stride;
   int32_t resid_width;
   int32_t phase_split;       /* 1: two workgroups per (pose, slice), one per accumulation phase (scalar / vector output channels) - halves a
-                                conv's latency when B*slices cannot fill the chip; results are bit-identical.  fp32-MFMA kernel only
-                                (ignored otherwise and for kinds with a single phase) */
+                                conv's latency when B*slices cannot fill the chip; results are bit-identical.  The fp32-MFMA kernel, and DP_EDGES_LIST
+                                launches that carry a whole conv (sh0_zero = 0: two workgroups per 128-edge chunk, each emits the output channels of its
+                                phase - dp_forward: the phore-phore conv of a batch with at most 64 chunks); ignored otherwise and for kinds with a
+                                single phase */
   /* node-side formulation (DP_ALGO_NODE): weights in the layout of dp_pack_conv_weights_node; `slices` = node groups per pose with
    * ceil(max_scatter / slices) <= dp_conv_node_max_nodes().  Kinds 0-3; DP_PREC_F32 (weights from dp_pack_conv_weights_node) or
    * DP_PREC_BF16 (weights from dp_pack_conv_weights_node_bf16, plus edge_emb_bf below; no path_split / conv split variants: such
@@ -198,7 +200,10 @@ int dp_list_reduce(const float* msg, const int32_t* rowptr, int32_t B, const int
  * c < resid_width or 0 - the epilogue of the CSR kernel, for convs whose poses have too few edges to fill 128-edge chunks of their own
  * (dp_forward: the phore-phore convs of small pharmacophores). */
 int dp_list_finish(const float* msg, const int32_t* rowptr, const int32_t* rowend, int32_t n_nodes, int32_t d_out, const float* bn_scale, const float* bn_shift,
-                   const float* resid, int32_t resid_stride, int32_t resid_width, float* out, int32_t out_stride, int32_t accumulate, void* stream);
+                   const float* resid, int32_t resid_stride, int32_t resid_width, float* out, int32_t out_stride, int32_t accumulate, int32_t bcast_nodes,
+                   void* stream);
+/* (bcast_nodes > 0: the list holds the edges of the first bcast_nodes nodes only and node n takes the messages of node n mod bcast_nodes - one
+ *  pharmacophore's conv handed to every pose that carries it, DpBatch.ph_shared; 0 = every node its own rows) */
 /* the node-side kernel directly (dp_tp_conv dispatches here when args->algo == DP_ALGO_NODE) */
 int dp_tp_conv_node(const DpConvArgs* args, void* stream);
 int dp_conv_node_max_nodes(void);
@@ -298,6 +303,12 @@ typedef struct DpBatch {
   const int32_t* xs_rowptr;                   /* [n_lig + 1] the pairs of atom a are xs_rowptr[a] .. xs_rowptr[a + 1] */
   const int32_t *xt_src, *xt_nbr, *xt_feat;   /* [n_xs] sorted by (pose, node, atom): global node id, global atom id, the same dense cross row */
   const int32_t* xt_rowptr;                   /* [n_ph + 1] */
+  /* 1 = every pose of the batch carries the SAME pharmacophore (same node features, positions, normals, the same edges in the same order): a virtual
+   * screen against one pharmacophore, the N samples of one complex (inference.py:183-209).  Found by dp_pack_query (content comparison with pose 0).
+   * What the model computes from the pharmacophore alone is then the same for every pose while the diffusion times are (DpWork.t_uniform): dp_forward
+   * evaluates the layer-0 phore-phore conv - inputs h_p^0, e_pp, sh_pp: score_model_phore.py:691-693 at l = 0 - on pose 0's edges only and hands every
+   * pose that output (dp_list_finish, bcast_nodes).  0 = not known / not so. */
+  int32_t ph_shared;
 } DpBatch;
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -475,7 +486,18 @@ typedef struct DpWork {
                                        listed, each is evaluated as its l = 0 part on every pair (DpConvArgs.s0_only, its own node-side launch) + the
                                        other paths on the listed pairs (DP_EDGES_LIST + dp_list_reduce): the same sum, term by term, without the terms
                                        that multiply by an exact zero; 1 = whenever possible, 2 = never (the dense conv; A/B runs and tests) */
+  int32_t t_uniform;                /* the caller's statement about THIS forward: every pose carries the same (t_tr, t_rot, t_tor) - what set_time_phore does
+                                       in the sampling loop (sampling.py:218; dp_sample states it itself: it writes the times).  0 = not known */
+  int32_t ph_share;                 /* 0 = with DpBatch.ph_shared and t_uniform, the layer-0 phore-phore conv once for the batch; 2 = never (A/B runs, tests) */
+  const float* t_row;               /* optional DEVICE [3]: THE (t_tr, t_rot, t_tor) of every pose for this forward - set_time_phore (sampling.py:218) folded into
+                                       the first kernel of the step: it reads this row instead of DpBatch.t and writes it there for every pose.  Implies
+                                       t_uniform.  dp_sample points it at row i of DpSchedule.t.  NULL = the per-pose times of DpBatch.t */
+  float* tp_table;                  /* workspace [DP_TP_TABLE_STEPS, 32]: dp_sample's time parameters (sigma embedding, sigmas, score norms) of every step of
+                                       the schedule, computed once per run by the same kernel that computes them per pose */
+  const float* tp_row;              /* optional DEVICE [32], with t_row: that row's time parameters, computed before - dp_forward then only hands them to
+                                       every pose (dp_sample: row i of tp_table) */
 } DpWork;
+#define DP_TP_TABLE_STEPS 1024
 
 typedef struct DpStepParams {       /* per reverse-diffusion step scalars (sampling.py:205-244), computed by the host */
   float tr_c1, tr_c2;               /* tr_perturb  = tr_c1 * tr_score  + tr_c2 * z_tr   (c1 = g^2 dt or g^2 dt / 2 for ODE) */

@@ -10,7 +10,7 @@
  * diffphore_amd/sampling.py does with a flagged batch; bit 0 alone (a degenerate Kabsch alignment) does not.  It prints "replayed=0|1".
  *
  * Dump format: records of { char name[64]; int32 dtype (0 f32, 1 i32, 2 u8); int64 count; data }, names = DpBatch field names,
- * plus "dims" (i32[15]: B n_lig n_ph n_bond n_tor n_pp n_x ll_cap n_llp max_nl max_np max_t no_tail_nl no_tail_np n_xs), "blob" (f32), "scalars" (f32[12]),
+ * plus "dims" (i32[16]: B n_lig n_ph n_bond n_tor n_pp n_x ll_cap n_llp max_nl max_np max_t no_tail_nl no_tail_np n_xs ph_shared), "blob" (f32), "scalars" (f32[12]),
  * "precision" (i32[1]), "conv_algo" (i32[1]).
  */
 #include <hip/hip_runtime_api.h>
@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
   b.n_llp = d[8]; b.max_nl = d[9]; b.max_np = d[10]; b.max_t = d[11];
   b.no_tail_nl = d[12]; b.no_tail_np = d[13];      /* hints: which node-side instantiation dp_forward may launch */
   b.n_xs = d[14];                                  /* the cross pairs with type agreement (the normals convs' listed pairs) */
+  b.ph_shared = d[15];                             /* every pose on one pharmacophore (dp_pack_query's finding) */
 #define I32(field) b.field = (const int32_t*)find(#field)->dev
 #define F32(field) b.field = (const float*)find(#field)->dev
   I32(lig_ptr); I32(ph_ptr); I32(bond_ptr); I32(tor_ptr); I32(pp_ptr); I32(x_ptr); I32(ll_ptr); I32(mask_ptr); I32(pose_ptr); I32(llp_ptr);
@@ -88,6 +89,12 @@ int main(int argc, char** argv) {
   float *tr, *rot, *tor;
   CHECK(dp_work_bind(&b, work, wb, &k, &tr, &rot, &tor));
   k.conv_algo = *(const int32_t*)find("conv_algo")->host;
+  {                                                /* this host wrote the times itself: it can state that every pose carries the same ones */
+    const float* th = (const float*)find("t")->host;
+    int uni = 1;
+    for (int i = 1; i < b.B; ++i) uni &= th[3 * i] == th[0] && th[3 * i + 1] == th[1] && th[3 * i + 2] == th[2];
+    k.t_uniform = uni;
+  }
   hipStream_t st;
   CHECK(hipStreamCreate(&st));
   CHECK(dp_work_init(&b, &k, st));

@@ -124,7 +124,7 @@ def test_workspace_and_blob_layout_queries_need_no_gpu():
     base = 1 << 20                                                            # a fake (aligned) device address: bind touches no memory
     assert L.dp_work_bind(C.byref(b), base, n1, C.byref(w), *[C.byref(p) for p in ptrs]) == 0
     fields = [getattr(w, n) for n, _ in engine.DpWork._fields_ if n not in ("h_l", "h_p", "prof_start", "prof_stop", "prof_layer",
-                                                                            "prof_conv", "prof_events", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "path_split", "edge_bf16x6", "ll_node_max_atoms", "aux_mode", "node_f16", "xn_sparse", "aux2_stream", "ev_join2", "ev_x2", "xs_place")]
+                                                                            "prof_conv", "prof_events", "conv_algo", "aux_stream", "ev_fork", "ev_join", "conv_fuse", "path_split", "edge_bf16x6", "ll_node_max_atoms", "aux_mode", "node_f16", "xn_sparse", "aux2_stream", "ev_join2", "ev_x2", "xs_place", "t_uniform", "ph_share", "t_row", "tp_row")]
     fields += list(w.h_l) + list(w.h_p) + [p.value for p in ptrs]
     assert all(f is not None and base <= f < base + n1 and f % 256 == 0 for f in fields) and len(set(fields)) == len(fields)
     assert L.dp_work_bind(C.byref(b), base, n1 - 1, C.byref(w), *[C.byref(p) for p in ptrs]) == -3

@@ -33,7 +33,7 @@ def write_dump(path, pb, model, conv_algo):
         f.write(arr.tobytes())
     s = pb.struct
     with open(path, "wb") as f:
-        rec(f, "dims", np.asarray([s.B, s.n_lig, s.n_ph, s.n_bond, s.n_tor, s.n_pp, s.n_x, s.ll_cap, s.n_llp, s.max_nl, s.max_np, s.max_t, s.no_tail_nl, s.no_tail_np, s.n_xs], dtype=np.int32))
+        rec(f, "dims", np.asarray([s.B, s.n_lig, s.n_ph, s.n_bond, s.n_tor, s.n_pp, s.n_x, s.ll_cap, s.n_llp, s.max_nl, s.max_np, s.max_t, s.no_tail_nl, s.no_tail_np, s.n_xs, s.ph_shared], dtype=np.int32))
         for k, v in pb.static.items():
             rec(f, k, v.cpu().numpy())
         rec(f, "pos", pb.pos.cpu().numpy())

@@ -476,10 +476,15 @@ def test_whole_conv_as_one_list_launch(kind):
                 attr1_tab=base["attr1_tab"], attr1_stride=dims["d_in"], attr2_tab=base["attr2_tab"], attr2_stride=dims["d_in"], edge_emb=base["edge_emb"],
                 edge_sh=base["edge_sh"], sh_stride=9, w1p=base["w1p"], w2p=lst["w2x"])
     _run(larg, keep)
+    # DpConvArgs.phase_split on a list launch: two workgroups per chunk, one accumulation phase each - the same messages, bit for bit
+    msg2 = torch.full((E, dims["d_out"]), float("nan")).cuda()
+    _run(dict(larg, msg_out=msg2, phase_split=1), keep)
+    torch.cuda.synchronize()
+    assert torch.equal(msg, msg2)
     out = torch.full((n_out, dims["d_out"]), float("nan")).cuda()
     rp = lst["rowptr"]
     _lib.check(_lib.lib().dp_list_finish(msg.data_ptr(), rp.data_ptr(), rp[1:].contiguous().data_ptr(), n_out, dims["d_out"], lst["bnx"].data_ptr(),
-                                         base["bn_shift"].data_ptr(), base["resid"].data_ptr(), dims["d_in"], dims["d_in"], out.data_ptr(), dims["d_out"], 0,
+                                         base["bn_shift"].data_ptr(), base["resid"].data_ptr(), dims["d_in"], dims["d_in"], out.data_ptr(), dims["d_out"], 0, 0,
                                          torch.cuda.current_stream().cuda_stream), "dp_list_finish")
     torch.cuda.synchronize()
     want = ref.clone()

@@ -140,6 +140,57 @@ def test_normals_convs_split_without_any_listed_pair(monkeypatch):
     assert all(v < 1e-5 for v in errs.values()), errs
 
 
+@pytest.mark.parametrize("shape", ["screen", "one_complex"])
+def test_layer0_phore_conv_once_per_shared_pharmacophore(shape, monkeypatch):
+    """A batch whose poses all carry ONE pharmacophore at one diffusion time (DpBatch.ph_shared + DpWork.t_uniform: a screen against one pharmacophore,
+    the 40 samples of one complex) evaluates the layer-0 phore-phore conv on pose 0's edges only and hands every pose that output.  Same scores as the
+    per-pose conv (bit for bit where that one is the list launch too, <= 1e-6 against the CSR kernel's summation order), the oracle's scores, and
+    per-pose times switch it off."""
+    from diffphore_amd.engine import DeviceModel, Engine, PackedBatch
+    from oracle import sampler as osampler
+    monkeypatch.setenv("DIFFPHORE_CONV_ALGO", "node")
+    if shape == "screen":
+        lib = synthetic.ScreenLibrary(4, 5)
+        gs = [lib.unit(i).sample_copy() for i in range(5) for _ in range(3)]
+    else:
+        gs = [synthetic.synthetic_pairs(97, 1, 20, 5, 14)[0].sample_copy() for _ in range(12)]
+    rng = np.random.default_rng(5)
+    for g in gs:                                           # every sample its own pose
+        g["ligand"].pos = g["ligand"].pos + torch.from_numpy(rng.normal(0, 0.7, size=tuple(g["ligand"].pos.shape)).astype(np.float32))
+    sd, om = _model()
+    model = DeviceModel(sd, config.ModelConfig(), "cuda")
+
+    def run(times, share):
+        monkeypatch.setenv("DIFFPHORE_PH_SHARE", "1" if share else "0")
+        pb = PackedBatch(gs, "cuda")
+        assert int(pb.struct.ph_shared) == 1
+        pb.set_time(*times)
+        eng = Engine(model, pb)
+        out = [x.clone() for x in eng.forward()]
+        torch.cuda.synchronize()
+        return out, eng.ws.t["h_p1"].clone(), int(eng.ws.struct.t_uniform)
+    once, hp_once, uni = run((0.4, 0.4, 0.4), True)
+    each, hp_each, _ = run((0.4, 0.4, 0.4), False)
+    assert uni == 1
+    if shape == "one_complex":                             # a 14-node pharmacophore: the per-pose conv is the list launch as well (dp_pp_as_list) - the same kernel
+        assert all(torch.equal(a, b) for a, b in zip(once, each)) and torch.equal(hp_once, hp_each)      # on the same numbers, the same sums
+    else:                                                  # 79 nodes: per pose it is the CSR kernel, which adds a node's messages up in another order
+        assert all(_rel(a, b) < 1e-6 for a, b in zip(once, each))
+    batch = Batch.from_data_list(gs)
+    osampler.set_time_phore(batch, 0.4, 0.4, 0.4, batch.num_graphs)
+    want = om(batch)
+    errs = [_rel(a, b) for a, b in zip(once, want)]
+    assert all(e < 1e-5 for e in errs), errs
+    # per-pose times (a training-style batch): no statement about the times, the conv runs per pose - and host tensors of ONE value are recognised
+    tt = torch.linspace(0.2, 0.9, len(gs))
+    mixed, _, uni_mixed = run((tt, tt, tt), True)
+    mixed_ref, _, _ = run((tt, tt, tt), False)
+    assert uni_mixed == 0 and all(torch.equal(a, b) for a, b in zip(mixed, mixed_ref))
+    same = torch.full((len(gs),), 0.4)
+    again, _, uni_same = run((same, same, same), True)
+    assert uni_same == 1 and all(torch.equal(a, b) for a, b in zip(again, once))
+
+
 @pytest.mark.parametrize("dense_fp", [False, True])
 def test_normals_convs_as_l0_part_plus_listed_pairs(dense_fp, monkeypatch):
     """The two normals convs of a layer (phore_to_lig_norm / lig_to_phore_norm) as their l = 0 part on every pair + the other paths on the listed

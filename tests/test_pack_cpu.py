@@ -85,6 +85,33 @@ def test_native_pack_equals_numpy_pack():
     assert s.lig_x == (1 << 30) + a._layout.lig_x and s.norm == (1 << 30) + a._layout.norm and s.no_tail_nl == 0 and s.no_tail_np == 0
 
 
+def test_ph_shared_is_found_by_both_packers():
+    """DpBatch.ph_shared: every pose on pose 0's pharmacophore (content, not tensor identity) - the samples of one complex, a screen against one
+    pharmacophore; not a mixed batch, not a single pose, not a pharmacophore that differs in one coordinate"""
+    def both(poses):
+        a = PackedBatch(poses, "cpu", upload=False, host_pack="native")
+        b = PackedBatch(poses, "cpu", upload=False, host_pack="numpy")
+        assert int(a._totals.ph_shared) == b._ph_shared
+        return b._ph_shared
+    gs = synthetic.synthetic_pairs(35, 3, (10, 14), 3, 12)
+    assert both(gs) == 0                                                            # three different pharmacophores
+    assert both([gs[0].sample_copy() for _ in range(4)]) == 1                       # samples of one complex
+    assert both([gs[0]]) == 0                                                       # a single pose: nothing to share
+    lib = synthetic.ScreenLibrary(4, 3)
+    units = [lib.unit(i) for i in range(3)]
+    assert units[0]["phore"].pos is not units[1]["phore"].pos
+    screen = [u.sample_copy() for u in units for _ in range(2)]
+    assert both(screen) == 1                                                        # different ligands, the same pharmacophore (equal content)
+    units[2]["phore"].pos = units[2]["phore"].pos.clone()
+    units[2]["phore"].pos[3, 1] += 1e-6
+    assert both([u.sample_copy() for u in units for _ in range(2)]) == 0
+    units = [lib.unit(i) for i in range(3)]
+    ei = units[1]["phore", "phore"].edge_index.clone()
+    ei[:, [0, 1]] = ei[:, [1, 0]]                                                   # the same edges in another order
+    units[1]["phore", "phore"].edge_index = ei
+    assert both([u.sample_copy() for u in units]) == 0
+
+
 def test_views_are_cached_per_complex_and_rebuilt_when_a_static_changes():
     gs = synthetic.synthetic_pairs(33, 2, 12, 3, 10)
     poses = [g.sample_copy() for g in gs for _ in range(4)]

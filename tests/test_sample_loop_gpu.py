@@ -22,7 +22,7 @@ def _args():
 
 
 def _run(gs, noise, S, monkeypatch, **env):
-    for k in ("DIFFPHORE_WHOLE_LOOP", "DIFFPHORE_GRAPH", "DIFFPHORE_TWO_STREAMS", "DIFFPHORE_CONV_ALGO", "DIFFPHORE_XN_SPARSE", "DIFFPHORE_PATH_SPLIT", "DIFFPHORE_PP_LIST"):
+    for k in ("DIFFPHORE_WHOLE_LOOP", "DIFFPHORE_GRAPH", "DIFFPHORE_TWO_STREAMS", "DIFFPHORE_CONV_ALGO", "DIFFPHORE_XN_SPARSE", "DIFFPHORE_PATH_SPLIT", "DIFFPHORE_PP_LIST", "DIFFPHORE_PH_SHARE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -59,6 +59,31 @@ def test_whole_loop_graph_and_two_streams_are_bit_identical_to_per_step(monkeypa
     for name, env in variants.items():
         got = run(gs, noise, S, monkeypatch, DIFFPHORE_CONV_ALGO=algo, **env)
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), name
+
+
+def test_samples_of_one_complex_share_the_layer0_phore_conv_in_every_driver(monkeypatch):
+    """the reference's own call shape (inference.py:183-209: N samples of ONE complex): every driver states the uniform times (dp_sample itself, the
+    per-step loop through PackedBatch.set_time_row), the batch is on one pharmacophore, the layer-0 phore-phore conv runs once per step - and the
+    trajectories are those of the per-pose conv, bit for bit (both are the list launch + dp_list_finish on this shape)"""
+    g0 = synthetic.synthetic_pairs(96, 1, 18, 4, 14)[0]
+    gs = [g0.sample_copy() for _ in range(8)]
+    rng = np.random.default_rng(11)
+    for g in gs:
+        g["ligand"].pos = g["ligand"].pos + torch.from_numpy(rng.normal(0, 0.5, size=tuple(g["ligand"].pos.shape)).astype(np.float32))
+    S = 4
+    gen = torch.Generator().manual_seed(4)
+    nT = sum(int(g["ligand"].edge_mask.sum()) for g in gs)
+    noise = dict(tr=torch.randn(S, len(gs), 3, generator=gen), rot=torch.randn(S, len(gs), 3, generator=gen), tor=torch.randn(S, nT, generator=gen))
+    base = _run(gs, noise, S, monkeypatch, DIFFPHORE_WHOLE_LOOP="0", DIFFPHORE_TWO_STREAMS="0", DIFFPHORE_PH_SHARE="0")
+    assert np.all(np.isfinite(base[0]))
+    for name, env in {"per step": dict(DIFFPHORE_WHOLE_LOOP="0", DIFFPHORE_TWO_STREAMS="0"), "dp_sample eager": dict(DIFFPHORE_GRAPH="0", DIFFPHORE_TWO_STREAMS="0"),
+                      "two streams, graph": dict(DIFFPHORE_GRAPH="1", DIFFPHORE_TWO_STREAMS="1"),
+                      "large-batch forms": dict(DIFFPHORE_XN_SPARSE="1", DIFFPHORE_PATH_SPLIT="0", DIFFPHORE_GRAPH="1")}.items():
+        got = _run(gs, noise, S, monkeypatch, **env)
+        if name == "large-batch forms":             # (other launches than `base`: the same poses within the kernels' tolerance)
+            assert np.abs(got[0] - base[0]).max() < 1e-4, name
+        else:
+            assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), name
 
 
 def test_graph_replay_reproduces_the_run():

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--shared-phore", action="store_true", help="every pose a sample of ONE complex (the reference's own call: N samples x one complex)")
+    ap.add_argument("--algos", default=None, help="comma list of conv formulations (default: edge,node where both exist)")
     a = ap.parse_args()
     c = synthetic.CONFIGS[a.config]
     cfg = config.ModelConfig()
@@ -43,7 +45,7 @@ def main():
     bmax = max(int(b) for b in a.batches.split(","))
     allg = synthetic.synthetic_pairs(a.config, min(bmax, 512), c["n_atoms"], c["n_tor"], c["n_phore"])
     for B in (int(b) for b in a.batches.split(",")):
-        gs = [allg[i % len(allg)].sample_copy() for i in range(B)]
+        gs = [allg[0 if a.shared_phore else i % len(allg)].sample_copy() for i in range(B)]
         torch.manual_seed(1)
         import numpy as np
         np.random.seed(1)
@@ -54,7 +56,7 @@ def main():
         ztr, zrot = torch.randn(S, B, 3, device="cuda", generator=g), torch.randn(S, B, 3, device="cuda", generator=g)
         ztor = torch.randn(S, int(pb.tor_ptr[-1]), device="cuda", generator=g)
         row = dict(poses=B)
-        for algo in (["edge", "node"] if a.precision in ("f32", "bf16") else ["edge"]):
+        for algo in (a.algos.split(",") if a.algos else (["edge", "node"] if a.precision in ("f32", "bf16") else ["edge"])):
             for drv in ("steps", "loop", "graph", "graph+2s"):
                 eng = Engine(model, pb, conv_algo=algo)
                 if drv == "graph+2s":
@@ -74,7 +76,7 @@ def main():
                     t0 = time.perf_counter()
                     if drv == "steps":
                         for t in range(S):
-                            pb.t.copy_(T[t].expand(B, 3))
+                            pb.set_time_row(T[t])
                             eng.sample_step(sps[t], ztr[t], zrot[t], ztor[t])
                     elif drv == "loop":
                         eng.sample(sps, T, ztr, zrot, ztor, graph=False)
