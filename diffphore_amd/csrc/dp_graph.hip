@@ -776,6 +776,10 @@ static int node_path_split_auto(int B, int slices, bool f16_avail) { return (lon
 #ifndef DP_F16_CSPLIT_MAX_WG
 #define DP_F16_CSPLIT_MAX_WG 384
 #endif
+#ifndef DP_HEADS_EARLY
+#define DP_HEADS_EARLY 1024          // centre edges / torsion-bond graph on the second stream beside the last interaction layer while that has at most
+                                     // this many ligand node groups (0: always in the tail)
+#endif
 #ifndef DP_PP_PSPLIT_MAX_CHUNKS
 #define DP_PP_PSPLIT_MAX_CHUNKS 64   // phore-phore conv as a list of at most this many 128-edge chunks: phase split (DpConvArgs.phase_split of a list launch)
 #endif
@@ -1025,7 +1029,9 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     if (prof) note(hipEventRecord((hipEvent_t)k->prof_stop, s_));
     return r;
   };
-  const bool heads_early = aux != nullptr && k->aux_mode != 1;
+  // (while the layer-3 launch leaves workgroup slots free: beside a launch that fills the chip they take its slots.  ms per step with / without, 30 atoms /
+  //  32 nodes, graph + second stream: 64 poses 0.666 / 0.673, 128: 1.034 / 1.062, 192: 1.359 / 1.371, 256: 1.621 / 1.622, 512: 3.015 / 2.954)
+  const bool heads_early = aux != nullptr && k->aux_mode != 1 && (long long)B * slices_pl <= DP_HEADS_EARLY;
   for (int l = 0; l < 4; ++l) {
     const float* hl = k->h_l[cur];
     const float* hp = k->h_p[cur];
@@ -1214,10 +1220,13 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     cur ^= 1;
   }
   const float* hl = k->h_l[cur];
-  // translation / rotation head on the launch stream, torsion head beside it when a second stream was given
+  // the two score heads side by side when a second stream was given: the LONGER chain (torsion bonds: conv over up to 32 edge slots per bond) stays on
+  // the launch stream, where the caller's next kernel (the conformer update) follows it without a cross-queue wait (~10 us); the translation /
+  // rotation head, done long before, goes to the second stream
   const bool tor_aux = aux != nullptr && b->n_tor > 0 && k->aux_mode != 1;
+  hipStream_t s_tr = tor_aux ? aux : st;
   if (tor_aux) fork();
-  if (!heads_early) hipLaunchKernelGGL(dp::center_edges_kernel, dim3(B), dim3(256), 0, st, *b, *w, *k);
+  if (!heads_early) hipLaunchKernelGGL(dp::center_edges_kernel, dim3(B), dim3(256), 0, s_tr, *b, *w, *k);
   {
     DpConvArgs c;
     memset(&c, 0, sizeof(c));
@@ -1226,12 +1235,12 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     c.edge_emb = k->c_emb; c.edge_sh = k->c_sh; c.sh_stride = 9;
     c.w1p = w->final_conv.w1p; c.w2p = w->final_conv.w2p; c.bn_scale = w->final_conv.bn_scale; c.bn_shift = w->final_conv.bn_shift;
     c.out = k->gpred; c.out_stride = 12;
-    if ((rc = dp_tp_conv(&c, st))) return fail(rc);
+    if ((rc = dp_tp_conv(&c, s_tr))) return fail(rc);
   }
-  hipLaunchKernelGGL(dp::trrot_head_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, *w, *k, tr, rot);
+  hipLaunchKernelGGL(dp::trrot_head_kernel, dim3((B + 3) / 4), dim3(256), 0, s_tr, B, *w, *k, tr, rot);
   // torsion head
   if (b->n_tor > 0) {
-    hipStream_t s2 = tor_aux ? aux : st;
+    hipStream_t s2 = st;
     if (!heads_early) hipLaunchKernelGGL(dp::tor_graph_kernel, dim3(B), dim3(256), 0, s2, *b, *w, *k);
     hipLaunchKernelGGL(dp::tor_hb_kernel, dim3((b->n_tor * dp::NS + 255) / 256), dim3(256), 0, s2, *b, *k, hl);
     DpConvArgs c;
