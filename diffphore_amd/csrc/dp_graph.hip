@@ -776,6 +776,9 @@ static int node_path_split_auto(int B, int slices, bool f16_avail) { return (lon
 #ifndef DP_F16_CSPLIT_MAX_WG
 #define DP_F16_CSPLIT_MAX_WG 384
 #endif
+#ifndef DP_SYM_BARRIER
+#define DP_SYM_BARRIER 1
+#endif
 #ifndef DP_HEADS_EARLY
 #define DP_HEADS_EARLY 1024          // centre edges / torsion-bond graph on the second stream beside the last interaction layer while that has at most
                                      // this many ligand node groups (0: always in the tail)
@@ -891,6 +894,29 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   };
   // error exit: never leave the aux stream forked (eager: later work on `st` must stay ordered after it; capture: an unjoined stream
   // turns the caller's hipStreamEndCapture into an error that masks `rc`)
+  // Between two stretches that both use the two streams (head -> layer 0, layer l -> l + 1) each stream needs what the OTHER one produced.  join() + fork()
+  // would chain the two waits (the second stream resumes one cross-queue latency - ~19 us eager - after the launch stream, which itself resumed one
+  // latency after the later of the two finished); recorded first and waited for crosswise, both resume one latency after the later one.  In a
+  // captured graph the dependencies are the same either way.
+  bool aux_synced = false, want_x2 = false;
+  bool capturing = false;
+  {
+    hipStreamCaptureStatus cs_ = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs_) == hipSuccess) capturing = cs_ != hipStreamCaptureStatusNone;
+    else (void)hipGetLastError();
+  }
+  auto barrier2 = [&]() {
+#if DP_SYM_BARRIER == 0      // A/B builds: the chained form
+    join();
+    return;
+#endif
+    note(hipEventRecord((hipEvent_t)k->ev_join, aux));
+    if (want_x2) note(hipEventRecord((hipEvent_t)k->ev_x2, aux));      // (the same position once more, for a third stream: see pp_beside)
+    note(hipEventRecord((hipEvent_t)k->ev_fork, st));
+    note(hipStreamWaitEvent(st, (hipEvent_t)k->ev_join, 0));
+    note(hipStreamWaitEvent(aux, (hipEvent_t)k->ev_fork, 0));
+    aux_forked = false; aux_synced = true;
+  };
   auto fail = [&](int rc_) { if (aux_forked) join(); return rc_; };
   if (k->t_row && k->tp_row)
     hipLaunchKernelGGL(dp::tp_bcast_kernel, dim3((B * dp::TP_STRIDE + 255) / 256), dim3(256), 0, st, B, const_cast<float*>(b->t), k->t_row, k->tp_row, k->tparams);
@@ -925,7 +951,6 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     const int x_slices = b->max_nl > 0 ? (b->max_nl + apw - 1) / apw : 1;
     hipLaunchKernelGGL(dp::cross_edges_kernel, dim3(B * x_slices), dim3(256), 0, st, *b, *w, kx, x_slices);
   }
-  if (aux) join();
   // workgroups per pose: keep <= 48 scatter nodes per workgroup and >= ~2 workgroups per CU in flight
   const int prec_edge = w->precision;        // (DP_PREC_BF16: the convs that stay edge-side run the one-product form of the split-bf16 kernel)
   int slices = 1;
@@ -1031,7 +1056,19 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
   };
   // (while the layer-3 launch leaves workgroup slots free: beside a launch that fills the chip they take its slots.  ms per step with / without, 30 atoms /
   //  32 nodes, graph + second stream: 64 poses 0.666 / 0.673, 128: 1.034 / 1.062, 192: 1.359 / 1.371, 256: 1.621 / 1.622, 512: 3.015 / 2.954)
+  // third stream for the phore-phore conv (see the pharmacophore side of the layer loop): the batch's answer, the same for layers 0-2
+  bool pp_beside_ok = false;
+  {
+    const bool pp_list_ = edge_x6 && w->ph_conv[0].w2x && w->ph_conv[0].bn_scale_x && k->pp_msg != nullptr && dp_pp_as_list(b);
+    const long long wg_pp = pp_list_ ? (b->n_pp + 127) / 128 : (long long)B * slices_x6;
+    const long long wg_layer = wg_pp + (long long)B * ((b->max_np + nb - 1) / nb) * 2 * 2 + (long long)B * ((b->max_nl + nb - 1) / nb) * 2 * 3;
+    pp_beside_ok = aux != nullptr && k->aux2_stream && k->ev_join2 && k->pp_tmp && node_side && fuse && !xs_ph && !xs_lig && f16_ph && f16_csplit(slices_lp) &&
+                   k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)2 * b->n_ph * 100 <= DP_CONV_PART_FLOATS / 2 && wg_layer <= DP_PP_BESIDE_MAX_WG;
+  }
   const bool heads_early = aux != nullptr && k->aux_mode != 1 && (long long)B * slices_pl <= DP_HEADS_EARLY;
+  // end of the head (launched above; everything in between is host arithmetic): both streams need all of it
+  want_x2 = pp_beside_ok && !capturing && k->ev_x2 != nullptr;
+  if (aux) { if (k->aux_mode != 1) barrier2(); else join(); }      // (layer 0 has two sides unless aux_mode = 1)
   for (int l = 0; l < 4; ++l) {
     const float* hl = k->h_l[cur];
     const float* hp = k->h_p[cur];
@@ -1047,7 +1084,12 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     a.gather_stride = a.attr1_stride = a.attr2_stride = 100;
     const bool two = aux != nullptr && l != 3 && k->aux_mode != 1;
     hipStream_t sp_ = two ? aux : st;           // stream of the phore-side convs
-    if (two) fork();
+    const bool layer_synced = two && aux_synced;
+    if (two) {
+      if (aux_synced) aux_forked = true;          // (the barrier that ended the previous stretch has made the second stream wait already)
+      else fork();
+      aux_synced = false;
+    }
     // the last layer has no pharmacophore side: the second stream builds the graphs of the two score heads meanwhile - centre edges and torsion-bond
     // neighbourhoods are functions of this step's positions and times only (35 us off the tail of a step, at any batch size)
     if (heads_early && l == 3) {
@@ -1058,7 +1100,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     xs_early[0] = xs_early[1] = false;
     if ((xs_async || xs_place == 1) && (xs_lig || (xs_ph && l != 3))) {
       // the layer's inputs are complete on st here (ev_fork: recorded by fork() when the layer has two sides)
-      if (!two) note(hipEventRecord((hipEvent_t)k->ev_fork, st));
+      // (a third stream: a fresh record - after barrier2 the launch stream has everything only behind its own wait for the second stream)
+      if (!two || xs_async) note(hipEventRecord((hipEvent_t)k->ev_fork, st));
       hipStream_t s_lig = xs_async ? (hipStream_t)k->aux2_stream : aux;       // crossed: the ligand side's list on the second stream ...
       hipStream_t s_ph = xs_async ? (hipStream_t)k->aux2_stream : st;         // ... the pharmacophore side's on the launch stream
       if (xs_async || !two) note(hipStreamWaitEvent(s_lig, (hipEvent_t)k->ev_fork, 0));      // (with two sides the second stream has waited in fork())
@@ -1150,13 +1193,21 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
       // ... while the three launches of a layer together leave workgroup slots free (256 CUs x 2): ms per step with / without, 30 atoms / 32 nodes,
       // graph + streams: 1 pose 0.439 / 0.473, 8: 0.476 / 0.499, 20: 0.570 / 0.535, 40: 0.678 / 0.652 - from ~18 poses on the chip is full of (long)
       // workgroups and one more concurrent launch only stretches the others
-      const bool pp_list_ = edge_x6 && w->ph_conv[l].w2x && w->ph_conv[l].bn_scale_x && k->pp_msg != nullptr && dp_pp_as_list(b);
-      const long long wg_pp = pp_list_ ? (b->n_pp + 127) / 128 : (long long)B * slices_x6;
-      const long long wg_layer = wg_pp + (long long)B * ((b->max_np + nb - 1) / nb) * 2 * 2 + (long long)B * ((b->max_nl + nb - 1) / nb) * 2 * 3;
-      const bool pp_beside = two && k->aux2_stream && k->ev_join2 && k->pp_tmp && node_side && fuse && !xs_ph && !xs_lig && f16_ph && f16_csplit(slices_lp) &&
-                             k->conv_part != nullptr && k->conv_fuse != 3 && (int64_t)2 * b->n_ph * 100 <= DP_CONV_PART_FLOATS / 2 && wg_layer <= DP_PP_BESIDE_MAX_WG;
+      const bool pp_beside = two && pp_beside_ok;
       hipStream_t s3 = pp_beside ? (hipStream_t)k->aux2_stream : sp_;
-      if (pp_beside) note(hipStreamWaitEvent(s3, (hipEvent_t)k->ev_fork, 0));        // (the layer's fork event, recorded on the launch stream above)
+      if (pp_beside) {
+        // the layer's inputs are what BOTH streams had produced when it began.  After fork() all of it is behind ev_fork; after barrier2 behind one
+        // event per stream (the second stream's position under a name of its own, ev_x2).  While the launch stream is being CAPTURED the third stream
+        // waits for a fresh record on the launch stream instead: joining a capture through the events of two different streams crashes inside the
+        // HIP runtime of ROCm 7.2 (hipStreamEndCapture), and a graph has no launch-stream latency to save anyway - the dependencies are the same.
+        if (layer_synced && want_x2) {      // barrier2: one event per stream, waited for side by side
+          note(hipStreamWaitEvent(s3, (hipEvent_t)k->ev_fork, 0));
+          note(hipStreamWaitEvent(s3, (hipEvent_t)k->ev_x2, 0));
+        } else {
+          if (layer_synced) note(hipEventRecord((hipEvent_t)k->ev_fork, st));
+          note(hipStreamWaitEvent(s3, (hipEvent_t)k->ev_fork, 0));
+        }
+      }
       {
         DpConvArgs c = a;
         c.mode = DP_EDGES_CSR; c.scat_ptr = b->ph_ptr; c.max_scatter = b->max_np; c.rowptr = b->pp_rowptr; c.rowend = b->pp_rowend; c.nbr = b->pp_dst;
@@ -1216,7 +1267,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
           if ((rc = (xs_ph && nv) ? timed_xs(phc[1], l, 5, false, hl, hp, sp_) : timed(phc[nv], l, 4 + nv, sp_))) return fail(rc);
       }
     }
-    if (two || (heads_early && l == 3)) join();
+    if (two && l + 1 < 3) barrier2();           // the next layer has two sides as well
+    else if (two || (heads_early && l == 3)) join();
     cur ^= 1;
   }
   const float* hl = k->h_l[cur];
