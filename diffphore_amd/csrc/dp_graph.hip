@@ -906,10 +906,13 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     else (void)hipGetLastError();
   }
   auto barrier2 = [&]() {
-#if DP_SYM_BARRIER == 0      // A/B builds: the chained form
-    join();
-    return;
-#endif
+    // (while the launch stream is being captured: the chained form.  The dependencies are the same, yet the replay of the graph captured from the
+    //  crosswise form is 6-9 % slower at 1-8 poses - 7.92 vs 7.25 ms per 20 steps at one pose - and equal from 40 poses on; eager it is the other way
+    //  round: 8.15 vs 9.07 ms at one pose, 11.4 vs 12.3 at 40, equal at 512.  DP_SYM_BARRIER = 0: A/B builds)
+    if (capturing || DP_SYM_BARRIER == 0) {
+      join();
+      return;
+    }
     note(hipEventRecord((hipEvent_t)k->ev_join, aux));
     if (want_x2) note(hipEventRecord((hipEvent_t)k->ev_x2, aux));      // (the same position once more, for a third stream: see pp_beside)
     note(hipEventRecord((hipEvent_t)k->ev_fork, st));
@@ -924,12 +927,14 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
     hipLaunchKernelGGL(dp::time_params_kernel, dim3((B + 7) / 8), dim3(256), 0, st, B, const_cast<float*>(b->t), k->t_row, *w, k->tparams);
   // the three graph / embedding kernels only share their inputs (positions, time parameters): the ligand radius graph runs on the second
   // stream beside the node embeddings and the cross edges (each is one workgroup per pose and latency-bound on its own)
+  // (starting the radius graph - positions only - before the time parameters: nothing eager, 10-15 % SLOWER as a captured graph, whose first node of
+  //  a step then fans out and whose lig_edges node gets a second predecessor: 1 pose 9.03 vs 7.88 ms per 20 steps, 40 poses 12.0 vs 10.7)
   if (aux) fork();
   const F16Plan pl = plan_f16(b, w, k);
   const bool f16_ok = pl.f16_ok, f16_lig = pl.f16_lig, f16_ph = pl.f16_ph;
   // the 16-bit images of the edge embeddings are written only for the convs that read them (DP_PREC_BF16 or DP_PREC_F16X3, node-side)
   const bool bf_node = node_side && w->precision == DP_PREC_BF16;
-  if (bf_node && (!k->x_emb_bf || (node_ll && !k->ll_emb_bf))) return DP_E_BADARG;
+  if (bf_node && (!k->x_emb_bf || (node_ll && !k->ll_emb_bf))) return fail(DP_E_BADARG);
   DpWork kx = *k;
   kx.node_f16 = (f16_lig || f16_ph) ? 1 : 0;
   if (!bf_node && !kx.node_f16) kx.x_emb_bf = kx.ll_emb_bf = nullptr;
