@@ -780,8 +780,8 @@ static int node_path_split_auto(int B, int slices, bool f16_avail) { return (lon
 #define DP_SYM_BARRIER 1
 #endif
 #ifndef DP_HEADS_EARLY
-#define DP_HEADS_EARLY 1024          // centre edges / torsion-bond graph on the second stream beside the last interaction layer while that has at most
-                                     // this many ligand node groups (0: always in the tail)
+#define DP_HEADS_EARLY 512           // centre edges / torsion-bond graph on the second stream beside the last interaction layer while that has at most
+                                     // this many 16-atom ligand node groups (B x slices_pl; 0: always in the tail)
 #endif
 #ifndef DP_PP_PSPLIT_MAX_CHUNKS
 #define DP_PP_PSPLIT_MAX_CHUNKS 64   // phore-phore conv as a list of at most this many 128-edge chunks: phase split (DpConvArgs.phase_split of a list launch)
@@ -1180,6 +1180,8 @@ int dp_forward(const DpBatch* b, const DpWeights* w, DpWork* k, float* tr, float
         if ((rc = timed_fused(ligc, 3, 0, 2, st))) return fail(rc);
       } else {
         if ((rc = timed_fused(ligc, 2, 0, 1, st))) return fail(rc);
+        // (a batch that fills the chip - heads_early off - with the head graphs on the second stream HERE, behind the fused launch and beside the normals
+        //  conv's short list launch: no difference, 173.8 vs 173.7 k pose-steps/s at 512 poses; not kept)
         if ((rc = timed_xs(ligc[2], l, 2, true, hl, hp, st))) return fail(rc);
       }
     } else {

@@ -25,5 +25,9 @@ bash tools/pmc_bench.sh ${tag}lig3 "tp_conv_node_f16_kernel<3, true" > /dev/null
 bash tools/pmc_bench.sh ${tag}s0lig3 "tp_conv_node_f16_kernel<3, false, 1, false, true" > /dev/null 2>&1
 bash tools/pmc_conv.sh ${tag}f16k3 --algo node --prec f16x3 --kind 3 --mode p2l > /dev/null 2>&1
 bash tools/gpu_step_timeline.sh 40 > gpurun_out/${tag}_small40.log 2>&1
+# N samples of ONE complex (the reference's own call): timeline of a step in the captured-graph driver, eager / captured / replayed loop times, shared-phore A/B
+for pc in "40 2" "1 2" "40 1"; do bash tools/gpu_graph_timeline.sh $pc > /dev/null 2>&1; done
+python tools/graph_create_cost.py 1 8 40 128 512 2>/dev/null | grep poses > gpurun_out/${tag}_loop_drivers.txt
+bash tools/gpu_phshare_ab.sh > /dev/null 2>&1; cp gpurun_out/phshare_ab.txt gpurun_out/${tag}_phshare_ab.txt
 python tools/rccl_single_rank_check.py > gpurun_out/${tag}_rccl_single_rank.txt 2>&1
 tail -3 gpurun_out/${tag}_gpu_suite.txt; tail -c 400 gpurun_out/${tag}_bench_full.json; ls gpurun_out | grep "^${tag}\|pmc_${tag}\|pmcb_${tag}"
