@@ -475,10 +475,14 @@ class _GraphView:
         gv = getattr(g, "_dp_view", None)
         src = None
         if gv is not None:
-            if id(gv) in checked:
-                return gv
             src = cls.sources(g)
-            if gv.valid_for(src):
+            if id(gv) in checked:
+                # validated for a sibling sample in this batch (same objects => same in-place versions): this sample must still hold the SAME objects -
+                # a sample whose static tensor was replaced since its last pack must not ride on its siblings' view
+                s0 = gv.src
+                if all(v is s0[i] for i, v in enumerate(src)):
+                    return gv
+            elif gv.valid_for(src):
                 by_key[gv.key] = gv
                 checked.add(id(gv))
                 return gv

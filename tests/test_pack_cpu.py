@@ -85,6 +85,33 @@ def test_native_pack_equals_numpy_pack():
     assert s.lig_x == (1 << 30) + a._layout.lig_x and s.norm == (1 << 30) + a._layout.norm and s.no_tail_nl == 0 and s.no_tail_np == 0
 
 
+def test_native_pack_of_a_large_batch_and_a_replaced_static_on_a_later_sample():
+    """210 poses (70 complexes x 3 samples): the same image and flags as the numpy packer; then ONE sample - not the first of its complex - gets a
+    replaced (malformed) static tensor: it must not ride on the view its siblings validated in the same batch"""
+    gs = synthetic.synthetic_pairs(36, 70, (12, 36), (0, 3), (5, 40))
+    poses = [g.sample_copy() for g in gs for _ in range(3)]                        # 210 poses
+    for k, p in enumerate(poses):
+        p["ligand"].pos = p["ligand"].pos + 0.001 * k
+    a = PackedBatch(poses, "cpu", upload=False, host_pack="native")
+    b = PackedBatch(poses, "cpu", upload=False, host_pack="numpy")
+    na = _native_arrays(a)
+    for k, v in b._host.items():
+        w = v.numpy().reshape(-1)
+        if (k == "mask_rotate" and int(b.mask_ptr[-1]) == 0) or (k[:3] in ("xs_", "xt_") and not k.endswith("rowptr") and b._n_xs == 0):
+            continue
+        assert np.array_equal(na[k], w.view(na[k].dtype) if w.dtype != na[k].dtype and w.dtype.itemsize == na[k].dtype.itemsize else w.astype(na[k].dtype)), k
+    assert np.array_equal(na["pos"], b._host_pos.numpy().reshape(-1)) and np.array_equal(na["norm"], b._host_norm.numpy().reshape(-1))
+    assert a.ll_pairs_ok == b.ll_pairs_ok and int(a._totals.n_xs) == b._n_xs
+    tail = lambda v: bool((((v - 1) % 32) < 16).any())                              # noqa: E731
+    assert bool(a._flags & 2) == tail(np.asarray(b.nl)) and bool(a._flags & 4) == tail(np.asarray(b.np_))
+    bad = poses[-2]
+    pt = bad["phore"].phoretype.clone()
+    pt[0] = 0.0
+    bad["phore"].phoretype = pt
+    with pytest.raises(ValueError, match="one-hot"):
+        PackedBatch(poses, "cpu", upload=False, host_pack="native")
+
+
 def test_ph_shared_is_found_by_both_packers():
     """DpBatch.ph_shared: every pose on pose 0's pharmacophore (content, not tensor identity) - the samples of one complex, a screen against one
     pharmacophore; not a mixed batch, not a single pose, not a pharmacophore that differs in one coordinate"""
