@@ -465,14 +465,18 @@ typedef struct DpWork {
   /* optional THIRD stream + one more event (both or none; created with dp_aux_create like the second): small batches whose pharmacophore-side launch takes
    * the conv split then run the layer's phore-phore conv on it, beside the ligand->phore convs instead of in front of them - it writes pad(h_p) + its
    * output to pp_tmp, which the combine launch of the conv split adds up with the other convs' parts.  A latency-bound step's longest chain per layer
-   * (phore-phore conv -> ligand->phore convs -> combine) becomes max(...) -> combine: 40 poses 0.65 -> ... ms per step.  Needs aux_stream. */
+   * (phore-phore conv -> ligand->phore convs -> combine) becomes max(...) -> combine (taken while the layer's launches together have at most 640
+   * workgroups: 20 poses of 30 atoms / 32 nodes 0.510 -> 0.479 ms per step; from ~30 poses on one more concurrent launch only stretches the others).
+   * Needs aux_stream. */
   void *aux2_stream, *ev_join2;
   void* ev_x2;                      /* one more event (optional; with ev_join2 it lets the list launches of a layer's normals convs run somewhere else than in front
-                                       of their s0-only launch, see xs_place) */
+                                       of their s0-only launch, see xs_place; eager enqueue with a third stream: the second stream's position at a layer
+                                       boundary under a name of its own, so that the third stream waits for both sides side by side) */
   float* pp_tmp;                    /* [n_ph, 100] */
   float* pp_msg;                    /* [n_pp, 100] per-edge messages of a phore-phore conv that runs as one DP_EDGES_LIST launch over the whole batch's edges +
                                        dp_list_finish (dp_forward: when the poses' own edge lists would leave their 128-edge chunks less than 70 % full -
-                                       small pharmacophores - and the two-limb fp16 edge-side weights are there), or NULL (dp_work_bind: not needed) */
+                                       small pharmacophores - and the two-limb fp16 edge-side weights are there; a batch on one pharmacophore, DpBatch.ph_shared: room
+                                       for one pose's edges at least, for the layer-0 conv that runs once), or NULL (dp_work_bind: not needed) */
   float* xs_msg;                    /* [2, n_xs, 100] per-edge messages of the listed pairs of the two normals convs of a layer (DP_EDGES_LIST; the two
                                        sides of a layer may run on two streams: one half each) */
   int32_t xs_place;                 /* the DP_EDGES_LIST launches of a layer's two normals convs (small grids, one chunk's latency each) and how their messages
