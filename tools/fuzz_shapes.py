@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--only", type=int, default=-1, help="evaluate only this batch index (same random sequence), with per-pose detail")
+    ap.add_argument("--shared", action="store_true", help="every other batch = 2..12 samples of ONE complex at perturbed poses (DpBatch.ph_shared: the "
+                                                          "layer-0 phore-phore conv runs once for the batch)")
     a = ap.parse_args()
     run(a)
 
@@ -56,6 +58,11 @@ def run(a):
                     break
                 except RuntimeError:
                     nt = max(0, nt - 1)
+        if getattr(a, "shared", False) and bi % 2 == 1:
+            g0 = gs[0]
+            gs = [g0.sample_copy() for _ in range(int(rng.integers(2, 13)))]
+            for g in gs:
+                g["ligand"].pos = g["ligand"].pos + torch.from_numpy(rng.normal(0, 0.6, size=tuple(g["ligand"].pos.shape)).astype(np.float32))
         batch = Batch.from_data_list(gs)
         t = float(rng.uniform(0.02, 1.0))
         if a.only >= 0 and bi != a.only:
