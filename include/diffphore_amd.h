@@ -342,14 +342,15 @@ typedef struct DpPackLayout {
   int64_t xs_src, xs_nbr, xs_feat, xs_rowptr, xt_src, xt_nbr, xt_feat, xt_rowptr;
   int64_t bytes;
 } DpPackLayout;
-/* totals (B, n_*, max_*) of the batch into *totals and the block layout into *layout; DP_E_TOOLARGE for a pose over the kernel limits
+/* totals (B, n_*, max_*, n_xs, ph_shared) of the batch into *totals and the block layout into *layout; DP_E_TOOLARGE for a pose over the kernel limits
  * (256 atoms / 256 pharmacophore nodes / 128 torsions) or a batch beyond int32 edge indexing */
 int dp_pack_query(int32_t n, const DpPoseRef* poses, DpBatch* totals, DpPackLayout* layout);
 /* fill a HOST block of layout->bytes: CSR offsets, concatenated static arrays with global ids, one-hots as indices, pharmacophore edges
  * sorted by source (stable), pos / norm.  *flags: bit 0 = a ligand lists the same ordered bond twice (no pair tables), bit 1 / 2 = some
  * pose ends on a short ligand / pharmacophore pass (the no_tail hints).  DP_E_BADARG for a malformed view (not one-hot, ids out of range). */
 int dp_pack_fill(int32_t n, const DpPoseRef* poses, const DpPackLayout* layout, void* host_block, int32_t* flags);
-/* set the pointer fields of *b (and llp / no_tail from `flags`) to a block at `base` - typically the DEVICE copy of the filled block */
+/* set the pointer fields of *b (and llp / no_tail from `flags`) to a block at `base` - typically the DEVICE copy of the filled block.  *b = the totals
+ * dp_pack_query returned (the scalar fields - B, n_*, max_*, n_xs, ph_shared - are not touched here) */
 int dp_pack_bind(const DpPackLayout* layout, void* base, int32_t flags, DpBatch* b);
 
 typedef struct DpMlp { const float *w0, *b0, *w3, *b3; } DpMlp;   /* nn.Sequential(Linear, act, Dropout, Linear) */
